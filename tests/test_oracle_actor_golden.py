@@ -1,0 +1,99 @@
+"""Pin the actor half of the oracle against reference outputs (tests/golden/actor.npz,
+written by tools/gen_golden.py from models/actor.py run in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref, synth
+
+OPT = cpu_ref.default_opt(input_dropout_p=0.0, dropout_p=0.0)
+B, H, W, L = 4, 64, 64, 17
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'actor.npz'))
+
+
+@pytest.fixture(scope='module')
+def sd():
+    return synth.fill_state_dict(cpu_ref.actor_state_skeleton(OPT), seed=7)
+
+
+def test_state_dict_layout(gold, sd):
+    assert list(sd.keys()) == list(gold['sd_keys'])
+    assert [v.numel() for v in sd.values()] == list(gold['sd_numel'])
+    assert sum(v.numel() for k, v in sd.items() if not k.endswith(cpu_ref.NON_PARAM_SUFFIXES)) == 22165917
+
+
+def test_pieces_eval(gold, sd):
+    x = synth.requests(B, L, 41)
+    img = synth.images(B, H, W, 42)
+    with torch.no_grad():
+        enc_out, (h, c) = cpu_ref.lang_encoder(sd, x, OPT)
+        np.testing.assert_allclose(enc_out.numpy(), gold['enc_out'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(h.numpy(), gold['enc_h'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(c.numpy(), gold['enc_c'], rtol=1e-6, atol=1e-7)
+        feat = cpu_ref.image_features(sd, img)
+        np.testing.assert_allclose(feat.numpy(), gold['img_feat_eval'], rtol=1e-5, atol=1e-6)
+        q = synth.uniform((B, 1, 512), 44, -1, 1)
+        ao, aw = cpu_ref.attention(sd, q, enc_out)
+        np.testing.assert_allclose(ao.numpy(), gold['attn_out'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(aw.numpy(), gold['attn_w'], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_episode_and_l1_step(gold, sd, mode):
+    p = 'ep_%s_' % mode
+    leaf = cpu_ref.make_leaf_params(sd)
+    x = synth.requests(B, L, 41)
+    img = synth.images(B, H, W, 42)
+    tgt = synth.images(B, H, W, 43)
+    r = cpu_ref.episode_forward(leaf, x, img, OPT, reinforce_sample=0, training=(mode == 'train'))
+    np.testing.assert_array_equal(r['pred_ops'].numpy(), gold[p + 'pred_ops'])      # indices exact
+    np.testing.assert_allclose(r['logprobs'].detach().numpy(), gold[p + 'logprobs'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r['attns'].detach().numpy(), gold[p + 'attn'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(torch.stack(r['pred_params'], 0).detach().numpy(), gold[p + 'pred_params'],
+                               rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r['pred_imgs'][:, :, :, 8:24, 8:24].detach().numpy(), gold[p + 'imgs_crop'],
+                               rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r['pred_imgs'].detach().double().mean((2, 3, 4)).numpy(), gold[p + 'imgs_mean'],
+                               rtol=1e-6, atol=1e-7)
+    picked = cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], OPT.end_id)
+    loss = cpu_ref.l1_loss(picked, tgt)
+    assert abs(loss.item() - float(gold[p + 'loss'])) < 1e-6
+    loss.backward()
+    names = list(gold['param_names'])
+    gn = np.array([0.0 if leaf[n].grad is None else leaf[n].grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-9)
+    assert [leaf[n].grad is None for n in names] == list(gold[p + 'grad_none'])
+    if mode == 'train':
+        np.testing.assert_allclose(leaf['bn1.running_mean'].numpy(), gold['bn1_running_mean_after'], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_supervised_step(gold, sd, mode):
+    p = 'sup_%s_' % mode
+    leaf = cpu_ref.make_leaf_params(sd)
+    x = synth.requests(B, L, 41)
+    img = synth.images(B, H, W, 42)
+    y = synth.op_targets(B, 45)
+    img_y = synth.uniform((B, 6, 3, H, W), 46)
+    gt_params = synth.uniform((B, 5, 24), 47, -1, 1)
+    nparam = {3: 1, 4: 1, 5: 1, 6: 24, 8: 8, 9: 1}
+    for b in range(B):
+        for k in range(5):
+            gt_params[b, k, nparam[int(y[b, k + 1])]:] = 0
+    pred_imgs, pred_params, logp = cpu_ref.supervised_forward(leaf, x, y, img, img_y, OPT, training=(mode == 'train'))
+    np.testing.assert_allclose(pred_params.detach().numpy(), gold[p + 'pred_params'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logp.detach().numpy(), gold[p + 'logprobs'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().numpy(), gold[p + 'imgs_crop'], rtol=1e-5, atol=1e-5)
+    op_loss, param_loss = cpu_ref.supervised_loss(pred_params, logp, y, gt_params, OPT)
+    assert abs(op_loss.item() - float(gold[p + 'op_loss'])) < 1e-5
+    assert abs(param_loss.item() - float(gold[p + 'param_loss'])) < 1e-5
+    (op_loss + param_loss).backward()
+    names = list(gold['param_names'])
+    gn = np.array([0.0 if leaf[n].grad is None else leaf[n].grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-9)
