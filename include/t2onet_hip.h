@@ -1,0 +1,119 @@
+/* t2onet_hip.h -- C ABI of libt2onet_hip.so, the MI355X (gfx950) implementation of
+ * the T2ONet executor/operator hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI; the interface these entry points
+ * replace is the Python one, cited per function (paths relative to the reference):
+ *     Executor.execute            executors/executor.py:33-55
+ *     Operator.execute / process  models/operators.py:112-131 and the process()
+ *                                 bodies :240-245 :277-283 :351-358 :473-479 :509-511
+ *                                 :571-585 :607-616
+ *     L1 step                     experiments/t2onet/train_seq2seqL1.py:78-85
+ *     Attention.forward           models/attention.py:37-40 (score / softmax / mix)
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, DEVICE pointers: images (B,3,H,W) NCHW RGB in
+ *     [0,1]; params (B,param_stride) rows; masks (B,mask_ch,H,W), mask_ch in {1,3};
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it:
+ *     no allocation, no host synchronisation, safe to capture in a hipGraph;
+ *   - caller-owned scratch: `workspace` of at least t2o_workspace_bytes(B,H,W) bytes;
+ *   - return value: 0 = ok, otherwise a T2O_E* code; t2o_last_error() gives the text
+ *     (thread-local).  Nothing throws.
+ *
+ * Operator indices (executors/executor.py:30):
+ *   0 brightness 1 contrast 2 saturation 3 color-curve 4 inpaint(unsupported)
+ *   5 tone-curve 6 sharpness 7 white;  -1 = identity (executor.py:44-46).
+ */
+#ifndef T2ONET_HIP_H
+#define T2ONET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2O_OK 0
+#define T2O_EINVAL 1        /* bad pointer / shape / stride */
+#define T2O_EUNSUPPORTED 2  /* operator 4 (inpaint) or unknown operator index */
+#define T2O_EWORKSPACE 3    /* workspace too small */
+#define T2O_ELAUNCH 4       /* HIP reported a launch error */
+
+#define T2O_OP_IDENTITY (-1)
+#define T2O_MAX_PARAM 24
+
+int t2o_abi_version(void);
+const char* t2o_last_error(void);
+
+/* number of parameters of operator `op` (Executor.get_param_num, executor.py:61-63); -1 if unknown */
+int t2o_op_num_params(int op);
+
+/* bytes of scratch needed by the *_bwd / *_l1 / sequence calls for images of this shape */
+size_t t2o_workspace_bytes(int B, int H, int W);
+
+/* ---- one operator over a whole (sub)batch: Operator.execute once `param` is known ----
+ * out = clamp(process(img, param) * mask + img * (1 - mask), 0, 1)   (operators.py:128-130)
+ * mask may be NULL (mask_ch = 0).  op = -1 copies img to out (no clamp). */
+int t2o_op_fwd(int op, const float* img, const float* param, int param_stride,
+               const float* mask, int mask_ch, float* out, int B, int H, int W, void* stream);
+
+/* gradient of the above: gimg (nullable) and gparam (B,gparam_stride; first n columns written) */
+int t2o_op_bwd(int op, const float* img, const float* param, int param_stride,
+               const float* mask, int mask_ch, const float* gout,
+               float* gimg, float* gparam, int gparam_stride,
+               void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+
+/* ---- per-sample operators in ONE launch: replaces Actor.divide_op_group + the per-group
+ * execute + index_select regrouping (models/actor.py:100-114, :244-259).
+ * op_id: (B) int32 DEVICE array; param rows padded to param_stride (24 in the actor). */
+int t2o_apply_fwd(const int* op_id, const float* img, const float* param, int param_stride,
+                  const float* mask, int mask_ch, float* out, int B, int H, int W, void* stream);
+int t2o_apply_bwd(const int* op_id, const float* img, const float* param, int param_stride,
+                  const float* mask, int mask_ch, const float* gout,
+                  float* gimg, float* gparam, int gparam_stride,
+                  void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+
+/* ---- L1 loss, train_seq2seqL1.py:85: loss[0] = mean |pred - target| over n floats ---- */
+int t2o_l1_fwd(const float* pred, const float* target, float* loss, size_t n,
+               void* workspace, size_t workspace_bytes, void* stream);
+/* gpred = sign(pred - target) * gloss[0] / n      (gloss: device scalar) */
+int t2o_l1_bwd(const float* pred, const float* target, const float* gloss, float* gpred,
+               size_t n, void* stream);
+
+/* ---- operator fused with the L1 loss on its output (last operator of a sequence) ----
+ * forward also reads `target` and writes loss[0] = mean |out - target|;
+ * backward takes the target instead of gout: gout = sign(out - target) * gloss[0] / (B*3*H*W). */
+int t2o_op_fwd_l1(int op, const float* img, const float* param, int param_stride,
+                  const float* mask, int mask_ch, const float* target, float* out, float* loss,
+                  void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+int t2o_op_bwd_l1(int op, const float* img, const float* param, int param_stride,
+                  const float* mask, int mask_ch, const float* target, const float* gloss,
+                  float* gimg, float* gparam, int gparam_stride,
+                  void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+
+/* ---- a known operator sequence (executor benchmark / planner: utils/beam_search.py:79) ----
+ * ops: K HOST ints; params: (K,B,24) device; acts: (K,B,3,H,W) device, acts[k] = output of
+ * operator k (every intermediate image is materialised, as Executor.execute returns it);
+ * loss[0] = mean |acts[K-1] - target|.  One host call, 2K+2 kernel launches, no sync. */
+int t2o_sequence_fwd(const int* ops, int K, const float* img, const float* params,
+                     const float* target, float* acts, float* loss,
+                     void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+/* gimg (nullable), gparams (K,B,24); gbuf: scratch of 2 images (2,B,3,H,W) */
+int t2o_sequence_bwd(const int* ops, int K, const float* img, const float* params,
+                     const float* target, const float* acts, const float* gloss,
+                     float* gimg, float* gparams, float* gbuf,
+                     void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+
+/* ---- dot-product attention core, models/attention.py:37-40 ----
+ * q (B,D), ctx (B,L,D) -> attn (B,L) = softmax_l(q . ctx_l) over ALL L rows (no padding
+ * mask, as the reference), mix (B,D) = sum_l attn_l ctx_l.   D % 64 == 0, D <= 1024, L <= 64 */
+int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix,
+                 int B, int L, int D, void* stream);
+/* gmix (B,D), gattn (B,L) nullable -> gq (B,D), gctx (B,L,D) */
+int t2o_attn_bwd(const float* q, const float* ctx, const float* attn, const float* gmix,
+                 const float* gattn, float* gq, float* gctx, int B, int L, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2ONET_HIP_H */

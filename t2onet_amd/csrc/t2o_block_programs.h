@@ -1,0 +1,486 @@
+// Block programs: what ONE thread of ONE workgroup does in each kernel phase.
+//
+// The kernels in t2o_kernels.hip are thin wrappers: they map blockIdx/threadIdx
+// to (sample, chunk/tile, tid), call these `__host__ __device__` phase functions
+// with `__syncthreads()` between phases, and do the wave-shuffle reductions.
+// tests/host_emul runs the same phase functions thread by thread on the CPU to
+// check indexing, halos and bounds without a GPU (test harness only).
+//
+// Data layout: images are fp32 NCHW contiguous, RGB in
+// [0,1]; a sample is 3 planes of H*W floats.  Parameters are rows of
+// `param_stride` floats per sample.  Masks are (B,1,H,W) or (B,3,H,W).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "t2o_pixel_math.h"
+
+namespace t2o {
+
+constexpr int kThreads = 256;      // 4 waves of 64
+constexpr int kRedSlots = 24;      // widest per-sample parameter-gradient reduction (color curve)
+
+// Stencil tile: 16 rows x 64 columns per workgroup, thread (ty,tx) owns 4 pixels of one row.
+constexpr int kTileW = 64;
+constexpr int kTileH = 16;
+constexpr int kRowStride = 72;     // floats per LDS row: [..halo][64 interior at +4][halo..], 16-B aligned rows
+constexpr int kIntOff = 4;         // LDS column index of interior column 0
+
+struct OpArgs {
+  // inputs
+  const float* img;        // (B,3,H,W)
+  const float* param;      // (B,param_stride)
+  const float* mask;       // null, (B,1,H,W) or (B,3,H,W)
+  const int* op_id;        // (B) device ints, used when op == OP_DYNAMIC
+  const float* gout;       // backward: gradient w.r.t. the operator output (null when l1 fused)
+  const float* target;     // fused L1: (B,3,H,W) target image, else null
+  const float* gloss;      // fused L1 backward: device scalar d(total)/d(loss)
+  // outputs
+  float* out;              // forward: (B,3,H,W)
+  float* gimg;             // backward: (B,3,H,W) or null
+  float* partials;         // backward: (B, nblk_max, kRedSlots) raw parameter-gradient sums
+  float* loss_partials;    // fused L1 forward: (B, nblk_max)
+  // geometry
+  int op;                  // operator index or OP_DYNAMIC
+  int param_stride;
+  int mask_ch;             // 0, 1 or 3
+  int B, H, W;
+  int iters;               // pointwise: pixel groups per thread
+  int nblk_max;            // stride (in blocks) of partials / loss_partials per sample
+  float inv_n;             // fused L1: 1 / (B*3*H*W)
+};
+
+T2O_HD size_t plane_off(const OpArgs& a, int b, int c) { return ((size_t)b * 3 + c) * (size_t)a.H * a.W; }
+
+T2O_HD float mask_at(const OpArgs& a, int b, int c, size_t px) {
+  const int mc = a.mask_ch == 3 ? c : 0;
+  return a.mask[((size_t)b * a.mask_ch + mc) * (size_t)a.H * a.W + px];
+}
+
+template <int V>
+T2O_HD void load_vec(const float* p, float (&r)[V]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    return;
+  }
+#endif
+  T2O_UNROLL
+  for (int i = 0; i < V; ++i) r[i] = p[i];
+}
+
+template <int V>
+T2O_HD void store_vec(float* p, const float (&r)[V]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    return;
+  }
+#endif
+  T2O_UNROLL
+  for (int i = 0; i < V; ++i) p[i] = r[i];
+}
+
+T2O_HD float sign_of(float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); }
+
+// ===================================================================== pointwise operators
+// Per-sample base pointers + 32-bit offsets inside the sample: keeps the address arithmetic in
+// a handful of scalar registers (a sample is < 2^31 floats).
+struct SampleView {
+  const float* x;      // this sample's 3 input planes
+  const float* g;      // gout, or the L1 target when fused
+  const float* m;      // mask planes (or null)
+  float* o;            // out / gimg planes (or null)
+  const float* t;      // forward fused-L1 target planes (or null)
+  unsigned hw;         // plane stride
+  unsigned mstride;    // hw for a 3-channel mask, 0 for a 1-channel mask
+};
+
+// Forward: one thread, `iters` groups of V consecutive pixels of sample b.
+// Returns this thread's partial sum of |out - target| (0 when not L1).
+template <int V, bool MASKED, bool L1>
+T2O_HD float pointwise_fwd_thread(const OpArgs& a, int op, int b, int blk, int tid) {
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const unsigned groups = hw / V;
+  const size_t sb = (size_t)b * 3 * hw;
+  SampleView s;
+  s.x = a.img + sb;
+  s.o = a.out + sb;
+  s.t = L1 ? a.target + sb : nullptr;
+  s.m = MASKED ? a.mask + (size_t)b * a.mask_ch * hw : nullptr;
+  s.mstride = (MASKED && a.mask_ch == 3) ? hw : 0u;
+  const float* prow = a.param ? a.param + (size_t)b * a.param_stride : nullptr;
+  Curve cv;
+  if (op == OP_COLOR || op == OP_TONE) curve_load(cv, prow, op == OP_COLOR);
+  float p0[1] = {(op >= 0 && prow) ? prow[0] : 0.0f};
+  float l1 = 0.0f;
+  for (int it = 0; it < a.iters; ++it) {
+    const unsigned g = ((unsigned)blk * a.iters + it) * kThreads + tid;
+    if (g >= groups) break;
+    const unsigned px = g * V;
+    float x[3][V], o[3][V], mk[3][V];
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      load_vec<V>(s.x + c * hw + px, x[c]);
+      if (MASKED && (c == 0 || s.mstride)) load_vec<V>(s.m + c * s.mstride + px, mk[c]);
+    }
+    T2O_UNROLL
+    for (int i = 0; i < V; ++i) {
+      Rgb xi = {{x[0][i], x[1][i], x[2][i]}};
+      if (op == OP_IDENTITY) {                       // executor.py:44-46: returned as is, no clamp
+        o[0][i] = xi.c[0]; o[1][i] = xi.c[1]; o[2][i] = xi.c[2];
+      } else {
+        const Rgb r = pointwise_fwd(op, xi, p0, cv);
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) {
+          float z = r.c[c];
+          if (MASKED) z = blend(z, xi.c[c], s.mstride ? mk[c][i] : mk[0][i]);
+          o[c][i] = clamp01(z);
+        }
+      }
+    }
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) store_vec<V>(s.o + c * hw + px, o[c]);
+    if (L1) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        float t[V];
+        load_vec<V>(s.t + c * hw + px, t);
+        T2O_UNROLL
+        for (int i = 0; i < V; ++i) l1 += fabsf(o[c][i] - t[i]);
+      }
+    }
+  }
+  return l1;
+}
+
+// Backward: recompute the forward (for the clamp test), apply the closed-form
+// derivative, write gimg, accumulate raw parameter-gradient sums into red[].
+template <int V, bool MASKED, bool L1>
+T2O_HD void pointwise_bwd_thread(const OpArgs& a, int op, int b, int blk, int tid, float (&red)[kRedSlots]) {
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const unsigned groups = hw / V;
+  const size_t sb = (size_t)b * 3 * hw;
+  SampleView s;
+  s.x = a.img + sb;
+  s.g = (L1 ? a.target : a.gout) + sb;
+  s.o = a.gimg ? a.gimg + sb : nullptr;
+  s.m = MASKED ? a.mask + (size_t)b * a.mask_ch * hw : nullptr;
+  s.mstride = (MASKED && a.mask_ch == 3) ? hw : 0u;
+  const float* prow = a.param ? a.param + (size_t)b * a.param_stride : nullptr;
+  Curve cv;
+  if (op == OP_COLOR || op == OP_TONE) curve_load(cv, prow, op == OP_COLOR);
+  float p0[1] = {(op >= 0 && prow) ? prow[0] : 0.0f};
+  const float gs = L1 ? a.gloss[0] * a.inv_n : 0.0f;
+  for (int it = 0; it < a.iters; ++it) {
+    const unsigned g = ((unsigned)blk * a.iters + it) * kThreads + tid;
+    if (g >= groups) break;
+    const unsigned px = g * V;
+    float x[3][V], gg[3][V], gx[3][V], mk[3][V];
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      load_vec<V>(s.x + c * hw + px, x[c]);
+      load_vec<V>(s.g + c * hw + px, gg[c]);
+      if (MASKED && (c == 0 || s.mstride)) load_vec<V>(s.m + c * s.mstride + px, mk[c]);
+    }
+    if (op == OP_TONE || op == OP_COLOR) {
+      // channels are independent: run the thread's 3V pixel-channels strictly one after another
+      // (dependency chain), so only one channel's 8 segment terms are live at a time
+      const bool color = op == OP_COLOR;
+      float dep = 0.0f;
+      T2O_UNROLL
+      for (int i = 0; i < V; ++i) {
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) {
+          const float xv = T2O_CHAIN(x[c][i], dep);
+          const float r = curve_fwd_1(cv, color, c, xv);
+          const float m = MASKED ? (s.mstride ? mk[c][i] : mk[0][i]) : 1.0f;
+          const float z = MASKED ? blend(r, xv, m) : r;
+          const float gz = L1 ? sign_of(clamp01(z) - gg[c][i]) * gs : gg[c][i];
+          const float dz = (z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
+          const int kc = color ? c : 0;
+          const float gi = curve_bwd_1(cv.k[kc], cv.scale[kc], xv, MASKED ? dz * m : dz, red + kc * kCurveSteps);
+          gx[c][i] = MASKED ? gi + dz * (1.0f - m) : gi;
+          dep = gx[c][i];
+          T2O_UNROLL
+          for (int j = 0; j < kCurveSteps; ++j) T2O_KEEP(red[kc * kCurveSteps + j]);
+        }
+      }
+    } else {
+    T2O_UNROLL
+    for (int i = 0; i < V; ++i) {
+      Rgb xi = {{x[0][i], x[1][i], x[2][i]}};
+      if (op == OP_IDENTITY) {
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) gx[c][i] = L1 ? sign_of(xi.c[c] - gg[c][i]) * gs : gg[c][i];
+        continue;
+      }
+      const Rgb r = pointwise_fwd(op, xi, p0, cv);
+      Rgb go, gpass;
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        const float m = MASKED ? (s.mstride ? mk[c][i] : mk[0][i]) : 1.0f;
+        const float z = MASKED ? blend(r.c[c], xi.c[c], m) : r.c[c];
+        const float gz = L1 ? sign_of(clamp01(z) - gg[c][i]) * gs : gg[c][i];
+        const float dz = (z >= 0.0f && z <= 1.0f) ? gz : 0.0f;     // clamp(0,1) backward, inclusive
+        go.c[c] = MASKED ? dz * m : dz;
+        gpass.c[c] = MASKED ? dz * (1.0f - m) : 0.0f;
+      }
+      const Rgb gi = pointwise_bwd(op, xi, p0, cv, go, red);
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) gx[c][i] = gi.c[c] + gpass.c[c];
+    }
+    }
+    if (s.o) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) store_vec<V>(s.o + c * hw + px, gx[c]);
+    }
+  }
+}
+
+// ===================================================================== sharpness (3x3 stencil)
+// LDS tile of one channel plane: rows of kRowStride floats; interior column j at kIntOff + j.
+// `halo` = 1 (forward, gradient, mask tiles) or 2 (backward image tile).
+T2O_HD int tile_rows(int halo) { return kTileH + 2 * halo; }
+T2O_HD int tile_floats(int halo) { return tile_rows(halo) * kRowStride; }
+
+// Cooperative load of a (kTileH+2*halo) x (kTileW+2*halo) window of `planes` planes
+// starting at plane pointer src (plane stride hw) into lds; zero outside the image.
+// V == 4 (W % 4 == 0): interior as aligned float4 + scalar halo columns; V == 1: scalars.
+template <int V>
+T2O_HD void tile_load(const float* src, size_t hw, int planes, int H, int W, int y0, int x0, int halo,
+                      float* lds, int tid) {
+  const int rows = tile_rows(halo);
+  if (V == 4) {
+    const int per_plane = rows * (kTileW / 4);
+    for (int i = tid; i < planes * per_plane; i += kThreads) {
+      const int c = i / per_plane, rem = i % per_plane;
+      const int r = rem / (kTileW / 4), q = rem % (kTileW / 4);
+      const int gy = y0 - halo + r, gx = x0 + 4 * q;
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (gy >= 0 && gy < H && gx < W) load_vec<4>(src + c * hw + (size_t)gy * W + gx, v);
+      store_vec<4>(lds + c * tile_floats(halo) + r * kRowStride + kIntOff + 4 * q, v);
+    }
+    const int hper = rows * 2 * halo;
+    for (int i = tid; i < planes * hper; i += kThreads) {
+      const int c = i / hper, rem = i % hper;
+      const int r = rem / (2 * halo), k = rem % (2 * halo);
+      const int j = k < halo ? k - halo : kTileW + (k - halo);     // column relative to the tile
+      const int gy = y0 - halo + r, gx = x0 + j;
+      float v = 0.0f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[c * hw + (size_t)gy * W + gx];
+      lds[c * tile_floats(halo) + r * kRowStride + kIntOff + j] = v;
+    }
+  } else {
+    const int cols = kTileW + 2 * halo;
+    const int per_plane = rows * cols;
+    for (int i = tid; i < planes * per_plane; i += kThreads) {
+      const int c = i / per_plane, rem = i % per_plane;
+      const int r = rem / cols, j = rem % cols - halo;
+      const int gy = y0 - halo + r, gx = x0 + j;
+      float v = 0.0f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[c * hw + (size_t)gy * W + gx];
+      lds[c * tile_floats(halo) + r * kRowStride + kIntOff + j] = v;
+    }
+  }
+}
+
+// element (row r, column j) of plane c of a tile with the given halo; r, j relative to the tile origin
+T2O_HD float tile_at(const float* lds, int halo, int c, int r, int j) {
+  return lds[c * tile_floats(halo) + (r + halo) * kRowStride + kIntOff + j];
+}
+
+T2O_HD void tile_origin(const OpArgs& a, int tile, int& y0, int& x0) {
+  const int tiles_x = (a.W + kTileW - 1) / kTileW;
+  y0 = (tile / tiles_x) * kTileH;
+  x0 = (tile % tiles_x) * kTileW;
+}
+T2O_HD int sharp_num_tiles(int H, int W) {
+  return ((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
+}
+
+// ---- forward ----   LDS: [3 planes, halo 1]
+T2O_HD int sharp_fwd_lds_floats() { return 3 * tile_floats(1); }
+
+template <int V>
+T2O_HD void sharp_fwd_phase_load(const OpArgs& a, int b, int tile, int tid, float* lds) {
+  int y0, x0;
+  tile_origin(a, tile, y0, x0);
+  tile_load<V>(a.img + plane_off(a, b, 0), (size_t)a.H * a.W, 3, a.H, a.W, y0, x0, 1, lds, tid);
+}
+
+template <int V>
+T2O_HD float sharp_fwd_phase_compute(const OpArgs& a, int b, int tile, int tid, const float* lds) {
+  int y0, x0;
+  tile_origin(a, tile, y0, x0);
+  const int ty = tid / (kTileW / 4), tx = tid % (kTileW / 4);
+  const int gy = y0 + ty, gx0 = x0 + 4 * tx;
+  if (gy >= a.H || gx0 >= a.W) return 0.0f;
+  const float p = a.param[(size_t)b * a.param_stride];
+  float l1 = 0.0f;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    float o[4];
+    T2O_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * tx + i;
+      const float xc = tile_at(lds, 1, c, ty, j);
+      const float d = sharp_delta(xc, tile_at(lds, 1, c, ty - 1, j), tile_at(lds, 1, c, ty, j - 1),
+                                  tile_at(lds, 1, c, ty, j + 1), tile_at(lds, 1, c, ty + 1, j));
+      float z = xc + p * d;
+      if (a.mask_ch && gx0 + i < a.W) z = blend(z, xc, mask_at(a, b, c, (size_t)gy * a.W + gx0 + i));
+      o[i] = clamp01(z);
+    }
+    float* dst = a.out + plane_off(a, b, c) + (size_t)gy * a.W + gx0;
+    const float* tg = a.target ? a.target + plane_off(a, b, c) + (size_t)gy * a.W + gx0 : nullptr;
+    if (V == 4) {
+      store_vec<4>(dst, o);
+      if (tg) {
+        float t[4];
+        load_vec<4>(tg, t);
+        T2O_UNROLL
+        for (int i = 0; i < 4; ++i) l1 += fabsf(o[i] - t[i]);
+      }
+    } else {
+      for (int i = 0; i < 4 && gx0 + i < a.W; ++i) {
+        dst[i] = o[i];
+        if (tg) l1 += fabsf(o[i] - tg[i]);
+      }
+    }
+  }
+  return l1;
+}
+
+// ---- backward ----  LDS: [X: 3 planes halo 2][G: 3 planes halo 1][M: mask_ch planes halo 1]
+T2O_HD int sharp_bwd_x_off() { return 0; }
+T2O_HD int sharp_bwd_g_off() { return 3 * tile_floats(2); }
+T2O_HD int sharp_bwd_m_off() { return 3 * tile_floats(2) + 3 * tile_floats(1); }
+T2O_HD int sharp_bwd_lds_floats(int mask_ch) { return sharp_bwd_m_off() + mask_ch * tile_floats(1); }
+
+template <int V>
+T2O_HD void sharp_bwd_phase_load(const OpArgs& a, int b, int tile, int tid, float* lds) {
+  int y0, x0;
+  tile_origin(a, tile, y0, x0);
+  const size_t hw = (size_t)a.H * a.W;
+  tile_load<V>(a.img + plane_off(a, b, 0), hw, 3, a.H, a.W, y0, x0, 2, lds + sharp_bwd_x_off(), tid);
+  tile_load<V>((a.target ? a.target : a.gout) + plane_off(a, b, 0), hw, 3, a.H, a.W, y0, x0, 1,
+               lds + sharp_bwd_g_off(), tid);
+  if (a.mask_ch)
+    tile_load<V>(a.mask + (size_t)b * a.mask_ch * hw, hw, a.mask_ch, a.H, a.W, y0, x0, 1,
+                 lds + sharp_bwd_m_off(), tid);
+}
+
+// Phase 2: at every window position (interior + 1-px halo) replace G by
+// dz = [0 <= z <= 1] * gradient of the clamped output, zero outside the image.
+T2O_HD void sharp_bwd_phase_dz(const OpArgs& a, int b, int tile, int tid, float* lds) {
+  int y0, x0;
+  tile_origin(a, tile, y0, x0);
+  const float p = a.param[(size_t)b * a.param_stride];
+  const float gs = a.target ? a.gloss[0] * a.inv_n : 0.0f;
+  const float* X = lds + sharp_bwd_x_off();
+  float* G = lds + sharp_bwd_g_off();
+  const float* M = lds + sharp_bwd_m_off();
+  const int cols = kTileW + 2, rows = kTileH + 2;
+  for (int i = tid; i < rows * cols; i += kThreads) {
+    const int r = i / cols - 1, j = i % cols - 1;
+    const int gy = y0 + r, gx = x0 + j;
+    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      float dz = 0.0f;
+      if (in) {
+        const float xc = tile_at(X, 2, c, r, j);
+        const float d = sharp_delta(xc, tile_at(X, 2, c, r - 1, j), tile_at(X, 2, c, r, j - 1),
+                                    tile_at(X, 2, c, r, j + 1), tile_at(X, 2, c, r + 1, j));
+        float z = xc + p * d;
+        if (a.mask_ch) z = blend(z, xc, tile_at(M, 1, a.mask_ch == 3 ? c : 0, r, j));
+        const float gv = tile_at(G, 1, c, r, j);
+        const float gz = a.target ? sign_of(clamp01(z) - gv) * gs : gv;
+        dz = (z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
+      }
+      G[c * tile_floats(1) + (r + 1) * kRowStride + kIntOff + j] = dz;
+    }
+  }
+}
+
+// Phase 3: gimg = dz (1 - m) + do + p * Laplacian(do), do = dz * m;  red[0] += sum do * Laplacian(x)
+template <int V>
+T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const float* lds, float& red0) {
+  int y0, x0;
+  tile_origin(a, tile, y0, x0);
+  const int ty = tid / (kTileW / 4), tx = tid % (kTileW / 4);
+  const int gy = y0 + ty, gx0 = x0 + 4 * tx;
+  if (gy >= a.H || gx0 >= a.W) return;
+  const float p = a.param[(size_t)b * a.param_stride];
+  const float* X = lds + sharp_bwd_x_off();
+  const float* G = lds + sharp_bwd_g_off();
+  const float* M = lds + sharp_bwd_m_off();
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    const int mc = a.mask_ch == 3 ? c : 0;
+    float o[4];
+    T2O_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * tx + i;
+      float dzc = tile_at(G, 1, c, ty, j), dou = tile_at(G, 1, c, ty - 1, j), dol = tile_at(G, 1, c, ty, j - 1),
+            dor = tile_at(G, 1, c, ty, j + 1), dod = tile_at(G, 1, c, ty + 1, j);
+      float doc = dzc, pass = 0.0f;
+      if (a.mask_ch) {
+        const float m = tile_at(M, 1, mc, ty, j);
+        doc = dzc * m;
+        pass = dzc * (1.0f - m);
+        dou *= tile_at(M, 1, mc, ty - 1, j);
+        dol *= tile_at(M, 1, mc, ty, j - 1);
+        dor *= tile_at(M, 1, mc, ty, j + 1);
+        dod *= tile_at(M, 1, mc, ty + 1, j);
+      }
+      o[i] = pass + (doc + p * sharp_delta(doc, dou, dol, dor, dod));
+      if (gx0 + i < a.W) {
+        const float dx = sharp_delta(tile_at(X, 2, c, ty, j), tile_at(X, 2, c, ty - 1, j), tile_at(X, 2, c, ty, j - 1),
+                                     tile_at(X, 2, c, ty, j + 1), tile_at(X, 2, c, ty + 1, j));
+        red0 += doc * dx;
+      }
+    }
+    if (a.gimg) {
+      float* dst = a.gimg + plane_off(a, b, c) + (size_t)gy * a.W + gx0;
+      if (V == 4) store_vec<4>(dst, o);
+      else for (int i = 0; i < 4 && gx0 + i < a.W; ++i) dst[i] = o[i];
+    }
+  }
+}
+
+// ===================================================================== launch geometry (host)
+struct Geometry {
+  int vec;         // 4 when H*W % 4 == 0 (pointwise kernels use 16-byte accesses)
+  int vec_tile;    // 4 when W % 4 == 0 (stencil kernels)
+  int iters;       // pixel groups per thread (pointwise)
+  int nblk_point;  // workgroups per sample (pointwise)
+  int nblk_sharp;  // tiles per sample (stencil)
+  int nblk_max;    // stride of the per-sample partial-sum rows
+};
+
+inline Geometry geometry(int B, int H, int W, int forced_iters = 0) {
+  Geometry g;
+  const size_t hw = (size_t)H * W;
+  g.vec = (hw % 4 == 0) ? 4 : 1;
+  g.vec_tile = (W % 4 == 0) ? 4 : 1;
+  const size_t groups = hw / g.vec;
+  // aim for >= 16 workgroups per CU (4096 on 256 CUs) before giving a thread more work
+  size_t iters = forced_iters > 0 ? (size_t)forced_iters : (groups * (size_t)B) / ((size_t)kThreads * 4096);
+  if (iters < 1) iters = 1;
+  if (iters > 8) iters = 8;
+  g.iters = (int)iters;
+  g.nblk_point = (int)((groups + (size_t)kThreads * g.iters - 1) / ((size_t)kThreads * g.iters));
+  g.nblk_sharp = sharp_num_tiles(H, W);
+  g.nblk_max = g.nblk_point > g.nblk_sharp ? g.nblk_point : g.nblk_sharp;
+  return g;
+}
+
+// ===================================================================== finalisation
+// partials (B, nblk_max, kRedSlots) -> gparam (B, gparam_stride); one call per sample.
+T2O_HD void finalize_sample(int op, const float* param_row, const float* sums, float* gparam_row) {
+  finalize_param_grad(op, param_row, sums, gparam_row);
+}
+
+}  // namespace t2o

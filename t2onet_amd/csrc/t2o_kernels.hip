@@ -1,0 +1,607 @@
+// libt2onet_hip: gfx950 kernels + C ABI (include/t2onet_hip.h) for the T2ONet
+// executor/operator hot path.  Written for CDNA4 only: wave64, 256-thread
+// workgroups, 16-byte coalesced global accesses, LDS tiles for the stencil,
+// wave-shuffle + LDS reductions, deterministic two-stage parameter-gradient sums
+// (no float atomics), XCD-aware workgroup -> tile mapping.
+//
+// All per-thread arithmetic lives in t2o_pixel_math.h / t2o_block_programs.h;
+// this file is launch geometry, barriers, reductions and argument checking.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/t2onet_hip.h"
+#include "t2o_block_programs.h"
+
+using namespace t2o;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2).  Give every XCD a
+// CONTIGUOUS range of logical work items so neighbouring tiles (shared halo rows) and
+// consecutive chunks of one image meet in the same L2.  Bijective for any total.
+__device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned total) {
+  const unsigned q = total / 8, r = total % 8, xcd = lin % 8, slot = lin / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+// (sample, block-in-sample) of this workgroup, forced into scalar registers: the integer
+// division is lowered through the vector ALU, and without readfirstlane every per-sample
+// parameter load would become a per-lane vector load holding 24+ VGPRs.
+__device__ __forceinline__ void wg_coords(int per_sample, int& b, int& blk) {
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  b = __builtin_amdgcn_readfirstlane((int)(w / (unsigned)per_sample));
+  blk = __builtin_amdgcn_readfirstlane((int)(w % (unsigned)per_sample));
+}
+
+__device__ __forceinline__ int nred_of(int op) { return op == OP_COLOR ? 24 : op == OP_TONE ? 8 : 1; }
+
+// red[0..n) of every thread -> partials row of this block (fixed order => reproducible)
+__device__ __forceinline__ void block_reduce_store(const float (&red)[kRedSlots], int n, float* dst) {
+  __shared__ float sred[kThreads / 64][kRedSlots];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < kRedSlots; ++i) {
+    if (i < n) {
+      const float s = wave_sum(red[i]);
+      if (lane == 0) sred[wave][i] = s;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n)
+    dst[threadIdx.x] = ((sred[0][threadIdx.x] + sred[1][threadIdx.x]) + sred[2][threadIdx.x]) + sred[3][threadIdx.x];
+}
+
+__device__ __forceinline__ void block_reduce_store1(float v, float* dst) {
+  __shared__ float s1[kThreads / 64];
+  const float s = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[0] = ((s1[0] + s1[1]) + s1[2]) + s1[3];
+}
+
+// ------------------------------------------------------------------ pointwise kernels
+// grid: 1-D, B * nblk workgroups (XCD-remapped); each handles `iters` x 256 pixel groups of one sample.
+template <int OP, int V, bool MASKED, bool L1>
+__global__ __launch_bounds__(kThreads) void k_point_fwd(OpArgs a, int nblk) {
+  int b, blk;
+  wg_coords(nblk, b, blk);
+  const int op = (OP == OP_DYNAMIC) ? a.op_id[b] : OP;
+  if (OP == OP_DYNAMIC && op == OP_SHARPNESS) return;      // handled by the stencil kernel
+  float l1 = 0.0f;
+  if (OP == OP_DYNAMIC) {
+    // one specialised body per operator: the kernel's register allocation is the widest
+    // branch, not the union of all of them
+    switch (op) {
+#define T2O_CASE(K) case K: l1 = pointwise_fwd_thread<V, MASKED, L1>(a, K, b, blk, threadIdx.x); break;
+      T2O_CASE(OP_BRIGHTNESS) T2O_CASE(OP_CONTRAST) T2O_CASE(OP_SATURATION) T2O_CASE(OP_COLOR)
+      T2O_CASE(OP_TONE) T2O_CASE(OP_WHITE)
+#undef T2O_CASE
+      default: l1 = pointwise_fwd_thread<V, MASKED, L1>(a, OP_IDENTITY, b, blk, threadIdx.x); break;
+    }
+  } else {
+    l1 = pointwise_fwd_thread<V, MASKED, L1>(a, OP, b, blk, threadIdx.x);
+  }
+  if (L1) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk_max + blk);
+}
+
+template <int OP, int V, bool MASKED, bool L1>
+__global__ __launch_bounds__(kThreads) void k_point_bwd(OpArgs a, int nblk) {
+  int b, blk;
+  wg_coords(nblk, b, blk);
+  const int op = (OP == OP_DYNAMIC) ? a.op_id[b] : OP;
+  if (OP == OP_DYNAMIC && op == OP_SHARPNESS) return;
+  float red[kRedSlots];
+#pragma unroll
+  for (int i = 0; i < kRedSlots; ++i) red[i] = 0.0f;
+  if (OP == OP_DYNAMIC) {
+    switch (op) {
+#define T2O_CASE(K) case K: pointwise_bwd_thread<V, MASKED, L1>(a, K, b, blk, threadIdx.x, red); break;
+      T2O_CASE(OP_BRIGHTNESS) T2O_CASE(OP_CONTRAST) T2O_CASE(OP_SATURATION) T2O_CASE(OP_COLOR)
+      T2O_CASE(OP_TONE) T2O_CASE(OP_WHITE)
+#undef T2O_CASE
+      default: pointwise_bwd_thread<V, MASKED, L1>(a, OP_IDENTITY, b, blk, threadIdx.x, red); break;
+    }
+  } else {
+    pointwise_bwd_thread<V, MASKED, L1>(a, OP, b, blk, threadIdx.x, red);
+  }
+  if (op == OP_IDENTITY || op == OP_WHITE) return;        // no parameter gradient (uniform per block)
+  block_reduce_store(red, nred_of(op), a.partials + ((size_t)b * a.nblk_max + blk) * kRedSlots);
+}
+
+// ------------------------------------------------------------------ sharpness kernels
+// grid: 1-D, B * tiles workgroups; dynamic LDS.
+template <bool DYN, int V>
+__global__ __launch_bounds__(kThreads) void k_sharp_fwd(OpArgs a, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int b, tile;
+  wg_coords(tiles, b, tile);
+  if (DYN && a.op_id[b] != OP_SHARPNESS) return;
+  sharp_fwd_phase_load<V>(a, b, tile, threadIdx.x, lds);
+  __syncthreads();
+  const float l1 = sharp_fwd_phase_compute<V>(a, b, tile, threadIdx.x, lds);
+  if (a.target) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk_max + tile);
+}
+
+template <bool DYN, int V>
+__global__ __launch_bounds__(kThreads) void k_sharp_bwd(OpArgs a, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int b, tile;
+  wg_coords(tiles, b, tile);
+  if (DYN && a.op_id[b] != OP_SHARPNESS) return;
+  sharp_bwd_phase_load<V>(a, b, tile, threadIdx.x, lds);
+  __syncthreads();
+  sharp_bwd_phase_dz(a, b, tile, threadIdx.x, lds);
+  __syncthreads();
+  float red0 = 0.0f;
+  sharp_bwd_phase_out<V>(a, b, tile, threadIdx.x, lds, red0);
+  block_reduce_store1(red0, a.partials + ((size_t)b * a.nblk_max + tile) * kRedSlots);
+}
+
+// ------------------------------------------------------------------ finalisation kernels
+// one wave per sample: sum the per-block raw sums in block order, then raw sums -> gparam
+__global__ __launch_bounds__(64) void k_finalize_params(OpArgs a, float* gparam, int gparam_stride,
+                                                        int nblk_point, int nblk_sharp) {
+  __shared__ float sums[kRedSlots];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
+  float* grow = gparam + (size_t)b * gparam_stride;
+  const int np = op_num_params(op);
+  if (op == OP_IDENTITY || op == OP_WHITE || np == 0) {
+    if (lane < np) grow[lane] = 0.0f;
+    return;
+  }
+  const int n = nred_of(op);
+  const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
+  const float* base = a.partials + (size_t)b * a.nblk_max * kRedSlots;
+  for (int s = 0; s < n; ++s) {
+    float acc = 0.0f;
+    for (int k = lane; k < nb; k += 64) acc += base[(size_t)k * kRedSlots + s];
+    acc = wave_sum(acc);
+    if (lane == 0) sums[s] = acc;
+  }
+  __syncthreads();
+  if (lane == 0) finalize_param_grad(op, a.param + (size_t)b * a.param_stride, sums, grow);
+}
+
+// loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order)
+__global__ __launch_bounds__(kThreads) void k_finalize_loss(OpArgs a, float* loss, int nblk_point, int nblk_sharp) {
+  float acc = 0.0f;
+  for (int b = 0; b < a.B; ++b) {
+    const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
+    const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
+    for (int k = threadIdx.x; k < nb; k += kThreads) acc += a.loss_partials[(size_t)b * a.nblk_max + k];
+  }
+  __shared__ float out1;
+  block_reduce_store1(acc, &out1);
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = out1 * a.inv_n;
+}
+
+// ------------------------------------------------------------------ plain L1 over n floats
+template <int V>
+__global__ __launch_bounds__(kThreads) void k_l1_fwd(const float* pred, const float* target, float* partial,
+                                                     size_t n, int iters) {
+  float acc = 0.0f;
+  for (int it = 0; it < iters; ++it) {
+    const size_t g = ((size_t)blockIdx.x * iters + it) * kThreads + threadIdx.x;
+    if (g * V >= n) break;
+    float p[V], t[V];
+    load_vec<V>(pred + g * V, p);
+    load_vec<V>(target + g * V, t);
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc += fabsf(p[i] - t[i]);
+  }
+  block_reduce_store1(acc, partial + blockIdx.x);
+}
+
+__global__ __launch_bounds__(kThreads) void k_l1_finalize(const float* partial, int nblk, float inv_n, float* loss) {
+  float acc = 0.0f;
+  for (int k = threadIdx.x; k < nblk; k += kThreads) acc += partial[k];
+  __shared__ float out1;
+  block_reduce_store1(acc, &out1);
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = out1 * inv_n;
+}
+
+template <int V>
+__global__ __launch_bounds__(kThreads) void k_l1_bwd(const float* pred, const float* target, const float* gloss,
+                                                     float* gpred, size_t n, float inv_n, int iters) {
+  const float gs = gloss[0] * inv_n;
+  for (int it = 0; it < iters; ++it) {
+    const size_t g = ((size_t)blockIdx.x * iters + it) * kThreads + threadIdx.x;
+    if (g * V >= n) break;
+    float p[V], t[V], o[V];
+    load_vec<V>(pred + g * V, p);
+    load_vec<V>(target + g * V, t);
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = sign_of(p[i] - t[i]) * gs;
+    store_vec<V>(gpred + g * V, o);
+  }
+}
+
+// ------------------------------------------------------------------ attention core
+// One wave per sample.  Lane l (< L) owns score / probability l; every lane owns D/64 columns.
+__global__ __launch_bounds__(kThreads) void k_attn_fwd(const float* q, const float* ctx, float* attn, float* mix,
+                                                       int B, int L, int D) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* qb = q + (size_t)b * D;
+  const float* cb = ctx + (size_t)b * L * D;
+  float mine = -INFINITY;
+  for (int l = 0; l < L; ++l) {
+    float part = 0.0f;
+    for (int e = lane; e < D; e += 64) part += qb[e] * cb[(size_t)l * D + e];
+    const float s = wave_sum(part);
+    if (lane == l) mine = s;
+  }
+  const float mx = wave_max(mine);
+  const float ex = lane < L ? expf(mine - mx) : 0.0f;
+  const float den = wave_sum(ex);
+  const float prob = ex / den;
+  if (lane < L) attn[(size_t)b * L + lane] = prob;
+  for (int e = lane; e < D; e += 64) {
+    float acc = 0.0f;
+    for (int l = 0; l < L; ++l) acc += __shfl(prob, l, 64) * cb[(size_t)l * D + e];
+    mix[(size_t)b * D + e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_attn_bwd(const float* q, const float* ctx, const float* attn,
+                                                       const float* gmix, const float* gattn, float* gq, float* gctx,
+                                                       int B, int L, int D) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* qb = q + (size_t)b * D;
+  const float* cb = ctx + (size_t)b * L * D;
+  const float* gm = gmix + (size_t)b * D;
+  const float prob = lane < L ? attn[(size_t)b * L + lane] : 0.0f;
+  float ga = 0.0f;                                 // d loss / d prob_l on lane l
+  for (int l = 0; l < L; ++l) {
+    float part = 0.0f;
+    for (int e = lane; e < D; e += 64) part += gm[e] * cb[(size_t)l * D + e];
+    const float s = wave_sum(part);
+    if (lane == l) ga = s;
+  }
+  if (gattn && lane < L) ga += gattn[(size_t)b * L + lane];
+  const float dot = wave_sum(prob * ga);
+  const float gs = prob * (ga - dot);              // d loss / d score_l (softmax backward)
+  for (int e = lane; e < D; e += 64) {
+    float acc = 0.0f;
+    const float qe = qb[e], ge = gm[e];
+    for (int l = 0; l < L; ++l) {
+      const float gsl = __shfl(gs, l, 64), pl = __shfl(prob, l, 64);
+      acc += gsl * cb[(size_t)l * D + e];
+      gctx[((size_t)b * L + l) * D + e] = pl * ge + gsl * qe;
+    }
+    gq[(size_t)b * D + e] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ host-side launch logic
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+Geometry launch_geometry(int B, int H, int W) {
+  static const int forced = env_int("T2O_ITERS", 0);   // tuning knob: pixel groups per thread
+  return t2o::geometry(B, H, W, forced);
+}
+
+size_t ws_partials_floats(const Geometry& g, int B) { return (size_t)B * g.nblk_max * kRedSlots; }
+size_t ws_loss_floats(const Geometry& g, int B) { return (size_t)B * g.nblk_max; }
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return T2O_ELAUNCH;
+  }
+  return T2O_OK;
+}
+
+bool op_supported(int op) { return op == OP_IDENTITY || (op >= 0 && op <= 7 && op != OP_INPAINT); }
+
+#define T2O_POINT_OPS(KERNEL, V, M, L)                                                        \
+  switch (op) {                                                                             \
+    case OP_IDENTITY:   KERNEL<OP_IDENTITY, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break;   \
+    case OP_BRIGHTNESS: KERNEL<OP_BRIGHTNESS, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break; \
+    case OP_CONTRAST:   KERNEL<OP_CONTRAST, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break;   \
+    case OP_SATURATION: KERNEL<OP_SATURATION, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break; \
+    case OP_COLOR:      KERNEL<OP_COLOR, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break;      \
+    case OP_TONE:       KERNEL<OP_TONE, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break;       \
+    case OP_WHITE:      KERNEL<OP_WHITE, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break;      \
+    case OP_DYNAMIC:    KERNEL<OP_DYNAMIC, V, M, L><<<grid, kThreads, 0, st>>>(a, nblk); break;    \
+    default: break;                                                                         \
+  }
+#define T2O_POINT_CASES(KERNEL, V)                                    \
+  if (masked) {                                                       \
+    if (l1) { T2O_POINT_OPS(KERNEL, V, true, true) } else { T2O_POINT_OPS(KERNEL, V, true, false) }   \
+  } else {                                                            \
+    if (l1) { T2O_POINT_OPS(KERNEL, V, false, true) } else { T2O_POINT_OPS(KERNEL, V, false, false) } \
+  }
+
+void launch_point_fwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
+  const int op = a.op, nblk = g.nblk_point;
+  const bool masked = a.mask_ch != 0, l1 = a.target != nullptr;
+  const unsigned grid = (unsigned)a.B * nblk;
+  if (g.vec == 4) { T2O_POINT_CASES(k_point_fwd, 4) } else { T2O_POINT_CASES(k_point_fwd, 1) }
+}
+void launch_point_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
+  const int op = a.op, nblk = g.nblk_point;
+  const bool masked = a.mask_ch != 0, l1 = a.target != nullptr;
+  const unsigned grid = (unsigned)a.B * nblk;
+  if (g.vec == 4) { T2O_POINT_CASES(k_point_bwd, 4) } else { T2O_POINT_CASES(k_point_bwd, 1) }
+}
+void launch_sharp_fwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
+  const unsigned grid = (unsigned)a.B * g.nblk_sharp;
+  const size_t lds = sizeof(float) * sharp_fwd_lds_floats();
+  const bool dyn = a.op == OP_DYNAMIC;
+  if (g.vec_tile == 4) {
+    if (dyn) k_sharp_fwd<true, 4><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+    else k_sharp_fwd<false, 4><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+  } else {
+    if (dyn) k_sharp_fwd<true, 1><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+    else k_sharp_fwd<false, 1><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+  }
+}
+void launch_sharp_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
+  const unsigned grid = (unsigned)a.B * g.nblk_sharp;
+  const size_t lds = sizeof(float) * sharp_bwd_lds_floats(a.mask_ch);
+  const bool dyn = a.op == OP_DYNAMIC;
+  if (g.vec_tile == 4) {
+    if (dyn) k_sharp_bwd<true, 4><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+    else k_sharp_bwd<false, 4><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+  } else {
+    if (dyn) k_sharp_bwd<true, 1><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+    else k_sharp_bwd<false, 1><<<grid, kThreads, lds, st>>>(a, g.nblk_sharp);
+  }
+}
+
+int check_common(int op, const int* op_id, const float* img, const float* param, int param_stride,
+                 const float* mask, int mask_ch, int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return fail(T2O_EINVAL, "B, H, W must be positive");
+  if (!img) return fail(T2O_EINVAL, "img is null");
+  if (op == OP_DYNAMIC) {
+    if (!op_id) return fail(T2O_EINVAL, "op_id is null");
+    if (!param || param_stride < kMaxParam) return fail(T2O_EINVAL, "apply: param rows must be padded to >= 24 floats");
+  } else {
+    if (!op_supported(op)) return fail(T2O_EUNSUPPORTED, "operator index not supported (4 = inpaint needs EdgeConnect)");
+    if (op >= 0 && op != OP_WHITE && (!param || param_stride < op_num_params(op)))
+      return fail(T2O_EINVAL, "param is null or param_stride < number of operator parameters");
+  }
+  if ((mask == nullptr) != (mask_ch == 0) || !(mask_ch == 0 || mask_ch == 1 || mask_ch == 3))
+    return fail(T2O_EINVAL, "mask_ch must be 0 (mask NULL), 1 or 3");
+  if ((size_t)B * (size_t)sharp_num_tiles(H, W) > 0x7fffffffull || (size_t)H * W / 1 > 0x7fffffffull)
+    return fail(T2O_EINVAL, "image too large for the launch grid");
+  return T2O_OK;
+}
+
+// forward of one operator (static or per-sample), optionally fused with the L1 loss
+int run_fwd(int op, const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
+            int mask_ch, const float* target, float* out, float* loss, void* ws, size_t ws_bytes, int B, int H, int W,
+            void* stream) {
+  if (int rc = check_common(op, op_id, img, param, param_stride, mask, mask_ch, B, H, W)) return rc;
+  if (!out) return fail(T2O_EINVAL, "out is null");
+  const Geometry g = launch_geometry(B, H, W);
+  OpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.img = img; a.param = param; a.mask = mask; a.op_id = op_id; a.target = target; a.out = out;
+  a.op = op; a.param_stride = param_stride; a.mask_ch = mask_ch; a.B = B; a.H = H; a.W = W;
+  a.iters = g.iters; a.nblk_max = g.nblk_max;
+  a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
+  if (target) {
+    if (!loss) return fail(T2O_EINVAL, "loss is null");
+    if (!ws || ws_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
+    a.loss_partials = (float*)ws + ws_partials_floats(g, B);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (op != OP_SHARPNESS) launch_point_fwd(a, g, st);
+  if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_fwd(a, g, st);
+  if (target) k_finalize_loss<<<1, kThreads, 0, st>>>(a, loss, g.nblk_point, g.nblk_sharp);
+  return check_launch("operator forward");
+}
+
+int run_bwd(int op, const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
+            int mask_ch, const float* gout, const float* target, const float* gloss, float* gimg, float* gparam,
+            int gparam_stride, void* ws, size_t ws_bytes, int B, int H, int W, void* stream) {
+  if (int rc = check_common(op, op_id, img, param, param_stride, mask, mask_ch, B, H, W)) return rc;
+  if (!target && !gout) return fail(T2O_EINVAL, "gout is null");
+  if (target && !gloss) return fail(T2O_EINVAL, "gloss is null");
+  if (!ws || ws_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
+  if (gparam && gparam_stride < (op == OP_DYNAMIC ? kMaxParam : op_num_params(op)))
+    return fail(T2O_EINVAL, "gparam_stride too small");
+  const Geometry g = launch_geometry(B, H, W);
+  OpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.img = img; a.param = param; a.mask = mask; a.op_id = op_id; a.gout = gout; a.target = target; a.gloss = gloss;
+  a.gimg = gimg; a.partials = (float*)ws;
+  a.op = op; a.param_stride = param_stride; a.mask_ch = mask_ch; a.B = B; a.H = H; a.W = W;
+  a.iters = g.iters; a.nblk_max = g.nblk_max;
+  a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
+  hipStream_t st = (hipStream_t)stream;
+  if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
+  if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_bwd(a, g, st);
+  if (gparam && op != OP_IDENTITY)
+    k_finalize_params<<<B, 64, 0, st>>>(a, gparam, gparam_stride, g.nblk_point, g.nblk_sharp);
+  return check_launch("operator backward");
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+extern "C" {
+
+int t2o_abi_version(void) { return 1; }
+const char* t2o_last_error(void) { return g_err; }
+
+int t2o_op_num_params(int op) { return (op >= 0 && op <= 7) ? op_num_params(op) : -1; }
+
+size_t t2o_workspace_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  const Geometry g = launch_geometry(B, H, W);
+  size_t f = ws_partials_floats(g, B) + ws_loss_floats(g, B);
+  // plain L1 over the same number of floats uses the partial area too
+  const size_t n = (size_t)B * 3 * H * W;
+  const size_t l1blk = n / ((size_t)kThreads * 8) + 2;      // k_l1_fwd partials, worst case V = 1
+  if (f < l1blk) f = l1blk;
+  return f * sizeof(float);
+}
+
+int t2o_op_fwd(int op, const float* img, const float* param, int param_stride, const float* mask, int mask_ch,
+               float* out, int B, int H, int W, void* stream) {
+  if (op == OP_DYNAMIC) return fail(T2O_EUNSUPPORTED, "use t2o_apply_fwd for per-sample operators");
+  return run_fwd(op, nullptr, img, param, param_stride, mask, mask_ch, nullptr, out, nullptr, nullptr, 0, B, H, W, stream);
+}
+
+int t2o_op_bwd(int op, const float* img, const float* param, int param_stride, const float* mask, int mask_ch,
+               const float* gout, float* gimg, float* gparam, int gparam_stride, void* workspace,
+               size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (op == OP_DYNAMIC) return fail(T2O_EUNSUPPORTED, "use t2o_apply_bwd for per-sample operators");
+  return run_bwd(op, nullptr, img, param, param_stride, mask, mask_ch, gout, nullptr, nullptr, gimg, gparam,
+                 gparam_stride, workspace, workspace_bytes, B, H, W, stream);
+}
+
+int t2o_apply_fwd(const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
+                  int mask_ch, float* out, int B, int H, int W, void* stream) {
+  return run_fwd(OP_DYNAMIC, op_id, img, param, param_stride, mask, mask_ch, nullptr, out, nullptr, nullptr, 0, B, H, W,
+                 stream);
+}
+
+int t2o_apply_bwd(const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
+                  int mask_ch, const float* gout, float* gimg, float* gparam, int gparam_stride, void* workspace,
+                  size_t workspace_bytes, int B, int H, int W, void* stream) {
+  return run_bwd(OP_DYNAMIC, op_id, img, param, param_stride, mask, mask_ch, gout, nullptr, nullptr, gimg, gparam,
+                 gparam_stride, workspace, workspace_bytes, B, H, W, stream);
+}
+
+int t2o_op_fwd_l1(int op, const float* img, const float* param, int param_stride, const float* mask, int mask_ch,
+                  const float* target, float* out, float* loss, void* workspace, size_t workspace_bytes, int B, int H,
+                  int W, void* stream) {
+  if (!target) return fail(T2O_EINVAL, "target is null");
+  if (op == OP_DYNAMIC) return fail(T2O_EUNSUPPORTED, "fused L1 takes a static operator");
+  return run_fwd(op, nullptr, img, param, param_stride, mask, mask_ch, target, out, loss, workspace, workspace_bytes, B,
+                 H, W, stream);
+}
+
+int t2o_op_bwd_l1(int op, const float* img, const float* param, int param_stride, const float* mask, int mask_ch,
+                  const float* target, const float* gloss, float* gimg, float* gparam, int gparam_stride,
+                  void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (!target) return fail(T2O_EINVAL, "target is null");
+  if (op == OP_DYNAMIC) return fail(T2O_EUNSUPPORTED, "fused L1 takes a static operator");
+  return run_bwd(op, nullptr, img, param, param_stride, mask, mask_ch, nullptr, target, gloss, gimg, gparam,
+                 gparam_stride, workspace, workspace_bytes, B, H, W, stream);
+}
+
+int t2o_l1_fwd(const float* pred, const float* target, float* loss, size_t n, void* workspace, size_t workspace_bytes,
+               void* stream) {
+  if (!pred || !target || !loss || n == 0) return fail(T2O_EINVAL, "l1_fwd: null pointer or n == 0");
+  const int V = (n % 4 == 0) ? 4 : 1;
+  const int iters = 8;
+  const size_t groups = n / V;
+  const size_t nblk = (groups + (size_t)kThreads * iters - 1) / ((size_t)kThreads * iters);
+  if (!workspace || workspace_bytes < nblk * sizeof(float)) return fail(T2O_EWORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  if (V == 4) k_l1_fwd<4><<<(unsigned)nblk, kThreads, 0, st>>>(pred, target, partial, n, iters);
+  else k_l1_fwd<1><<<(unsigned)nblk, kThreads, 0, st>>>(pred, target, partial, n, iters);
+  k_l1_finalize<<<1, kThreads, 0, st>>>(partial, (int)nblk, 1.0f / (float)n, loss);
+  return check_launch("l1 forward");
+}
+
+int t2o_l1_bwd(const float* pred, const float* target, const float* gloss, float* gpred, size_t n, void* stream) {
+  if (!pred || !target || !gloss || !gpred || n == 0) return fail(T2O_EINVAL, "l1_bwd: null pointer or n == 0");
+  const int V = (n % 4 == 0) ? 4 : 1;
+  const int iters = 4;
+  const size_t groups = n / V;
+  const size_t nblk = (groups + (size_t)kThreads * iters - 1) / ((size_t)kThreads * iters);
+  hipStream_t st = (hipStream_t)stream;
+  if (V == 4) k_l1_bwd<4><<<(unsigned)nblk, kThreads, 0, st>>>(pred, target, gloss, gpred, n, 1.0f / (float)n, iters);
+  else k_l1_bwd<1><<<(unsigned)nblk, kThreads, 0, st>>>(pred, target, gloss, gpred, n, 1.0f / (float)n, iters);
+  return check_launch("l1 backward");
+}
+
+int t2o_sequence_fwd(const int* ops, int K, const float* img, const float* params, const float* target, float* acts,
+                     float* loss, void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (!ops || K <= 0 || !params || !acts) return fail(T2O_EINVAL, "sequence_fwd: null pointer or K <= 0");
+  const size_t img_floats = (size_t)B * 3 * H * W;
+  const float* cur = img;
+  for (int k = 0; k < K; ++k) {
+    float* out = acts + (size_t)k * img_floats;
+    const float* p = params + (size_t)k * B * kMaxParam;
+    const bool last = (k == K - 1) && target;
+    const int rc = run_fwd(ops[k], nullptr, cur, p, kMaxParam, nullptr, 0, last ? target : nullptr, out,
+                           last ? loss : nullptr, workspace, workspace_bytes, B, H, W, stream);
+    if (rc) return rc;
+    cur = out;
+  }
+  return T2O_OK;
+}
+
+int t2o_sequence_bwd(const int* ops, int K, const float* img, const float* params, const float* target,
+                     const float* acts, const float* gloss, float* gimg, float* gparams, float* gbuf, void* workspace,
+                     size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (!ops || K <= 0 || !params || !acts || !target || !gloss || !gparams || !gbuf)
+    return fail(T2O_EINVAL, "sequence_bwd: null pointer or K <= 0");
+  const size_t img_floats = (size_t)B * 3 * H * W;
+  const float* gcur = nullptr;
+  for (int k = K - 1; k >= 0; --k) {
+    const float* in = k == 0 ? img : acts + (size_t)(k - 1) * img_floats;
+    const float* p = params + (size_t)k * B * kMaxParam;
+    float* gp = gparams + (size_t)k * B * kMaxParam;
+    float* gout_next = (k == 0) ? gimg : gbuf + (size_t)(k & 1) * img_floats;
+    int rc;
+    if (k == K - 1)
+      rc = run_bwd(ops[k], nullptr, in, p, kMaxParam, nullptr, 0, nullptr, target, gloss, gout_next, gp, kMaxParam,
+                   workspace, workspace_bytes, B, H, W, stream);
+    else
+      rc = run_bwd(ops[k], nullptr, in, p, kMaxParam, nullptr, 0, gcur, nullptr, nullptr, gout_next, gp, kMaxParam,
+                   workspace, workspace_bytes, B, H, W, stream);
+    if (rc) return rc;
+    gcur = gout_next;
+  }
+  return T2O_OK;
+}
+
+int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix, int B, int L, int D, void* stream) {
+  if (!q || !ctx || !attn || !mix) return fail(T2O_EINVAL, "attn_fwd: null pointer");
+  if (B <= 0 || L <= 0 || L > 64 || D <= 0 || D % 64 != 0 || D > 1024)
+    return fail(T2O_EINVAL, "attn: need 1 <= L <= 64, D % 64 == 0, D <= 1024");
+  const unsigned grid = (unsigned)((B + kThreads / 64 - 1) / (kThreads / 64));
+  k_attn_fwd<<<grid, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, mix, B, L, D);
+  return check_launch("attention forward");
+}
+
+int t2o_attn_bwd(const float* q, const float* ctx, const float* attn, const float* gmix, const float* gattn, float* gq,
+                 float* gctx, int B, int L, int D, void* stream) {
+  if (!q || !ctx || !attn || !gmix || !gq || !gctx) return fail(T2O_EINVAL, "attn_bwd: null pointer");
+  if (B <= 0 || L <= 0 || L > 64 || D <= 0 || D % 64 != 0 || D > 1024)
+    return fail(T2O_EINVAL, "attn: need 1 <= L <= 64, D % 64 == 0, D <= 1024");
+  const unsigned grid = (unsigned)((B + kThreads / 64 - 1) / (kThreads / 64));
+  k_attn_bwd<<<grid, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, gmix, gattn, gq, gctx, B, L, D);
+  return check_launch("attention backward");
+}
+
+}  // extern "C"

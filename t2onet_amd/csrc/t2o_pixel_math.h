@@ -1,0 +1,403 @@
+// Per-pixel arithmetic of the T2ONet edit operators, forward and backward.
+//
+// Every function here is `__host__ __device__`: the HIP kernels in
+// t2o_kernels.hip are the product path; tests/host_emul compiles the SAME
+// functions with g++ so the arithmetic can be checked against the oracle on a
+// machine without a GPU.  (That host build is a test harness, never a fallback:
+// the Python package refuses to run without the HIP library.)
+//
+// Forward functions follow the reference's operation ORDER step for step, one
+// fp32 rounding per step (build with -ffp-contract=off), so results track the
+// reference's eager fp32 path to the last bit or two:
+//   brightness  models/operators.py:277-283  (+ HSV spec: oracle/hsv_spec.py)
+//   contrast    models/operators.py:240-245, utils/operator_utils.py:5-11
+//   saturation  models/operators.py:473-479
+//   color curve models/operators.py:607-616
+//   tone curve  models/operators.py:571-585
+//   sharpness   models/operators.py:351-358
+//   white       models/operators.py:509-511
+//   epilogue    models/operators.py:129-130 (mask blend + clamp)
+// Backward functions are the closed-form derivatives of those formulas with
+// PyTorch's conventions (clamp passes the gradient on [lo,hi] inclusive;
+// max/min over channels route to one index).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define T2O_HD __host__ __device__ __forceinline__
+#define T2O_UNROLL _Pragma("unroll")
+#else
+#define T2O_HD static inline
+#define T2O_UNROLL
+#endif
+
+// Register-pressure controls for the gfx950 build (no-ops on the host).  hipcc freely reorders
+// and defers a thread's independent pixel-channels for ILP; for the curve operators that keeps
+// the 8 segment terms of all 12 pixel-channels live (256 VGPRs, 1 wave per SIMD).  These three
+// empty-asm helpers pin the order instead.
+#if defined(__HIP_DEVICE_COMPILE__)
+// v through an empty asm: the optimiser cannot see it is the same value, so cheap terms are
+// RECOMPUTED where they are needed again rather than kept live.
+__device__ __forceinline__ float t2o_opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+// v, made to depend on `dep`: work on v cannot start before dep has been computed.
+__device__ __forceinline__ float t2o_chain(float v, float dep) { asm volatile("" : "+v"(v) : "v"(dep)); return v; }
+#define T2O_OPAQUE(v) t2o_opaque(v)
+#define T2O_CHAIN(v, dep) t2o_chain(v, dep)
+// v must have been computed by this point (volatile asms keep their order): stops accumulations
+// from being deferred with their inputs held in registers.
+#define T2O_KEEP(v) asm volatile("" ::"v"(v))
+#else
+#define T2O_OPAQUE(v) (v)
+#define T2O_CHAIN(v, dep) (v)
+#define T2O_KEEP(v) ((void)0)
+#endif
+
+namespace t2o {
+
+enum : int {
+  OP_IDENTITY = -1,
+  OP_BRIGHTNESS = 0,
+  OP_CONTRAST = 1,
+  OP_SATURATION = 2,
+  OP_COLOR = 3,
+  OP_INPAINT = 4,   // needs the EdgeConnect network: not a per-pixel operator, unsupported
+  OP_TONE = 5,
+  OP_SHARPNESS = 6,
+  OP_WHITE = 7,
+  OP_DYNAMIC = -2   // kernels only: read the operator of each sample from op_id[b]
+};
+
+constexpr int kCurveSteps = 8;    // options/seq2seqGAN_base_options.py:87
+constexpr int kMaxParam = 24;     // 3 x kCurveSteps, also the padded width in actor.py:166
+constexpr float kHsvEps = 1e-6f;  // oracle/hsv_spec.py HSV_EPS
+constexpr float kTwoPi = 6.283185307179586f;
+constexpr float kPi = 3.141592653589793f;
+
+T2O_HD int op_num_params(int op) {
+  return op == OP_COLOR ? 24 : op == OP_TONE ? 8 : (op >= 0 && op <= 7) ? 1 : 0;
+}
+
+T2O_HD float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+// torch.remainder(x, 6) for x in [0, 12)
+T2O_HD float rem6(float x) { return x >= 6.0f ? x - 6.0f : x; }
+
+struct Rgb {
+  float c[3];
+};
+
+// r.c[idx] += v without dynamic register indexing (which would spill to scratch)
+T2O_HD void add_at(Rgb& r, int idx, float v) {
+  r.c[0] += (idx == 0) ? v : 0.0f;
+  r.c[1] += (idx == 1) ? v : 0.0f;
+  r.c[2] += (idx == 2) ? v : 0.0f;
+}
+
+// ---------------------------------------------------------------- HSV (oracle/hsv_spec.py)
+struct Hsv {
+  float h, s, v;
+};
+
+T2O_HD Hsv rgb_to_hsv(float r, float g, float b) {
+  float maxc = r;
+  int arg = 0;
+  if (g > maxc) { maxc = g; arg = 1; }
+  if (b > maxc) { maxc = b; arg = 2; }
+  const float minc = fminf(r, fminf(g, b));
+  const float delta = maxc - minc;
+  Hsv o;
+  o.v = maxc;
+  o.s = delta / (maxc + kHsvEps);
+  const float ds = (delta == 0.0f) ? 1.0f : delta;
+  const float rc = maxc - r, gc = maxc - g, bc = maxc - b;
+  float hn;
+  if (arg == 0) hn = bc - gc;
+  else if (arg == 1) hn = (rc - bc) + 2.0f * ds;
+  else hn = (gc - rc) + 4.0f * ds;
+  float h = hn / ds;
+  h = h / 6.0f;
+  h = h - truncf(h);            // fmod(h, 1)
+  if (h < 0.0f) h += 1.0f;      // torch.remainder sign fix-up
+  o.h = kTwoPi * h;
+  return o;
+}
+
+T2O_HD Rgb hsv_to_rgb(float H, float s, float v) {
+  const float h = H / kTwoPi;
+  const float h6 = h * 6.0f;
+  const float hi = rem6(floorf(h6));
+  const float f = rem6(h6) - hi;
+  const float p = v * (1.0f - s);
+  const float q = v * (1.0f - f * s);
+  const float t = v * (1.0f - (1.0f - f) * s);
+  const int k = (int)hi;
+  Rgb o;
+  //                 sector 0        1        2        3        4        5
+  o.c[0] = k == 0 ? v : k == 1 ? q : k == 2 ? p : k == 3 ? p : k == 4 ? t : v;
+  o.c[1] = k == 0 ? t : k == 1 ? v : k == 2 ? v : k == 3 ? q : k == 4 ? p : p;
+  o.c[2] = k == 0 ? p : k == 1 ? p : k == 2 ? t : k == 3 ? v : k == 4 ? v : q;
+  return o;
+}
+
+// ---------------------------------------------------------------- curve parameters
+// One sample's curve, loaded once per block (wave-uniform -> scalar registers).
+struct Curve {
+  float k[3][kCurveSteps];  // tone: the three rows are the same curve
+  float sum[3];             // sum_i k_i + 1e-10
+  float scale[3];           // d out / d total = 8 / sum
+};
+
+T2O_HD void curve_load(Curve& cv, const float* p, bool color) {
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    const float* row = color ? p + c * kCurveSteps : p;
+    float s = 0.0f;
+    T2O_UNROLL
+  for (int i = 0; i < kCurveSteps; ++i) {
+      cv.k[c][i] = row[i];
+      s = s + row[i];
+    }
+    s = s + 1e-10f;
+    cv.sum[c] = s;
+    cv.scale[c] = (1.0f / s) * (float)kCurveSteps;   // torch: n / tensor == reciprocal(tensor) * n
+  }
+}
+
+T2O_HD float curve_total(const float k[kCurveSteps], float x) {
+  float total = 0.0f;
+  T2O_UNROLL
+  for (int i = 0; i < kCurveSteps; ++i) {
+    const float t = fminf(fmaxf(x - (float)i / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+    total = total + t * k[i];
+  }
+  return total;
+}
+
+// ---------------------------------------------------------------- forward, per pixel
+// `process()` of the pointwise operators.  p = this sample's parameter row.
+T2O_HD Rgb brightness_fwd(const Rgb& x, float p) {
+  const Hsv a = rgb_to_hsv(x.c[0], x.c[1], x.c[2]);
+  const float v2 = clamp01(a.v * (1.0f + p));
+  return hsv_to_rgb(a.h, a.s, v2);
+}
+
+T2O_HD Rgb saturation_fwd(const Rgb& x, float p) {
+  const Hsv a = rgb_to_hsv(x.c[0], x.c[1], x.c[2]);
+  const float s2 = clamp01(a.s * (1.0f + p));
+  return hsv_to_rgb(a.h, s2, a.v);
+}
+
+T2O_HD float luminance(const Rgb& x) { return (0.27f * x.c[0] + 0.67f * x.c[1]) + 0.06f * x.c[2]; }
+
+T2O_HD Rgb contrast_fwd(const Rgb& x, float p) {
+  const float L = fminf(fmaxf(luminance(x), 0.0f), 1.0f);
+  const float cl = (-cosf(kPi * L)) * 0.5f + 0.5f;
+  const float Le = L + 1e-6f;
+  const float om = 1.0f - p;
+  Rgb o;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    const float ci = (x.c[c] / Le) * cl;
+    o.c[c] = om * x.c[c] + p * ci;
+  }
+  return o;
+}
+
+// one channel of the tone (shared curve) / color (per-channel curve) operator
+T2O_HD float curve_fwd_1(const Curve& cv, bool color, int c, float x) {
+  return color ? curve_total(cv.k[c], x) * cv.scale[c]
+               : (curve_total(cv.k[0], x) * (float)kCurveSteps) / cv.sum[0];
+}
+
+T2O_HD Rgb tone_fwd(const Rgb& x, const Curve& cv) {
+  Rgb o;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c)
+    o.c[c] = (curve_total(cv.k[0], x.c[c]) * (float)kCurveSteps) / cv.sum[0];
+  return o;
+}
+
+T2O_HD Rgb color_fwd(const Rgb& x, const Curve& cv) {
+  Rgb o;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) o.c[c] = curve_total(cv.k[c], x.c[c]) * cv.scale[c];
+  return o;
+}
+
+// 3x3 Laplacian-style kernel [[0,-1,0],[-1,4,-1],[0,-1,0]], row-major accumulation
+T2O_HD float sharp_delta(float c, float up, float left, float right, float down) {
+  return ((((-up) - left) + 4.0f * c) - right) - down;
+}
+
+// Operator.execute epilogue: blend with the mask, clamp.  z is the pre-clamp value.
+T2O_HD float blend(float o, float x, float m) { return o * m + x * (1.0f - m); }
+
+// Pointwise dispatcher (everything except sharpness / identity).
+T2O_HD Rgb pointwise_fwd(int op, const Rgb& x, const float* p, const Curve& cv) {
+  switch (op) {
+    case OP_BRIGHTNESS: return brightness_fwd(x, p[0]);
+    case OP_CONTRAST:   return contrast_fwd(x, p[0]);
+    case OP_SATURATION: return saturation_fwd(x, p[0]);
+    case OP_COLOR:      return color_fwd(x, cv);
+    case OP_TONE:       return tone_fwd(x, cv);
+    case OP_WHITE: { Rgb o; o.c[0] = o.c[1] = o.c[2] = 1.0f; return o; }
+    default:            return x;
+  }
+}
+
+// ---------------------------------------------------------------- backward, per pixel
+// g  = gradient w.r.t. the operator's process() output at this pixel
+// gx = gradient w.r.t. the input pixel THROUGH process() (the caller adds the mask path)
+// red[] accumulates this sample's parameter-gradient raw sums:
+//   1-parameter ops: red[0] += d loss / d p
+//   tone:            red[i]      += g * t_i(x)            (i < 8, all channels)
+//   color:           red[8c + i] += g_c * t_i(x_c)
+// (curve raw sums are turned into gradients by curve_param_grad below.)
+T2O_HD void argmaxmin(const Rgb& x, int& amax, int& amin, float& vmax, float& vmin) {
+  vmax = x.c[0]; amax = 0;
+  if (x.c[1] > vmax) { vmax = x.c[1]; amax = 1; }
+  if (x.c[2] > vmax) { vmax = x.c[2]; amax = 2; }
+  vmin = x.c[0]; amin = 0;
+  if (x.c[1] < vmin) { vmin = x.c[1]; amin = 1; }
+  if (x.c[2] < vmin) { vmin = x.c[2]; amin = 2; }
+}
+
+// out_c = v' (x_c + eps) / (v + eps),  v' = clamp(v (1 + p), 0, 1)
+T2O_HD Rgb brightness_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
+  int amax, amin; float v, mn;
+  argmaxmin(x, amax, amin, v, mn);
+  const float ve = v + kHsvEps;
+  const float t = v * (1.0f + p);
+  float a, da_dv, da_dp;
+  if (t < 0.0f)      { a = 0.0f; da_dv = 0.0f; da_dp = 0.0f; }
+  else if (t > 1.0f) { a = 1.0f / ve; da_dv = -a / ve; da_dp = 0.0f; }
+  else               { a = t / ve; da_dv = (1.0f + p) * kHsvEps / (ve * ve); da_dp = v / ve; }
+  const float S = g.c[0] * (x.c[0] + kHsvEps) + g.c[1] * (x.c[1] + kHsvEps) + g.c[2] * (x.c[2] + kHsvEps);
+  Rgb gx;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) gx.c[c] = a * g.c[c];
+  add_at(gx, amax, S * da_dv);
+  red[0] += S * da_dp;
+  return gx;
+}
+
+// out_c = v (1 - s' (v - x_c) / delta),  s' = clamp(s (1 + p), 0, 1),  s = delta / (v + eps)
+T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
+  int amax, amin; float v, mn;
+  argmaxmin(x, amax, amin, v, mn);
+  const float ve = v + kHsvEps;
+  const float delta = v - mn;
+  const float s = delta / ve;
+  const float t = s * (1.0f + p);
+  const float u0 = v - x.c[0], u1 = v - x.c[1], u2 = v - x.c[2];
+  const float G = g.c[0] + g.c[1] + g.c[2];
+  const float GU = g.c[0] * u0 + g.c[1] * u1 + g.c[2] * u2;
+  Rgb gx;
+  if (t < 0.0f) {                       // s' = 0: every channel becomes v
+    gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
+    add_at(gx, amax, G);
+  } else if (t > 1.0f) {                // s' = 1 (needs delta > 0)
+    const float vd = v / delta;
+    T2O_UNROLL
+  for (int c = 0; c < 3; ++c) gx.c[c] = vd * g.c[c];
+    add_at(gx, amax, G * (1.0f - vd) + GU * (vd - 1.0f) / delta);
+    add_at(gx, amin, -GU * vd / delta);
+  } else {                              // s' = s (1 + p)
+    const float b = v * (1.0f + p) / ve;
+    const float db = (1.0f + p) * kHsvEps / (ve * ve);
+    T2O_UNROLL
+  for (int c = 0; c < 3; ++c) gx.c[c] = b * g.c[c];
+    add_at(gx, amax, G * (1.0f - b) - GU * db);
+    red[0] += -GU * (v / ve);
+  }
+  return gx;
+}
+
+// out_c = x_c ((1 - p) + p q(L)),  q = cl(L) / (L + 1e-6)
+T2O_HD Rgb contrast_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
+  const float lum = luminance(x);
+  const float L = fminf(fmaxf(lum, 0.0f), 1.0f);
+  const bool inside = (lum > 0.0f) && (lum < 1.0f);
+  const float cl = (-cosf(kPi * L)) * 0.5f + 0.5f;
+  const float Le = L + 1e-6f;
+  const float q = cl / Le;
+  const float dq = (0.5f * kPi * sinf(kPi * L) * Le - cl) / (Le * Le);
+  const float S = g.c[0] * x.c[0] + g.c[1] * x.c[1] + g.c[2] * x.c[2];
+  const float k0 = (1.0f - p) + p * q;
+  const float k1 = inside ? p * S * dq : 0.0f;
+  Rgb gx;
+  gx.c[0] = g.c[0] * k0 + k1 * 0.27f;
+  gx.c[1] = g.c[1] * k0 + k1 * 0.67f;
+  gx.c[2] = g.c[2] * k0 + k1 * 0.06f;
+  red[0] += S * (q - 1.0f);
+  return gx;
+}
+
+// d out / d x = scale * sum_i k_i [0 <= x - i/8 <= 1/8]   (clamp is inclusive at both ends)
+T2O_HD float curve_bwd_1(const float k[kCurveSteps], float scale, float xin, float g, float* red) {
+  const float x = T2O_OPAQUE(xin);
+  float slope = 0.0f;
+  T2O_UNROLL
+  for (int i = 0; i < kCurveSteps; ++i) {
+    const float d = x - (float)i / kCurveSteps;
+    const float t = fminf(fmaxf(d, 0.0f), 1.0f / kCurveSteps);
+    red[i] += g * t;
+    slope += (d >= 0.0f && d <= 1.0f / kCurveSteps) ? k[i] : 0.0f;
+  }
+  return g * scale * slope;
+}
+
+T2O_HD Rgb tone_bwd(const Rgb& x, const Curve& cv, const Rgb& g, float* red) {
+  Rgb gx;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) gx.c[c] = curve_bwd_1(cv.k[0], cv.scale[0], x.c[c], g.c[c], red);
+  return gx;
+}
+
+T2O_HD Rgb color_bwd(const Rgb& x, const Curve& cv, const Rgb& g, float* red) {
+  Rgb gx;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c)
+    gx.c[c] = curve_bwd_1(cv.k[c], cv.scale[c], x.c[c], g.c[c], red + c * kCurveSteps);
+  return gx;
+}
+
+T2O_HD Rgb pointwise_bwd(int op, const Rgb& x, const float* p, const Curve& cv, const Rgb& g, float* red) {
+  switch (op) {
+    case OP_BRIGHTNESS: return brightness_bwd(x, p[0], g, red);
+    case OP_CONTRAST:   return contrast_bwd(x, p[0], g, red);
+    case OP_SATURATION: return saturation_bwd(x, p[0], g, red);
+    case OP_COLOR:      return color_bwd(x, cv, g, red);
+    case OP_TONE:       return tone_bwd(x, cv, g, red);
+    case OP_WHITE: { Rgb z; z.c[0] = z.c[1] = z.c[2] = 0.0f; return z; }
+    default:            return g;
+  }
+}
+
+// Raw per-sample sums -> parameter gradients.  out = total * 8 / sum, total = sum_j k_j t_j:
+//   d out / d k_i = scale t_i - (scale / sum) total   =>   gk_i = scale A_i - (scale / sum) sum_j k_j A_j
+T2O_HD void curve_param_grad(const float* k, const float* A, float* gk) {
+  float s = 0.0f, dot = 0.0f;
+  T2O_UNROLL
+  for (int i = 0; i < kCurveSteps; ++i) { s = s + k[i]; dot += k[i] * A[i]; }
+  s = s + 1e-10f;
+  const float scale = (float)kCurveSteps / s;
+  T2O_UNROLL
+  for (int i = 0; i < kCurveSteps; ++i) gk[i] = scale * A[i] - (scale / s) * dot;
+}
+
+T2O_HD void finalize_param_grad(int op, const float* param, const float* red, float* gparam) {
+  if (op == OP_TONE) {
+    curve_param_grad(param, red, gparam);
+  } else if (op == OP_COLOR) {
+    T2O_UNROLL
+  for (int c = 0; c < 3; ++c)
+      curve_param_grad(param + c * kCurveSteps, red + c * kCurveSteps, gparam + c * kCurveSteps);
+  } else if (op == OP_WHITE || op == OP_IDENTITY) {
+    const int n = op_num_params(op);
+    for (int i = 0; i < n; ++i) gparam[i] = 0.0f;
+  } else {
+    gparam[0] = red[0];
+  }
+}
+
+}  // namespace t2o

@@ -1,0 +1,58 @@
+"""ctypes front end of tests/host_emul/emul.cpp (host emulation of the HIP block programs).
+TEST HARNESS ONLY: lets the CPU suite check the kernels' per-thread code against the oracle."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        out = os.path.join(ROOT, 'tests', '_build')
+        os.makedirs(out, exist_ok=True)
+        so = os.path.join(out, 'libt2o_emul.so')
+        src = os.path.join(ROOT, 'tests', 'host_emul', 'emul.cpp')
+        deps = [src] + [os.path.join(ROOT, 't2onet_amd', 'csrc', f) for f in ('t2o_pixel_math.h', 't2o_block_programs.h')]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(['g++', '-O2', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared', '-o', so, src])
+        _lib = ctypes.CDLL(so)
+    return _lib
+
+
+def _p(a, t=ctypes.c_float):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def fwd(op, img, param, mask=None, op_id=None, target=None, iters=0):
+    img, param, mask, target = _f(img), _f(param), _f(mask), _f(target)
+    B, _, H, W = img.shape
+    out = np.empty_like(img)
+    loss = np.zeros(1, np.float32)
+    ids = None if op_id is None else np.ascontiguousarray(np.asarray(op_id, dtype=np.int32))
+    rc = lib().emul_fwd(op, _p(ids, ctypes.c_int), _p(img), _p(param), 0 if param is None else param.shape[1],
+                        _p(mask), 0 if mask is None else mask.shape[1], _p(target), _p(out), _p(loss), B, H, W, iters)
+    assert rc == 0
+    return out, float(loss[0])
+
+
+def bwd(op, img, param, gout=None, mask=None, op_id=None, target=None, gloss=1.0, iters=0):
+    img, param, mask, target, gout = _f(img), _f(param), _f(mask), _f(target), _f(gout)
+    B, _, H, W = img.shape
+    gimg = np.empty_like(img)
+    gparam = np.zeros_like(param)
+    gl = np.array([gloss], np.float32)
+    ids = None if op_id is None else np.ascontiguousarray(np.asarray(op_id, dtype=np.int32))
+    rc = lib().emul_bwd(op, _p(ids, ctypes.c_int), _p(img), _p(param), param.shape[1], _p(mask),
+                        0 if mask is None else mask.shape[1], _p(gout), _p(target), _p(gl), _p(gimg), _p(gparam),
+                        gparam.shape[1], B, H, W, iters)
+    assert rc == 0
+    return gimg, gparam

@@ -1,0 +1,114 @@
+"""CPU check of the kernels' per-thread code (t2o_pixel_math.h / t2o_block_programs.h) against
+the oracle, through the host emulation harness (tests/host_emul).  The same comparisons run on
+the real kernels in tests/test_gpu_operators.py (-m gpu).
+
+Tolerances (fp32): forward 1e-6 abs (same operation order as the oracle; cos differs by an ulp);
+gimg 2e-5 abs + 1e-4 rel against the oracle's fp32 autograd THROUGH the HSV round trip, which is
+itself noisy, and 2e-6 against its fp64 autograd for the closed forms."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref, synth
+from tests import emul
+
+OPT = cpu_ref.default_opt()
+OPS = [0, 1, 2, 3, 5, 6, 7]
+SHAPES = [(2, 24, 20), (2, 23, 19), (1, 40, 150), (3, 17, 68)]
+
+
+def oracle_fwd_bwd(op, img, p, mask, gout, dtype=torch.float32):
+    x = img.to(dtype).clone().requires_grad_(True)
+    pp = p.to(dtype).clone().requires_grad_(True)
+    m = None if mask is None else mask.to(dtype)
+    if dtype == torch.float64:
+        out = operator_apply64(op, x, pp, m)
+    else:
+        out = cpu_ref.operator_apply(op, x, pp, m, OPT)
+    out.backward(gout.to(dtype))
+    gp = pp.grad if pp.grad is not None else torch.zeros_like(pp)
+    return out.detach(), x.grad, gp
+
+
+def operator_apply64(op, x, p, m):
+    # the oracle formulas are dtype-agnostic except the sharpness kernel tensor
+    if op == 6:
+        k = torch.tensor([[cpu_ref.SHARP_KERNEL]], dtype=x.dtype)
+        d = torch.cat([torch.nn.functional.conv2d(x[:, c:c + 1], k, padding=1) for c in range(3)], 1)
+        out = x + p.unsqueeze(-1).unsqueeze(-1) * d
+        mm = torch.ones_like(x) if m is None else m
+        return torch.clamp(out * mm + x * (1 - mm), 0, 1)
+    if op == 1:
+        lum = torch.clamp(cpu_ref.rgb2lum(x), 0, 1)
+        clum = -torch.cos(np.pi * lum) * 0.5 + 0.5
+        out = cpu_ref.lerp(x, x / (lum + 1e-6) * clum, p.unsqueeze(-1).unsqueeze(-1))
+        mm = torch.ones_like(x) if m is None else m
+        return torch.clamp(out * mm + x * (1 - mm), 0, 1)
+    return cpu_ref.operator_apply(op, x, p, m, OPT)
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('op', OPS)
+def test_forward_backward_vs_oracle(op, shape):
+    B, H, W = shape
+    img = synth.images(B, H, W, 61)
+    gout = synth.uniform((B, 3, H, W), 62, -1.0, 1.0)
+    masks = {'none': None, 'm1': synth.masks(B, 1, H, W, 63), 'm3': synth.masks(B, 3, H, W, 64, soft=False)}
+    for si, setting in enumerate(['mid', 'strong', 'neg']):
+        p = synth.op_params(op, B, 400 + 10 * op + si, setting)
+        for mname, mask in masks.items():
+            tag = 'op%d %s %s %s' % (op, shape, setting, mname)
+            o_ref, gi_ref, gp_ref = oracle_fwd_bwd(op, img, p, mask, gout)
+            _, gi64, gp64 = oracle_fwd_bwd(op, img, p, mask, gout, torch.float64)
+            for iters in (0, 3):
+                out, _ = emul.fwd(op, img.numpy(), p.numpy(), None if mask is None else mask.numpy(), iters=iters)
+                np.testing.assert_allclose(out, o_ref.numpy(), rtol=0, atol=1e-6, err_msg=tag)
+                gi, gp = emul.bwd(op, img.numpy(), p.numpy(), gout.numpy(), None if mask is None else mask.numpy(), iters=iters)
+                np.testing.assert_allclose(gi, gi64.numpy(), rtol=1e-5, atol=2e-6, err_msg=tag + ' gimg/f64')
+                np.testing.assert_allclose(gi, gi_ref.numpy(), rtol=1e-4, atol=2e-5 if op in (0, 2) else 2e-6, err_msg=tag + ' gimg/f32')
+                scale = max(1.0, float(gp64.abs().max()))
+                np.testing.assert_allclose(gp, gp64.numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=tag + ' gparam')
+
+
+def test_identity_and_dynamic_batch():
+    B, H, W = 9, 24, 20
+    img = synth.images(B, H, W, 71)
+    gout = synth.uniform((B, 3, H, W), 72, -1.0, 1.0)
+    ops = [0, 1, 2, 3, 5, 6, 7, -1, 6]
+    params = torch.zeros(B, 24)
+    for b, op in enumerate(ops):
+        if op >= 0:
+            params[b, :cpu_ref.OP_NPARAM[op]] = synth.op_params(op, 1, 500 + b, 'mid')[0]
+    out, _ = emul.fwd(-2, img.numpy(), params.numpy(), op_id=ops)
+    gi, gp = emul.bwd(-2, img.numpy(), params.numpy(), gout.numpy(), op_id=ops)
+    for b, op in enumerate(ops):
+        if op < 0:
+            np.testing.assert_array_equal(out[b], img[b].numpy())
+            np.testing.assert_array_equal(gi[b], gout[b].numpy())
+            continue
+        n = cpu_ref.OP_NPARAM[op]
+        o_ref, gi_ref, gp_ref = oracle_fwd_bwd(op, img[b:b + 1], params[b:b + 1, :n], None, gout[b:b + 1], torch.float64)
+        np.testing.assert_allclose(out[b], o_ref[0].numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(gi[b], gi_ref[0].numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(gp[b, :n], gp_ref[0].numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(gp_ref.abs().max())))
+        assert np.all(gp[b, n:] == 0)
+
+
+@pytest.mark.parametrize('op', [0, 1, 2, 3, 5, 6, -1])
+def test_fused_l1(op):
+    B, H, W = 2, 20, 36
+    img = synth.images(B, H, W, 81)
+    tgt = synth.images(B, H, W, 82)
+    n = cpu_ref.OP_NPARAM[op] if op >= 0 else 1
+    p = synth.op_params(max(op, 0), B, 83, 'mid')
+    x = img.double().clone().requires_grad_(True)
+    pp = p.double().clone().requires_grad_(True)
+    out = x if op < 0 else operator_apply64(op, x, pp, None)
+    loss = (out - tgt.double()).abs().mean()
+    (loss * 3.0).backward()
+    o, l = emul.fwd(op, img.numpy(), p.numpy(), target=tgt.numpy())
+    assert abs(l - loss.item()) < 1e-6
+    gi, gp = emul.bwd(op, img.numpy(), p.numpy(), target=tgt.numpy(), gloss=3.0)
+    np.testing.assert_allclose(gi, x.grad.numpy(), rtol=1e-5, atol=1e-8)
+    if op >= 0:
+        np.testing.assert_allclose(gp, pp.grad.numpy(), rtol=1e-4, atol=1e-7)
