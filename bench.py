@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): bs=64 per GPU, 256x256 fp32, the six-operator executor
+sequence [brightness, contrast, saturation, color-curve, tone-curve, sharpness] forward + L1
+loss + backward to every operator parameter and to the input image.  Inputs are synthetic
+(U[0,1) images, torch.Generator seed 10; parameters as in SURVEY.md 8(d)) and already resident
+in HBM when the timed region starts.  A "step" = one such forward+L1+backward over the batch.
+
+The step runs through the C ABI (t2o_sequence_fwd / t2o_sequence_bwd): every intermediate
+image is materialised, as Executor.execute returns it, so the HBM traffic is the algorithmic
+K*60*P + 12*P bytes of SURVEY.md 8(d).  N > 1: the batch dimension shards (64 images per GPU,
+weak scaling), the executor path has no data-path collective; one process per
+GPU under torch.distributed/RCCL, timed between barriers, MAX over ranks.
+
+One JSON line on rank 0, with
+  roofline      dominant kernel (largest share of step time): algorithmic bytes per launch /
+                its mean duration, measured with HIP events on the launch stream in a second,
+                per-kernel instrumented pass over the same steps
+  cpu_baseline  the oracle (oracle/cpu_ref.py, eager PyTorch restatement of the reference)
+                timed on this node's host cores on a bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+OPS = [0, 1, 2, 3, 5, 6]
+OP_NAMES = {0: 'brightness', 1: 'contrast', 2: 'saturation', 3: 'color', 5: 'tone', 6: 'sharpness'}
+PARAM_RANGES = {0: (1, -0.3, 0.3), 1: (1, -0.3, 0.3), 2: (1, -0.3, 0.3), 3: (24, 0.5, 1.5), 5: (8, 0.5, 1.5), 6: (1, 0.0, 1.0)}
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_inputs(B, H, W, device, seed=10):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(B, 3, H, W, generator=g)
+    tgt = torch.rand(B, 3, H, W, generator=g)
+    params = torch.zeros(len(OPS), B, 24)
+    for k, op in enumerate(OPS):
+        n, lo, hi = PARAM_RANGES[op]
+        params[k, :, :n] = torch.rand(B, n, generator=g) * (hi - lo) + lo
+    return img.to(device), tgt.to(device), params.to(device)
+
+
+class SequenceRunner:
+    """Preallocated buffers + direct C-ABI calls (no autograd, no allocation in the step)."""
+
+    def __init__(self, B, H, W, device):
+        from t2onet_amd import _lib
+        self.lib = _lib.load()
+        self.check = _lib.check
+        self.B, self.H, self.W, self.K = B, H, W, len(OPS)
+        self.img, self.tgt, self.params = make_inputs(B, H, W, device)
+        self.acts = torch.empty(self.K, B, 3, H, W, device=device)
+        self.gbuf = torch.empty(2, B, 3, H, W, device=device)
+        self.gimg = torch.empty(B, 3, H, W, device=device)
+        self.gparams = torch.zeros(self.K, B, 24, device=device)
+        self.loss = torch.zeros((), device=device)
+        self.gloss = torch.ones((), device=device)
+        self.ws = torch.empty(self.lib.t2o_workspace_bytes(B, H, W), dtype=torch.uint8, device=device)
+        self.c_ops = (ctypes.c_int * self.K)(*OPS)
+
+    def _p(self, t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def step(self):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B, H, W = self.B, self.H, self.W
+        rc = self.lib.t2o_sequence_fwd(self.c_ops, self.K, self._p(self.img), self._p(self.params), self._p(self.tgt),
+                                       self._p(self.acts), self._p(self.loss), self._p(self.ws), self.ws.numel(), B, H, W, st)
+        self.check(rc, 't2o_sequence_fwd')
+        rc = self.lib.t2o_sequence_bwd(self.c_ops, self.K, self._p(self.img), self._p(self.params), self._p(self.tgt),
+                                       self._p(self.acts), self._p(self.gloss), self._p(self.gimg), self._p(self.gparams),
+                                       self._p(self.gbuf), self._p(self.ws), self.ws.numel(), B, H, W, st)
+        self.check(rc, 't2o_sequence_bwd')
+
+    def profiled_step(self, rec):
+        """The same launches, one C call per operator, each bracketed by HIP events recorded on
+        the launch stream (torch's current stream)."""
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B, H, W, K = self.B, self.H, self.W, self.K
+        wsn = self.ws.numel()
+
+        def timed(name, fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.check(fn(), name)
+            e1.record()
+            rec.setdefault(name, []).append((e0, e1))
+
+        cur = self.img
+        for k, op in enumerate(OPS):
+            out, p = self.acts[k], self.params[k]
+            if k == K - 1:
+                timed('fwd_%s+l1' % OP_NAMES[op], lambda: self.lib.t2o_op_fwd_l1(
+                    op, self._p(cur), self._p(p), 24, None, 0, self._p(self.tgt), self._p(out), self._p(self.loss),
+                    self._p(self.ws), wsn, B, H, W, st))
+            else:
+                timed('fwd_%s' % OP_NAMES[op], lambda: self.lib.t2o_op_fwd(
+                    op, self._p(cur), self._p(p), 24, None, 0, self._p(out), B, H, W, st))
+            cur = out
+        gcur = None
+        for k in range(K - 1, -1, -1):
+            op = OPS[k]
+            inp = self.img if k == 0 else self.acts[k - 1]
+            gnext = self.gimg if k == 0 else self.gbuf[k & 1]
+            p, gp = self.params[k], self.gparams[k]
+            if k == K - 1:
+                timed('bwd_%s+l1' % OP_NAMES[op], lambda: self.lib.t2o_op_bwd_l1(
+                    op, self._p(inp), self._p(p), 24, None, 0, self._p(self.tgt), self._p(self.gloss), self._p(gnext),
+                    self._p(gp), 24, self._p(self.ws), wsn, B, H, W, st))
+            else:
+                timed('bwd_%s' % OP_NAMES[op], lambda: self.lib.t2o_op_bwd(
+                    op, self._p(inp), self._p(p), 24, None, 0, self._p(gcur), self._p(gnext), self._p(gp), 24,
+                    self._p(self.ws), wsn, B, H, W, st))
+            gcur = gnext
+
+
+def algorithmic_bytes(name, P):
+    """operator forward 24 B/pixel, backward 36 B/pixel, +12 B/pixel (target)
+    for the forward fused with the L1 loss (its backward reads the target instead of gout)."""
+    if name.startswith('fwd'):
+        return (24 + (12 if name.endswith('+l1') else 0)) * P
+    return 36 * P
+
+
+def cpu_baseline(B_sample, H, W, reps=3):
+    """Oracle timed on the host cores: same sequence, fwd + L1 + bwd, on a bounded sample."""
+    from oracle import cpu_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    img, tgt, params = make_inputs(B_sample, H, W, 'cpu')
+    opt = cpu_ref.default_opt()
+
+    def once():
+        x = img.clone().requires_grad_(True)
+        ps = [params[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
+        out, _ = cpu_ref.run_sequence(x, OPS, ps, opt)
+        cpu_ref.l1_loss(out, tgt).backward()
+
+    once()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        once()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': B_sample / med, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle/cpu_ref.py eager fp32, same 6-op sequence fwd+L1+bwd, bs=%d %dx%d, median of %d reps '
+                      '(%.2f s each)' % (B_sample, H, W, reps, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    B, H, W = args.batch, args.size, args.size
+    run = SequenceRunner(B, H, W, device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_value = float(run.loss.item())
+
+    # second pass: the same steps, one event pair per operator launch
+    rec = {}
+    for _ in range(args.steps):
+        run.profiled_step(rec)
+    torch.cuda.synchronize()
+    P = B * H * W
+    kernels = {}
+    for name, evs in rec.items():
+        ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        by = algorithmic_bytes(name, P)
+        kernels[name] = {'ms': round(ms, 5), 'algorithmic_MB': round(by / 1e6, 2), 'GBps': round(by / ms / 1e6, 1)}
+    dom = max(kernels, key=lambda n: kernels[n]['ms'])
+    total_bytes = sum(algorithmic_bytes(n, P) for n in kernels)
+    sum_ms = sum(k['ms'] for k in kernels.values())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        n_gpus = world
+        line = {
+            'metric': 'images/sec (executor step: 6-op sequence fwd + L1 + bwd, bs=64/GPU, 256x256 fp32)',
+            'value': round(n_gpus * B * args.steps / elapsed, 1),
+            'unit': 'images/sec',
+            'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: bs=%d/GPU %dx%d fp32, executor ops %s forward + L1 + '
+                                   'backward, intermediates materialised, via t2o_sequence_fwd/bwd (C ABI)' % (B, H, W, OPS),
+                       'global_batch': n_gpus * B, 'parallelism': 'batch shards, no collective on the executor path'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['GBps'], 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'algorithmic_bytes_per_launch': algorithmic_bytes(dom, P),
+                         'avg_launch_ms': kernels[dom]['ms']},
+            'step_roofline': {'algorithmic_GB_per_step': round(total_bytes / 1e9, 4),
+                              'achieved_GBps_whole_step': round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                              'frac_of_peak': round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              'sum_kernel_ms': round(sum_ms, 4)},
+            'kernels': kernels,
+            'loss': loss_value,
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_sample, H, W)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

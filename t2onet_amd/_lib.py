@@ -1,0 +1,67 @@
+"""ctypes binding of libt2onet_hip.so (C ABI: include/t2onet_hip.h).
+
+There is deliberately NO fallback: if the library is missing or fails to load the package
+raises, and every wrapper raises RuntimeError with the library's error text on a non-zero
+status.  The library is built in-tree by `python -m t2onet_amd.build` (hipcc, gfx950).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours resolves against the same runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libt2onet_hip.so')
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_i = ctypes.POINTER(ctypes.c_int)
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every function declared in include/t2onet_hip.h
+SIGNATURES = {
+    't2o_abi_version': (_I, []),
+    't2o_last_error': (ctypes.c_char_p, []),
+    't2o_op_num_params': (_I, [_I]),
+    't2o_workspace_bytes': (_Z, [_I, _I, _I]),
+    't2o_op_fwd': (_I, [_I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    't2o_op_bwd': (_I, [_I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
+    't2o_apply_fwd': (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    't2o_apply_bwd': (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
+    't2o_l1_fwd': (_I, [_P, _P, _P, _Z, _P, _Z, _P]),
+    't2o_l1_bwd': (_I, [_P, _P, _P, _P, _Z, _P]),
+    't2o_op_fwd_l1': (_I, [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
+    't2o_op_bwd_l1': (_I, [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
+    't2o_sequence_fwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
+    't2o_sequence_bwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
+    't2o_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    't2o_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libt2onet_hip.so not found at %s: build it with `python -m t2onet_amd.build` '
+            '(needs hipcc; there is no CPU fallback)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.t2o_abi_version() != 1:
+        raise RuntimeError('libt2onet_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().t2o_last_error().decode('utf-8', 'replace')
+        raise RuntimeError('%s failed (status %d): %s' % (what, rc, msg))

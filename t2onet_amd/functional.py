@@ -1,0 +1,246 @@
+"""torch.autograd bridges to the HIP library: device pointers + the current HIP stream go
+straight to the C ABI; torch only owns the memory and the autograd graph.
+
+Every function requires CUDA(HIP) fp32 tensors and raises otherwise -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+OP_NPARAM = (1, 1, 1, 24, 1, 8, 1, 1)
+PARAM_PAD = 24
+_workspaces = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError('t2onet_amd: expected fp32 tensors on the GPU (got %s on %s); '
+                               'there is no CPU implementation' % (t.dtype, t.device))
+
+
+def _img(t):
+    if t.dim() != 4 or t.shape[1] != 3:
+        raise ValueError('image must be (B,3,H,W), got %s' % (tuple(t.shape),))
+    return t.contiguous()
+
+
+def _mask(mask, img):
+    if mask is None:
+        return None, 0
+    B, _, H, W = img.shape
+    if mask.dim() != 4 or mask.shape[0] != B or mask.shape[1] not in (1, 3) or tuple(mask.shape[2:]) != (H, W):
+        mask = mask.expand(B, mask.shape[1] if mask.shape[1] in (1, 3) else 3, H, W)
+    return mask.contiguous(), mask.shape[1]
+
+
+def workspace(B, H, W, device):
+    """Per-device scratch, grown on demand; kernels on one stream run in order, so one buffer
+    per device is enough."""
+    need = _lib.load().t2o_workspace_bytes(B, H, W)
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+class _OperatorFn(torch.autograd.Function):
+    """clamp(process(img, param) * mask + img * (1 - mask), 0, 1) for one operator."""
+
+    @staticmethod
+    def forward(ctx, img, param, mask, op):
+        _need_gpu(img, param, mask)
+        img = _img(img)
+        param = param.contiguous()
+        mask, mask_ch = _mask(mask, img)
+        B, _, H, W = img.shape
+        out = torch.empty_like(img)
+        rc = _lib.load().t2o_op_fwd(op, _ptr(img), _ptr(param), param.shape[1], _ptr(mask), mask_ch, _ptr(out),
+                                    B, H, W, _stream())
+        _lib.check(rc, 't2o_op_fwd')
+        ctx.save_for_backward(img, param, mask)
+        ctx.op, ctx.mask_ch = op, mask_ch
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        img, param, mask = ctx.saved_tensors
+        B, _, H, W = img.shape
+        gout = gout.contiguous()
+        gimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        gparam = torch.zeros_like(param)
+        ws = workspace(B, H, W, img.device)
+        rc = _lib.load().t2o_op_bwd(ctx.op, _ptr(img), _ptr(param), param.shape[1], _ptr(mask), ctx.mask_ch,
+                                    _ptr(gout), _ptr(gimg), _ptr(gparam), gparam.shape[1], _ptr(ws), ws.numel(),
+                                    B, H, W, _stream())
+        _lib.check(rc, 't2o_op_bwd')
+        return gimg, gparam, None, None
+
+
+def operator_apply(op, img, param, mask=None):
+    """One operator over a (sub)batch (models/operators.py:128-130, fused)."""
+    return _OperatorFn.apply(img, param, mask, int(op))
+
+
+class _ApplyFn(torch.autograd.Function):
+    """Per-sample operators in one launch (replaces models/actor.py:100-114,:244-259)."""
+
+    @staticmethod
+    def forward(ctx, img, param, mask, op_id):
+        _need_gpu(img, param, mask)
+        if op_id.dtype != torch.int32 or not op_id.is_cuda:
+            raise RuntimeError('op_id must be an int32 GPU tensor')
+        img = _img(img)
+        param = param.contiguous()
+        op_id = op_id.contiguous()
+        mask, mask_ch = _mask(mask, img)
+        B, _, H, W = img.shape
+        if param.shape != (B, PARAM_PAD):
+            raise ValueError('param must be (B,24)')
+        out = torch.empty_like(img)
+        rc = _lib.load().t2o_apply_fwd(_ptr(op_id), _ptr(img), _ptr(param), PARAM_PAD, _ptr(mask), mask_ch,
+                                       _ptr(out), B, H, W, _stream())
+        _lib.check(rc, 't2o_apply_fwd')
+        ctx.save_for_backward(img, param, mask, op_id)
+        ctx.mask_ch = mask_ch
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        img, param, mask, op_id = ctx.saved_tensors
+        B, _, H, W = img.shape
+        gout = gout.contiguous()
+        gimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        gparam = torch.zeros_like(param)
+        ws = workspace(B, H, W, img.device)
+        rc = _lib.load().t2o_apply_bwd(_ptr(op_id), _ptr(img), _ptr(param), PARAM_PAD, _ptr(mask), ctx.mask_ch,
+                                       _ptr(gout), _ptr(gimg), _ptr(gparam), PARAM_PAD, _ptr(ws), ws.numel(),
+                                       B, H, W, _stream())
+        _lib.check(rc, 't2o_apply_bwd')
+        return gimg, gparam, None, None
+
+
+def apply_per_sample(op_id, img, param, mask=None):
+    """op_id (B,) int32 on the GPU (executor index, -1 = identity); param (B,24)."""
+    return _ApplyFn.apply(img, param, mask, op_id)
+
+
+class _L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        _need_gpu(pred, target)
+        pred, target = pred.contiguous(), target.contiguous()
+        if pred.shape != target.shape:
+            raise ValueError('l1_loss: shape mismatch')
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        n = pred.numel()
+        ws = workspace(max(1, n // (3 * 64 * 64) + 1), 64, 64, pred.device)
+        rc = _lib.load().t2o_l1_fwd(_ptr(pred), _ptr(target), _ptr(loss), n, _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, 't2o_l1_fwd')
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, target = ctx.saved_tensors
+        gloss = gloss.contiguous().to(torch.float32)
+        gpred = torch.empty_like(pred)
+        rc = _lib.load().t2o_l1_bwd(_ptr(pred), _ptr(target), _ptr(gloss), _ptr(gpred), pred.numel(), _stream())
+        _lib.check(rc, 't2o_l1_bwd')
+        return gpred, None
+
+
+def l1_loss(pred, target):
+    """mean |pred - target| (experiments/t2onet/train_seq2seqL1.py:85)."""
+    return _L1Fn.apply(pred, target)
+
+
+class _AttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, context):
+        _need_gpu(q, context)
+        q, context = q.contiguous(), context.contiguous()
+        B, L, D = context.shape
+        attn = torch.empty(B, L, dtype=torch.float32, device=q.device)
+        mix = torch.empty(B, D, dtype=torch.float32, device=q.device)
+        rc = _lib.load().t2o_attn_fwd(_ptr(q), _ptr(context), _ptr(attn), _ptr(mix), B, L, D, _stream())
+        _lib.check(rc, 't2o_attn_fwd')
+        ctx.save_for_backward(q, context, attn)
+        return mix, attn
+
+    @staticmethod
+    def backward(ctx, gmix, gattn):
+        q, context, attn = ctx.saved_tensors
+        B, L, D = context.shape
+        gmix = gmix.contiguous()
+        gattn = None if gattn is None else gattn.contiguous()
+        gq = torch.empty_like(q)
+        gctx = torch.empty_like(context)
+        rc = _lib.load().t2o_attn_bwd(_ptr(q), _ptr(context), _ptr(attn), _ptr(gmix), _ptr(gattn), _ptr(gq),
+                                      _ptr(gctx), B, L, D, _stream())
+        _lib.check(rc, 't2o_attn_bwd')
+        return gq, gctx
+
+
+def attention_core(q, context):
+    """q (B,D), context (B,L,D) -> (mix (B,D), attn (B,L)); softmax over all L rows
+    (models/attention.py:37-40)."""
+    return _AttnFn.apply(q, context)
+
+
+class _SequenceFn(torch.autograd.Function):
+    """A known operator list with every intermediate materialised + L1 on the last output."""
+
+    @staticmethod
+    def forward(ctx, img, params, target, ops):
+        _need_gpu(img, params, target)
+        img, params, target = _img(img), params.contiguous(), _img(target)
+        B, _, H, W = img.shape
+        K = len(ops)
+        if params.shape != (K, B, PARAM_PAD):
+            raise ValueError('params must be (K,B,24)')
+        acts = torch.empty((K,) + tuple(img.shape), dtype=torch.float32, device=img.device)
+        loss = torch.empty((), dtype=torch.float32, device=img.device)
+        ws = workspace(B, H, W, img.device)
+        c_ops = (ctypes.c_int * K)(*ops)
+        rc = _lib.load().t2o_sequence_fwd(c_ops, K, _ptr(img), _ptr(params), _ptr(target), _ptr(acts), _ptr(loss),
+                                          _ptr(ws), ws.numel(), B, H, W, _stream())
+        _lib.check(rc, 't2o_sequence_fwd')
+        ctx.save_for_backward(img, params, target, acts)
+        ctx.ops = tuple(ops)
+        ctx.mark_non_differentiable(acts)
+        return loss, acts
+
+    @staticmethod
+    def backward(ctx, gloss, _gacts):
+        img, params, target, acts = ctx.saved_tensors
+        B, _, H, W = img.shape
+        K = len(ctx.ops)
+        gloss = gloss.contiguous().to(torch.float32)
+        gimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        gparams = torch.zeros_like(params)
+        gbuf = torch.empty((2,) + tuple(img.shape), dtype=torch.float32, device=img.device)
+        ws = workspace(B, H, W, img.device)
+        c_ops = (ctypes.c_int * K)(*ctx.ops)
+        rc = _lib.load().t2o_sequence_bwd(c_ops, K, _ptr(img), _ptr(params), _ptr(target), _ptr(acts), _ptr(gloss),
+                                          _ptr(gimg), _ptr(gparams), _ptr(gbuf), _ptr(ws), ws.numel(), B, H, W,
+                                          _stream())
+        _lib.check(rc, 't2o_sequence_bwd')
+        return gimg, gparams, None, None
+
+
+def sequence_l1(img, ops, params, target):
+    """Apply ops[k] with params[k] (K,B,24) in order; returns (mean |out - target|, acts (K,B,3,H,W))."""
+    return _SequenceFn.apply(img, params, target, [int(o) for o in ops])

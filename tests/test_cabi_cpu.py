@@ -1,0 +1,69 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/t2onet_hip.h declares, validates arguments without touching a device, and the Python
+surface mirrors the reference's Executor/Operator API and refuses CPU tensors."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from t2onet_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from t2onet_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 't2onet_hip.h')).read()
+    declared = set(re.findall(r'\b(t2o_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_argument_validation_without_a_device(lib):
+    assert lib.t2o_abi_version() == 1
+    assert [lib.t2o_op_num_params(i) for i in range(-1, 9)] == [-1, 1, 1, 1, 24, 1, 8, 1, 1, -1]
+    assert lib.t2o_workspace_bytes(0, 4, 4) == 0 and lib.t2o_workspace_bytes(64, 256, 256) > 0
+    # null image / unsupported operator / bad mask are rejected before any launch
+    assert lib.t2o_op_fwd(0, None, None, 1, None, 0, None, 1, 4, 4, None) == 1
+    assert b'null' in lib.t2o_last_error()
+    buf = torch.zeros(64)
+    p = buf.data_ptr()
+    assert lib.t2o_op_fwd(4, p, p, 1, None, 0, p, 1, 4, 4, None) == 2          # inpaint
+    assert lib.t2o_op_fwd(9, p, p, 1, None, 0, p, 1, 4, 4, None) == 2
+    assert lib.t2o_op_fwd(0, p, p, 1, p, 2, p, 1, 4, 4, None) == 1             # mask_ch must be 1 or 3
+    assert lib.t2o_op_bwd(0, p, p, 1, None, 0, p, p, p, 1, None, 0, 1, 4, 4, None) == 3   # no workspace
+    assert lib.t2o_attn_fwd(p, p, p, p, 1, 65, 64, None) == 1
+
+
+def test_python_surface_mirrors_reference():
+    import t2onet_amd
+    from oracle import cpu_ref
+    ex = t2onet_amd.Executor(t2onet_amd.default_options())
+    assert ex.name_list == cpu_ref.OP_NAMES
+    assert [ex.get_param_num(i) for i in range(8)] == cpu_ref.OP_NPARAM
+    for i in range(8):
+        assert tuple(ex.get_param_bnd(i)) == tuple(cpu_ref.param_range(i, cpu_ref.default_opt()))
+    sk = cpu_ref.actor_state_skeleton()
+    want = [k[len('executor.'):] for k in sk if k.startswith('executor.')]
+    assert list(ex.state_dict().keys()) == want
+    assert all(tuple(v.shape) == tuple(sk['executor.' + k].shape) for k, v in ex.state_dict().items())
+    # the parameter heads are plain torch and agree with the oracle on the CPU
+    from oracle import synth
+    ex.load_state_dict(synth.fill_state_dict(ex.state_dict(), seed=3))
+    sd = {'executor.' + k: v for k, v in ex.state_dict().items()}
+    f = synth.uniform((3, 512), 13, -1, 1)
+    for i in [0, 1, 2, 3, 5, 6, 7]:
+        assert torch.allclose(ex.ops[i].extract_parameters(f), cpu_ref.param_head(sd, i, f, cpu_ref.default_opt()), atol=1e-6)
+    # identity path and the no-CPU-fallback rule
+    img = torch.rand(2, 3, 8, 8)
+    out, par = ex.execute(img, -1, None)
+    assert out is img and par.shape == (2, 24)
+    with pytest.raises(RuntimeError, match='no CPU'):
+        ex.execute(img, 0, None, specified_param=torch.zeros(2, 1))

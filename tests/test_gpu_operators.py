@@ -1,0 +1,280 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI (ctypes) behind the
+reference-shaped Executor/Operator API, against
+  (a) the committed golden fixtures = outputs of the reference itself (tools/gen_golden.py),
+  (b) the oracle on seeded inputs at sizes it finishes in seconds,
+  (c) size-independent properties at BASELINE.json's full sizes.
+
+Tolerance (north_star: <= 1e-5 relative fp32): forward atol 1e-5 (observed ~1e-7: the kernels
+follow the reference's operation order with -ffp-contract=off); gradients are closed forms, so
+they are compared with the oracle's fp64 autograd at 1e-5 and with the reference's fp32
+autograd at 2e-5 + 1e-4 rel (its HSV round trip is itself that noisy: SURVEY.md section 7)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref, synth
+
+pytestmark = pytest.mark.gpu
+
+OPT = cpu_ref.default_opt()
+OPS = [0, 1, 2, 3, 5, 6, 7]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def executor(dev):
+    import t2onet_amd
+    ex = t2onet_amd.Executor(t2onet_amd.default_options())
+    ex.load_state_dict(synth.fill_state_dict(ex.state_dict(), seed=3))
+    return ex.to(dev)
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'operators.npz'))
+
+
+def test_library_is_loaded_natively():
+    from t2onet_amd import _lib
+    lib = _lib.load()
+    assert lib.t2o_abi_version() == 1
+    with open('/proc/self/maps') as f:
+        assert 'libt2onet_hip.so' in f.read()
+
+
+def test_executor_metadata(executor, gold):
+    assert list(gold['name_list']) == executor.name_list
+    assert list(gold['param_num']) == [executor.get_param_num(i) for i in range(8)]
+    for i in range(8):
+        np.testing.assert_allclose(gold['param_bnd'][i], executor.get_param_bnd(i), atol=1e-12)
+
+
+@pytest.mark.parametrize('op', OPS)
+def test_golden_reference_outputs(executor, gold, dev, op):
+    B, H, W = 2, 24, 20
+    img = synth.images(B, H, W, 11)
+    gout = synth.uniform((B, 3, H, W), 12, -1.0, 1.0).to(dev)
+    masks = {'none': None, 'm1': synth.masks(B, 1, H, W, 14), 'm3': synth.masks(B, 3, H, W, 15, soft=False)}
+    for si, setting in enumerate(['mid', 'strong', 'neg']):
+        for mname, mask in masks.items():
+            key = 'op%d_%s_%s' % (op, setting, mname)
+            if key + '_out' not in gold:
+                continue
+            x = img.to(dev).requires_grad_(True)
+            p = synth.op_params(op, B, 100 + 10 * op + si, setting).to(dev).requires_grad_(True)
+            out, par = executor.execute(x, op, None if mask is None else mask.to(dev), specified_param=p)
+            assert par is p
+            out.backward(gout)
+            np.testing.assert_allclose(out.detach().cpu().numpy(), gold[key + '_out'], rtol=0, atol=1e-5, err_msg=key)
+            np.testing.assert_allclose(x.grad.cpu().numpy(), gold[key + '_gimg'], rtol=1e-4,
+                                       atol=2e-5 if op in (0, 2) else 5e-6, err_msg=key)
+            scale = max(1.0, float(np.abs(gold[key + '_gparam']).max()))
+            np.testing.assert_allclose(p.grad.cpu().numpy(), gold[key + '_gparam'], rtol=1e-4, atol=5e-5 * scale, err_msg=key)
+
+
+@pytest.mark.parametrize('op', OPS)
+def test_golden_learned_parameter_path(executor, gold, dev, op):
+    B, H, W = 2, 24, 20
+    img = synth.images(B, H, W, 11).to(dev)
+    f = synth.uniform((B, 512), 13, -1.0, 1.0).to(dev).requires_grad_(True)
+    out, par = executor.execute(img, op, None, features=f)
+    np.testing.assert_allclose(par.detach().cpu().numpy(), gold['op%d_feat_param' % op], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), gold['op%d_feat_out' % op], rtol=0, atol=2e-5)
+    if 'op%d_feat_gfeat' % op in gold:
+        out.backward(synth.uniform((B, 3, H, W), 12, -1.0, 1.0).to(dev))
+        g = gold['op%d_feat_gfeat' % op]
+        np.testing.assert_allclose(f.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(g).max())))
+
+
+def test_identity_and_errors(executor, dev):
+    img = synth.images(2, 24, 20, 11).to(dev)
+    out, par = executor.execute(img, -1, None, features=img)
+    assert out is img and par.shape == (2, 24) and float(par.abs().sum()) == 0.0
+    with pytest.raises(AssertionError):
+        executor.execute(img, 0, None)                                    # neither features nor param
+    with pytest.raises(AssertionError):
+        executor.execute(img, 0, None, features=torch.zeros(2, 512, device=dev), specified_param=torch.zeros(2, 1, device=dev))
+    with pytest.raises(IndexError):
+        executor.execute(img, 8, None, specified_param=torch.zeros(2, 1, device=dev))
+    with pytest.raises(RuntimeError):
+        executor.execute(img.cpu(), 0, None, specified_param=torch.zeros(2, 1))      # no CPU fallback
+    with pytest.raises(RuntimeError):
+        executor.execute(img, 4, None, specified_param=torch.zeros(2, 1, device=dev))   # inpaint
+
+
+def _oracle64(op, img, p, mask, gout):
+    from tests.test_block_programs_cpu import oracle_fwd_bwd
+    return oracle_fwd_bwd(op, img, p, mask, gout, torch.float64)
+
+
+@pytest.mark.parametrize('shape', [(2, 23, 19), (1, 40, 150), (3, 17, 68), (2, 128, 128), (1, 397, 600)])
+@pytest.mark.parametrize('op', OPS)
+def test_vs_oracle_ragged_sizes(executor, dev, op, shape):
+    B, H, W = shape
+    img = synth.images(B, H, W, 61)
+    gout = synth.uniform((B, 3, H, W), 62, -1.0, 1.0)
+    for mask in (None, synth.masks(B, 1, H, W, 63)):
+        p = synth.op_params(op, B, 400 + op, 'mid')
+        o_ref = cpu_ref.operator_apply(op, img, p, mask, OPT)
+        _, gi64, gp64 = _oracle64(op, img, p, mask, gout)
+        x = img.to(dev).requires_grad_(True)
+        pp = p.to(dev).requires_grad_(True)
+        out, _ = executor.execute(x, op, None if mask is None else mask.to(dev), specified_param=pp)
+        out.backward(gout.to(dev))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), gi64.numpy(), rtol=1e-5, atol=5e-6)
+        scale = max(1.0, float(gp64.abs().max()))
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), gp64.numpy(), rtol=2e-4, atol=1e-4 * scale)
+
+
+def test_per_sample_operators_one_launch(executor, dev):
+    B, H, W = 9, 40, 72
+    img = synth.images(B, H, W, 71)
+    gout = synth.uniform((B, 3, H, W), 72, -1.0, 1.0)
+    ops = [0, 1, 2, 3, 5, 6, 7, -1, 6]
+    params = torch.zeros(B, 24)
+    for b, op in enumerate(ops):
+        if op >= 0:
+            params[b, :cpu_ref.OP_NPARAM[op]] = synth.op_params(op, 1, 500 + b, 'mid')[0]
+    x = img.to(dev).requires_grad_(True)
+    pp = params.to(dev).requires_grad_(True)
+    out, par = executor.execute_per_sample(x, torch.tensor(ops, device=dev), None, specified_param=pp)
+    out.backward(gout.to(dev))
+    for b, op in enumerate(ops):
+        if op < 0:
+            assert torch.equal(out[b].cpu(), img[b]) and torch.equal(x.grad[b].cpu(), gout[b])
+            continue
+        n = cpu_ref.OP_NPARAM[op]
+        o_ref = cpu_ref.operator_apply(op, img[b:b + 1], params[b:b + 1, :n], None, OPT)
+        _, gi64, gp64 = _oracle64(op, img[b:b + 1], params[b:b + 1, :n], None, gout[b:b + 1])
+        np.testing.assert_allclose(out[b].detach().cpu().numpy(), o_ref[0].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(x.grad[b].cpu().numpy(), gi64[0].numpy(), rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(pp.grad[b, :n].cpu().numpy(), gp64[0].numpy(), rtol=2e-4,
+                                   atol=1e-4 * max(1.0, float(gp64.abs().max())))
+        assert float(pp.grad[b, n:].abs().sum()) == 0.0
+
+
+def test_per_sample_learned_heads_match_grouped_execute(executor, dev):
+    """execute_per_sample(features=...) == the reference's per-group execute + regroup."""
+    B, H, W = 8, 32, 32
+    img = synth.images(B, H, W, 73).to(dev)
+    feats = synth.uniform((B, 512), 74, -1.0, 1.0).to(dev)
+    ops = torch.tensor([0, 1, 2, 3, 5, 6, -1, 3], device=dev)
+    out, par = executor.execute_per_sample(img, ops, None, features=feats)
+    for b in range(B):
+        o, p = executor.execute(img[b:b + 1], int(ops[b]), None, features=feats[b:b + 1])
+        assert torch.allclose(out[b:b + 1], o, atol=1e-6)
+        assert torch.allclose(par[b:b + 1, :p.shape[1]], p, atol=1e-6)
+
+
+def test_golden_cfg1_and_chain6(executor, gold, dev):
+    # BASELINE config 1: single 256x256 image, brightness -> contrast -> saturation
+    x = synth.images(1, 256, 256, 21).to(dev)
+    cur = x
+    for k, op in enumerate([0, 1, 2]):
+        cur, _ = executor.execute(cur, op, None, specified_param=synth.op_params(op, 1, 200 + k, 'mid').to(dev))
+    np.testing.assert_allclose(cur[:, :, 100:132, 60:92].cpu().numpy(), gold['cfg1_out_crop'], rtol=0, atol=1e-5)
+    assert abs(cur.double().sum().item() - float(gold['cfg1_out_sum'])) < 1e-2
+    # BASELINE config 2 at a small size, both product paths
+    import t2onet_amd.functional as T
+    B, H, W = 3, 32, 40
+    ops = [0, 1, 2, 3, 5, 6]
+    tgt = synth.images(B, H, W, 32).to(dev)
+    for path in ('execute', 'sequence'):
+        x = synth.images(B, H, W, 31).to(dev).requires_grad_(True)
+        ps = [synth.op_params(op, B, 300 + k, 'mid').to(dev).requires_grad_(True) for k, op in enumerate(ops)]
+        if path == 'execute':
+            cur = x
+            for op, p in zip(ops, ps):
+                cur, _ = executor.execute(cur, op, None, specified_param=p)
+            loss = T.l1_loss(cur, tgt)
+        else:
+            loss, acts = executor.run_sequence(x, ops, ps, tgt)
+            cur = acts[-1]
+        loss.backward()
+        np.testing.assert_allclose(cur.detach().cpu().numpy(), gold['chain6_out'], rtol=0, atol=1e-5, err_msg=path)
+        assert abs(loss.item() - float(gold['chain6_loss'])) < 1e-6                     # L1 deviation <= 1e-5
+        g = gold['chain6_gimg']
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g, rtol=2e-3, atol=2e-3 * np.abs(g).max(), err_msg=path)
+        for k, p in enumerate(ps):
+            gk = gold['chain6_gparam%d' % k]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), gk, rtol=2e-3, atol=2e-3 * max(np.abs(gk).max(), 1e-6),
+                                       err_msg='%s gparam %d' % (path, k))
+
+
+def test_full_size_properties(executor, dev):
+    """BASELINE config 2 shape (bs=64, 256x256): properties that need no oracle."""
+    import t2onet_amd.functional as T
+    B, H, W = 64, 256, 256
+    g = torch.Generator().manual_seed(10)
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
+    zero1 = torch.zeros(B, 1, device=dev)
+    ones8, ones24 = torch.ones(B, 8, device=dev), torch.ones(B, 24, device=dev)
+    # neutral parameters are the identity (up to fp32 rounding of each formula)
+    for op, p, tol in [(0, zero1, 2e-6), (1, zero1, 0.0), (2, zero1, 2e-6), (3, ones24, 2e-7), (5, ones8, 2e-7), (6, zero1, 0.0)]:
+        out, _ = executor.execute(img, op, None, specified_param=p)
+        assert (out - img).abs().max().item() <= tol, op
+    # a zero mask returns the input, a one mask the unmasked result; run-to-run bitwise reproducible
+    p = torch.full((B, 1), 0.4, device=dev)
+    a, _ = executor.execute(img, 6, None, specified_param=p)
+    b, _ = executor.execute(img, 6, torch.ones(B, 1, H, W, device=dev), specified_param=p)
+    c, _ = executor.execute(img, 6, torch.zeros(B, 1, H, W, device=dev), specified_param=p)
+    assert torch.equal(a, b) and torch.equal(c, img)
+    a2, _ = executor.execute(img, 6, None, specified_param=p)
+    assert torch.equal(a, a2)
+    # outputs stay in [0,1]; L1 agrees with torch; sequence loss == l1(acts[-1], target)
+    ops = [0, 1, 2, 3, 5, 6]
+    gen = torch.Generator().manual_seed(11)
+    ps = [(torch.rand(B, n, generator=gen) * (hi - lo) + lo).to(dev) for n, lo, hi in
+          [(1, -.3, .3), (1, -.3, .3), (1, -.3, .3), (24, .5, 1.5), (8, .5, 1.5), (1, 0., 1.)]]
+    x = img.clone().requires_grad_(True)
+    pl = [q.clone().requires_grad_(True) for q in ps]
+    loss, acts = executor.run_sequence(x, ops, pl, tgt)
+    assert acts.min().item() >= 0.0 and acts.max().item() <= 1.0
+    ref = (acts[-1] - tgt).abs().mean().item()
+    assert abs(loss.item() - ref) < 1e-6 and abs(T.l1_loss(acts[-1], tgt).item() - ref) < 1e-6
+    loss.backward()
+    g1 = [q.grad.clone() for q in pl] + [x.grad.clone()]
+    # the per-operator API path gives bit-identical images and gradients
+    x2 = img.clone().requires_grad_(True)
+    pl2 = [q.clone().requires_grad_(True) for q in ps]
+    cur = x2
+    for k, (op, q) in enumerate(zip(ops, pl2)):
+        cur, _ = executor.execute(cur, op, None, specified_param=q)
+        assert torch.equal(cur, acts[k])
+    T.l1_loss(cur, tgt).backward()
+    g2 = [q.grad for q in pl2] + [x2.grad]
+    for u, v in zip(g1, g2):
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-9)
+    # gradient of the loss w.r.t. the image has |g| <= amplification / N and is not identically zero
+    assert x.grad.abs().max().item() > 0
+
+
+def test_attention_core(dev):
+    import t2onet_amd.functional as T
+    for (B, L, D) in [(4, 14, 512), (64, 17, 512), (3, 1, 64), (5, 64, 1024)]:
+        q = synth.uniform((B, D), 91, -1, 1)
+        ctx = synth.uniform((B, L, D), 92, -0.2, 0.2)
+        ctx[:, L // 2:] *= 0.0 if L > 2 else 1.0          # zero-padded encoder rows take part in the softmax
+        gm = synth.uniform((B, D), 93, -1, 1)
+        ga = synth.uniform((B, L), 94, -1, 1)
+        q64, c64 = q.double().requires_grad_(True), ctx.double().requires_grad_(True)
+        s = torch.bmm(q64.unsqueeze(1), c64.transpose(1, 2))
+        a = torch.softmax(s.view(-1, L), 1).view(B, 1, L)
+        mix = torch.bmm(a, c64).squeeze(1)
+        ((mix * gm.double()).sum() + (a.squeeze(1) * ga.double()).sum()).backward()
+        qd, cd = q.to(dev).requires_grad_(True), ctx.to(dev).requires_grad_(True)
+        m2, a2 = T.attention_core(qd, cd)
+        ((m2 * gm.to(dev)).sum() + (a2 * ga.to(dev)).sum()).backward()
+        np.testing.assert_allclose(a2.detach().cpu().numpy(), a.squeeze(1).detach().numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(m2.detach().cpu().numpy(), mix.detach().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(qd.grad.cpu().numpy(), q64.grad.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(cd.grad.cpu().numpy(), c64.grad.numpy(), rtol=1e-4, atol=1e-6)
