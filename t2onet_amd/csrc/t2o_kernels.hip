@@ -158,38 +158,47 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd(OpArgs a, int tiles) {
 }
 
 // ------------------------------------------------------------------ finalisation kernels
-// one wave per sample: sum the per-block raw sums in block order, then raw sums -> gparam
-__global__ __launch_bounds__(64) void k_finalize_params(OpArgs a, float* gparam, int gparam_stride,
-                                                        int nblk_point, int nblk_sharp) {
+// One workgroup per sample: sum the per-block raw sums in a fixed order, then raw sums -> gparam.
+// Thread t owns slot (t % 32) of every 8th block row starting at (t / 32): 96-byte coalesced reads.
+__global__ __launch_bounds__(kThreads) void k_finalize_params(OpArgs a, float* gparam, int gparam_stride,
+                                                              int nblk_point, int nblk_sharp) {
+  __shared__ float part[kThreads / 32][32];
   __shared__ float sums[kRedSlots];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x, slot = threadIdx.x & 31, chunk = threadIdx.x >> 5;
   const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
   float* grow = gparam + (size_t)b * gparam_stride;
   const int np = op_num_params(op);
-  if (op == OP_IDENTITY || op == OP_WHITE || np == 0) {
-    if (lane < np) grow[lane] = 0.0f;
+  if (op == OP_IDENTITY || op == OP_WHITE || np == 0) {            // uniform per workgroup
+    if ((int)threadIdx.x < np) grow[threadIdx.x] = 0.0f;
     return;
   }
   const int n = nred_of(op);
   const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
   const float* base = a.partials + (size_t)b * a.nblk_max * kRedSlots;
-  for (int s = 0; s < n; ++s) {
-    float acc = 0.0f;
-    for (int k = lane; k < nb; k += 64) acc += base[(size_t)k * kRedSlots + s];
-    acc = wave_sum(acc);
-    if (lane == 0) sums[s] = acc;
+  float acc = 0.0f;
+  if (slot < n)
+    for (int k = chunk; k < nb; k += kThreads / 32) acc += base[(size_t)k * kRedSlots + slot];
+  part[chunk][slot] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kThreads / 32; ++c) s += part[c][threadIdx.x];
+    sums[threadIdx.x] = s;
   }
   __syncthreads();
-  if (lane == 0) finalize_param_grad(op, a.param + (size_t)b * a.param_stride, sums, grow);
+  if (threadIdx.x == 0) finalize_param_grad(op, a.param + (size_t)b * a.param_stride, sums, grow);
 }
 
 // loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order)
 __global__ __launch_bounds__(kThreads) void k_finalize_loss(OpArgs a, float* loss, int nblk_point, int nblk_sharp) {
   float acc = 0.0f;
-  for (int b = 0; b < a.B; ++b) {
+  const int total = a.B * a.nblk_max;
+  for (int i = threadIdx.x; i < total; i += kThreads) {
+    const int b = i / a.nblk_max, k = i - b * a.nblk_max;
     const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
     const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
-    for (int k = threadIdx.x; k < nb; k += kThreads) acc += a.loss_partials[(size_t)b * a.nblk_max + k];
+    if (k < nb) acc += a.loss_partials[i];
   }
   __shared__ float out1;
   block_reduce_store1(acc, &out1);
@@ -445,7 +454,7 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
   if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_bwd(a, g, st);
   if (gparam && op != OP_IDENTITY)
-    k_finalize_params<<<B, 64, 0, st>>>(a, gparam, gparam_stride, g.nblk_point, g.nblk_sharp);
+    k_finalize_params<<<B, kThreads, 0, st>>>(a, gparam, gparam_stride, g.nblk_point, g.nblk_sharp);
   return check_launch("operator backward");
 }
 

@@ -99,8 +99,9 @@ def test_identity_and_errors(executor, dev):
     assert out is img and par.shape == (2, 24) and float(par.abs().sum()) == 0.0
     with pytest.raises(AssertionError):
         executor.execute(img, 0, None)                                    # neither features nor param
-    with pytest.raises(AssertionError):
-        executor.execute(img, 0, None, features=torch.zeros(2, 512, device=dev), specified_param=torch.zeros(2, 1, device=dev))
+    with pytest.raises(AssertionError):                                   # operators.py:113, on the Operator itself
+        executor.brightness_op.execute(img, None, features=torch.zeros(2, 512, device=dev),
+                                       specified_param=torch.zeros(2, 1, device=dev))
     with pytest.raises(IndexError):
         executor.execute(img, 8, None, specified_param=torch.zeros(2, 1, device=dev))
     with pytest.raises(RuntimeError):
