@@ -1,0 +1,165 @@
+"""Actor with the reference's surface (models/actor.py:36-364): ResNet image encoder + request
+encoder + one-step attention decoder + Executor.
+
+Kept: constructor `Actor(opt)`, attributes `vis_encoder / lang_encoder / decoder / executor / bn1`
+(199-tensor state_dict, same keys), `supervised_forward`, `episode_forward`, `forward`,
+`get_entropy_penalty`, `divide_op_group`, return structures.
+
+Redesigned for the GPU (results unchanged):
+  * the per-step "unique ops -> per-group index_select -> execute -> cat -> index_select back"
+    loop (actor.py:100-114, :157-172, :244-259) is ONE Executor.execute_per_sample launch with a
+    per-sample operator id; no image gather/scatter, no `.item()` host sync per group;
+  * the per-sample python loop that clears op_mask (actor.py:235-236) is one scatter_;
+  * the attention core is a HIP kernel (attention.py).
+"""
+import json
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .action_decoder import Decoder
+from .actor_resnet import ResNet
+from .executor import Executor, PARAM_PAD
+from .lang_encoder import RNNEncoder
+
+# operators the FiveK path may choose: END + brightness/contrast/saturation/color/tone/sharpness
+# (inpaint_obj = 7 and color_bg = 10 are local edits, blocked: actor.py:211)
+OP_MASK = [0., 0., 1., 1., 1., 1., 1., 0., 1., 1., 0.]
+N_SPEC_TOKEN = 4
+
+
+def _vocab_sizes(opt):
+    """Vocabulary sizes from the reference's JSON files when present (utils/text_utils.py:28-38),
+    else from opt.input_vocab_size / opt.output_vocab_size (FiveK: 918 / 11)."""
+    vdir = getattr(opt, 'vocab_dir', None)
+    try:
+        with open(os.path.join(vdir, '%s_vocabs_sess_%s.json' % (opt.dataset, opt.session))) as f:
+            n_in = len(json.load(f))
+        with open(os.path.join(vdir, '%s_operator_vocabs_sess_%s.json' % (opt.dataset, opt.session))) as f:
+            n_out = len(json.load(f))
+        return n_in, n_out
+    except (OSError, TypeError, AttributeError):
+        return opt.input_vocab_size, opt.output_vocab_size
+
+
+class Actor(nn.Module):
+    def __init__(self, opt, word2vec=None):
+        super().__init__()
+        self.opt = opt
+        n_in, n_out = _vocab_sizes(opt)
+        self.vis_encoder = ResNet(3, 18, 512)
+        self.lang_encoder = RNNEncoder(n_in, opt.word_vec_dim, opt.hidden_size, N_SPEC_TOKEN,
+                                       bidirectional=bool(opt.bidirectional), input_dropout_p=opt.input_dropout_p,
+                                       dropout_p=opt.dropout_p, n_layers=opt.n_layers,
+                                       variable_lengths=opt.variable_lengths, word2vec=word2vec,
+                                       fix_embedding=opt.fix_input_embedding, pad_id=opt.null_id)
+        self.decoder = Decoder(n_out, opt.decoder_max_len, opt.word_vec_dim, opt.hidden_size, opt.n_layers,
+                               bidirectional=bool(opt.bidirectional), use_attention=opt.use_attention)
+        self.variable_lengths = opt.variable_lengths
+        self.null_id, self.start_id, self.end_id = opt.null_id, opt.start_id, opt.end_id
+        self.executor = Executor(opt)
+        self.bn1 = nn.BatchNorm1d(512)
+
+    # ------------------------------------------------------------------ helpers
+    def image_features(self, img):
+        return F.relu(self.bn1(self.vis_encoder(img)))                 # actor.py:142-143, :215-216
+
+    def divide_op_group(self, ops):
+        """Kept for API compatibility (actor.py:100-114); the forward passes do not use it."""
+        unqs = torch.unique(ops)
+        group_inds = [torch.nonzero(ops == u).squeeze(1) for u in unqs]
+        return unqs, group_inds, torch.argsort(torch.cat(group_inds))
+
+    def _execute(self, img, ops_vocab, context, mask=None):
+        """ops_vocab (B,) operator-vocabulary ids; executor index = id - 3, negative -> identity."""
+        return self.executor.execute_per_sample(img, ops_vocab.view(-1) - 3, mask, features=context)
+
+    # ------------------------------------------------------------------ teacher forcing
+    def supervised_forward(self, x, y, img_x, img_y, gt_params, mask, lengths=None):
+        """actor.py:116-181.  Returns (pred_imgs (B,step-2,3,H,W), pred_params (B,step-2,24),
+        pred_logprobs (B,step-1,n_cls))."""
+        if mask is not None:
+            raise NotImplementedError('local-edit masks belong to the GIER path (SURVEY.md 8(f) rank 4)')
+        enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
+        hidden = self.decoder._init_state(enc_hidden)
+        step = int((y != self.null_id).sum(1).max())
+        pred_params, pred_imgs, logprobs = [], [], []
+        ops = y[:, 0].unsqueeze(-1)
+        for i in range(1, step):
+            feat = self.image_features(img_x)
+            logp, hidden, _, context = self.decoder.forward_step(ops, hidden, enc_out, feat)
+            logprobs.append(logp)
+            ops = y[:, i].unsqueeze(-1)
+            if i == step - 1:
+                break
+            out, par = self._execute(img_x, ops, context)
+            pred_imgs.append(out)
+            pred_params.append(par)
+            img_x = img_y[:, i - 1]                        # next input = planned ground-truth intermediate
+        return torch.stack(pred_imgs, 1), torch.stack(pred_params, 1), torch.cat(logprobs, 1)
+
+    # ------------------------------------------------------------------ free running
+    def episode_forward(self, x, img_x, mask_dict, reinforce_sample=1, lengths=None):
+        """actor.py:184-284.  Returns (state, pred_imgs (B,T,3,H,W), pred_ops (B,T), pred_params list of T (B,24))."""
+        if mask_dict is not None:
+            raise NotImplementedError('local-edit masks belong to the GIER path (SURVEY.md 8(f) rank 4)')
+        B = x.shape[0]
+        dev = img_x.device
+        enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
+        hidden = self.decoder._init_state(enc_hidden)
+        hiddens = [tuple(h.detach() for h in hidden)]
+        op_mask = torch.tensor(OP_MASK, dtype=torch.float, device=dev).repeat(B, 1)
+        pred_op = torch.full((B, 1), self.start_id, dtype=torch.long, device=dev)
+        pred_ops, pred_params, pred_imgs = [], [], []
+        for _ in range(self.opt.decoder_max_len):
+            feat = self.image_features(img_x)
+            logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
+            hiddens.append(tuple(h.detach() for h in hidden))
+            probs = torch.exp(logp).squeeze(1)
+            probs = probs * (1 - self.opt.explore_prob) + self.opt.explore_prob
+            probs = probs * op_mask
+            probs = probs / (probs.sum(1, keepdim=True) + 1e-30)
+            if reinforce_sample:
+                pred_op = torch.distributions.Categorical(probs=probs).sample().view(B, -1)
+            else:
+                pred_op = probs.topk(1)[1].view(B, -1)
+            op_mask.scatter_(1, pred_op, 0.0)              # an operator is used at most once
+            img_x, par = self._execute(img_x, pred_op, context)
+            pred_imgs.append(img_x)
+            pred_params.append(par)
+            pred_ops.append(pred_op.squeeze(-1))
+        if not pred_ops:
+            return {}, img_x.unsqueeze(1), [], pred_params
+        pred_ops = torch.stack(pred_ops, 1)
+        pred_imgs = torch.stack(pred_imgs, 1)
+        state = {'reqs': x, 'imgs': pred_imgs.detach(), 'ops': pred_ops, 'param': pred_params,
+                 'hidden': hiddens, 'masks': None}
+        return state, pred_imgs, pred_ops, pred_params
+
+    # ------------------------------------------------------------------ single RL step (no caller in the reference)
+    def forward(self, x, img_x, hidden, op, mask_dict=None, lengths=None):
+        """actor.py:286-354."""
+        if mask_dict is not None:
+            raise NotImplementedError('local-edit masks belong to the GIER path')
+        op = op.view(-1, 1)
+        B = img_x.shape[0]
+        with torch.no_grad():
+            enc_out, _, _ = self.lang_encoder(x, lengths)
+        op_mask = torch.tensor(OP_MASK, dtype=torch.float, device=img_x.device).repeat(B, 1)
+        logp, dec_hidden, _, context = self.decoder.forward_step(op, hidden, enc_out, self.image_features(img_x))
+        entropy_penalty = self.get_entropy_penalty(logp)
+        probs = torch.exp(logp).squeeze(1) * (1 - self.opt.explore_prob) + self.opt.explore_prob
+        probs = probs * op_mask
+        probs = probs / (probs.sum(1, keepdim=True) + 1e-30)
+        pred_op = torch.distributions.Categorical(probs=probs).sample().view(B, -1)
+        pred_img, _ = self._execute(img_x, pred_op, context)
+        _, _, _, next_context = self.decoder.forward_step(pred_op, dec_hidden, enc_out, self.image_features(pred_img))
+        return pred_img, logp, entropy_penalty, context, next_context
+
+    def get_entropy_penalty(self, logprobs):
+        probs = torch.exp(logprobs)
+        entropy = -(probs * logprobs).sum(1, keepdim=True)
+        return math.log(logprobs.shape[-1]) - entropy

@@ -1,0 +1,53 @@
+"""Image encoder of the actor (models/actor_resnet.py): ResNet-18 layout with a 3x3 stride-2
+stem, no max-pool, every stage stride 2 (/32), global mean, fc.  The only dense contraction of
+the hot path: convolutions go to MIOpen (MFMA) through PyTorch-ROCm; nothing here is
+hand-written.  Module names follow the reference so its checkpoints load."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != planes:
+            self.shortcut = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return F.relu(out + self.shortcut(x))
+
+
+class ResNet(nn.Module):
+    def __init__(self, num_inputs=3, depth=18, num_outputs=512):
+        super().__init__()
+        if depth != 18:
+            raise NotImplementedError('the actor uses depth 18 (models/actor.py:74)')
+        self.in_planes = 64
+        self.conv1 = nn.Conv2d(num_inputs, 64, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._make_layer(64, 2, 2)
+        self.layer2 = self._make_layer(128, 2, 2)
+        self.layer3 = self._make_layer(256, 2, 2)
+        self.layer4 = self._make_layer(512, 2, 2)
+        self.fc = nn.Linear(512, num_outputs)
+
+    def _make_layer(self, planes, num_blocks, stride):
+        blocks = []
+        for s in [stride] + [1] * (num_blocks - 1):
+            blocks.append(BasicBlock(self.in_planes, planes, s))
+            self.in_planes = planes
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = x.mean((2, 3))
+        return self.fc(x.view(x.size(0), -1))

@@ -1,0 +1,89 @@
+"""The two alternating train steps of experiments/t2onet/train_seq2seqL1.py (:51-65 teacher
+forced, :74-88 episode + L1), plus single-node data parallelism the reference does not have:
+one process per GPU, the batch dimension sharded, ONE all-reduce of a flat fp32 gradient
+buffer per step (RCCL over xGMI when the process group backend is "nccl").
+
+Gradient semantics under data parallelism: every parameter owns a slice
+of one pre-zeroed flat buffer, so a head that no local sample selected contributes zeros to the
+all-reduce and Adam sees a zero gradient -- the behaviour of the reference under the
+zero-filling `zero_grad()` of the torch version it was written for.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import functional as T
+
+
+def select_end_images(pred_imgs, pred_ops, end_id):
+    """Image at the first END token, else the last one (train_seq2seqL1.py:78-84), without the
+    per-sample nonzero() host syncs."""
+    B, Tn = pred_ops.shape
+    is_end = pred_ops == end_id
+    first = torch.where(is_end.any(1), is_end.int().argmax(1), torch.full((B,), Tn - 1, device=pred_ops.device))
+    return pred_imgs[torch.arange(B, device=pred_ops.device), first]
+
+
+class FlatGradients:
+    """All trainable parameters' .grad as views of one flat fp32 buffer."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        """One collective for the whole model (88.7 MB for the actor)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+class Trainer:
+    """Drives the reference's alternation: odd iterations supervised, even iterations episode/L1."""
+
+    def __init__(self, model, opt, lr=None):
+        self.model, self.opt = model, opt
+        self.grads = FlatGradients(model.parameters())
+        self.optimizer = torch.optim.Adam(self.grads.params, lr=lr if lr is not None else opt.learning_rate)
+        self.itr = 0
+
+    def _finish(self, loss):
+        self.grads.zero()
+        loss.backward()
+        self.grads.all_reduce_mean()
+        self.optimizer.step()
+
+    def supervised_step(self, x, y, img_x, img_y, gt_params, lengths=None):
+        """train_seq2seqL1.py:51-65: NLL (mean, no ignore_index) + MSE(sum)/count_nonzero."""
+        step = int((y != self.opt.null_id).sum(1).max())
+        _, pred_params, logp = self.model.supervised_forward(x, y, img_x, img_y, gt_params, None, lengths)
+        target = y[:, 1:step].contiguous().view(-1)
+        op_loss = F.nll_loss(logp.reshape(-1, logp.shape[-1]), target)
+        gt = gt_params[:, :step - 2]
+        param_loss = F.mse_loss(pred_params, gt, reduction='sum') / ((gt != 0).sum())
+        self._finish(op_loss + param_loss)
+        return op_loss.detach(), param_loss.detach()
+
+    def episode_step(self, x, img_x, target, reinforce_sample=1, lengths=None):
+        """train_seq2seqL1.py:74-88: free-running episode, L1 between the END image and the target."""
+        _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths)
+        pred = select_end_images(pred_imgs, pred_ops, self.opt.end_id)
+        loss = T.l1_loss(pred, target)
+        self._finish(loss)
+        return loss.detach()
+
+    def step(self, batch):
+        """batch = (img_x, img_y (B,6,3,H,W), x, y, gt_params) as the reference's loader yields."""
+        self.itr += 1
+        img_x, img_y, x, y, gt_params = batch
+        if self.itr % 2 == 1:
+            return self.supervised_step(x, y, img_x, img_y, gt_params)
+        return self.episode_step(x, img_x, img_y[:, -1])

@@ -1,0 +1,113 @@
+"""CPU checks of the actor's host logic (everything that does not need the HIP library) and
+of the data-parallel path over gloo with world_size 2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import cpu_ref, synth
+
+OPT = cpu_ref.default_opt(input_dropout_p=0.0, dropout_p=0.0)
+
+
+@pytest.fixture(scope='module')
+def model():
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    m = Actor(t2onet_amd.default_options(input_dropout_p=0.0, dropout_p=0.0))
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), seed=7))
+    return m.eval()
+
+
+def test_state_dict_matches_reference_layout(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'actor.npz'))
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g['sd_keys'])
+    assert [v.numel() for v in sd.values()] == list(g['sd_numel'])
+    assert [n for n, _ in model.named_parameters()] == list(g['param_names'])
+
+
+def test_encoders_match_reference_outputs(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'actor.npz'))
+    x = synth.requests(4, 17, 41)
+    img = synth.images(4, 64, 64, 42)
+    with torch.no_grad():
+        enc_out, (h, c), _ = model.lang_encoder(x)
+        np.testing.assert_allclose(enc_out.numpy(), g['enc_out'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(h.numpy(), g['enc_h'], rtol=1e-6, atol=1e-7)
+        enc2, _, _ = model.lang_encoder(x, lengths=(x != 0).sum(1))
+        assert torch.equal(enc2, enc_out)
+        np.testing.assert_allclose(model.image_features(img).numpy(), g['img_feat_eval'], rtol=1e-5, atol=1e-6)
+        hid = model.decoder._init_state((h, c))
+        assert hid[0].shape == (2, 4, 512)
+
+
+def test_select_end_images_matches_reference_loop():
+    from t2onet_amd.train import select_end_images
+    pred_imgs = synth.uniform((6, 5, 3, 4, 4), 5)
+    pred_ops = torch.tensor([[4, 2, 3, 5, 6], [2, 4, 5, 6, 8], [3, 4, 5, 6, 8], [3, 4, 5, 6, 2], [4, 2, 2, 3, 5], [9, 8, 6, 5, 4]])
+    assert torch.equal(select_end_images(pred_imgs, pred_ops, 2), cpu_ref.select_end_images(pred_imgs, pred_ops, 2))
+
+
+def test_op_mask_scatter_equals_python_loop():
+    mask = torch.tensor(cpu_ref.OP_MASK).repeat(5, 1)
+    ops = torch.tensor([[2], [3], [9], [8], [5]])
+    ref = mask.clone()
+    for b in range(5):
+        ref[b, ops[b, 0]] = 0
+    assert torch.equal(mask.scatter_(1, ops, 0.0), ref)
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from t2onet_amd.train import FlatGradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+    grads = FlatGradients(net.parameters())
+    opt = torch.optim.Adam(grads.params, lr=1e-2)
+    data = synth.uniform((8, 8), 3, -1, 1)
+    tgt = synth.uniform((8, 4), 4, -1, 1)
+    shard = slice(rank * 4, rank * 4 + 4)
+    for _ in range(3):
+        grads.zero()
+        # the last layer is only used on rank 0: its gradient must count as zeros on rank 1
+        h = net[2](net[1](net[0](data[shard])))
+        y = net[3](h) if rank == 0 else h
+        ((y - tgt[shard]) ** 2).mean().backward()
+        grads.all_reduce_mean()
+        opt.step()
+    torch.save([p.detach().clone() for p in net.parameters()], out % rank)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_flat_allreduce_gloo(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    out = str(tmp_path / 'rank%d.pt')
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)                     # replicas stay bit-identical
+    # single-process reference: mean of the two shard gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    data, tgt = synth.uniform((8, 8), 3, -1, 1), synth.uniform((8, 4), 4, -1, 1)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=False)
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        total = 0
+        for r in range(2):
+            h = net[2](net[1](net[0](data[r * 4:r * 4 + 4])))
+            y = net[3](h) if r == 0 else h
+            total = total + 0.5 * ((y - tgt[r * 4:r * 4 + 4]) ** 2).mean()
+        total.backward()
+        opt.step()
+    for u, v in zip(a, net.parameters()):
+        assert torch.allclose(u, v.detach(), rtol=1e-5, atol=1e-7)

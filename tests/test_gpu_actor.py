@@ -1,0 +1,114 @@
+"""The actor on the GPU (HIP executor + attention kernels, MIOpen/hipBLASLt for conv/LSTM/GEMM)
+against outputs of the reference itself (tests/golden/actor.npz from tools/gen_golden.py).
+
+Operator indices must be identical (argmax mode); floating-point outputs within 1e-4 of the
+reference's CPU run here: they pass through a 21-conv ResNet and two LSTMs whose library
+kernels (MIOpen vs oneDNN) round differently, before reaching the hand-written kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref, synth
+
+pytestmark = pytest.mark.gpu
+B, H, W, L = 4, 64, 64, 17
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'actor.npz'))
+
+
+def make_model(dev):
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    torch.backends.cudnn.deterministic = True
+    opt = t2onet_amd.default_options(input_dropout_p=0.0, dropout_p=0.0)
+    m = Actor(opt)
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), seed=7))
+    return m.to(dev), opt
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_episode_l1_step_matches_reference(gold, mode):
+    from t2onet_amd.train import select_end_images
+    import t2onet_amd.functional as T
+    dev = torch.device('cuda:0')
+    model, opt = make_model(dev)
+    model.train(mode == 'train')
+    p = 'ep_%s_' % mode
+    x = synth.requests(B, L, 41).to(dev)
+    img = synth.images(B, H, W, 42).to(dev)
+    tgt = synth.images(B, H, W, 43).to(dev)
+    state, pred_imgs, pred_ops, pred_params = model.episode_forward(x, img, None, reinforce_sample=0)
+    np.testing.assert_array_equal(pred_ops.cpu().numpy(), gold[p + 'pred_ops'])             # bit-exact indices
+    np.testing.assert_allclose(torch.stack(pred_params, 0).detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pred_imgs.detach().double().mean((2, 3, 4)).cpu().numpy(), gold[p + 'imgs_mean'], rtol=0, atol=1e-5)
+    assert state['imgs'].shape == pred_imgs.shape and len(state['hidden']) == 6 and state['masks'] is None
+    loss = T.l1_loss(select_end_images(pred_imgs, pred_ops, opt.end_id), tgt)
+    assert abs(loss.item() - float(gold[p + 'loss'])) < 1e-5                                    # L1 deviation <= 1e-5
+    loss.backward()
+    names = list(gold['param_names'])
+    params = dict(model.named_parameters())
+    gn = np.array([0.0 if params[n].grad is None else params[n].grad.double().norm().item() for n in names])
+    ref = gold[p + 'grad_norm']
+    big = ref > 1e-3 * ref.max()
+    np.testing.assert_allclose(gn[big], ref[big], rtol=2e-2)
+    # heads of unused operators get zeros here (gather over all heads) where the reference has None
+    none_ref = gold[p + 'grad_none']
+    assert np.all(gn[none_ref] == 0.0)
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_supervised_step_matches_reference(gold, mode):
+    dev = torch.device('cuda:0')
+    model, opt = make_model(dev)
+    model.train(mode == 'train')
+    p = 'sup_%s_' % mode
+    x = synth.requests(B, L, 41).to(dev)
+    img = synth.images(B, H, W, 42).to(dev)
+    y = synth.op_targets(B, 45)
+    img_y = synth.uniform((B, 6, 3, H, W), 46).to(dev)
+    gt_params = synth.uniform((B, 5, 24), 47, -1, 1)
+    nparam = {3: 1, 4: 1, 5: 1, 6: 24, 8: 8, 9: 1}
+    for b in range(B):
+        for k in range(5):
+            gt_params[b, k, nparam[int(y[b, k + 1])]:] = 0
+    y, gt_params = y.to(dev), gt_params.to(dev)
+    pred_imgs, pred_params, logp = model.supervised_forward(x, y, img, img_y, gt_params, None)
+    np.testing.assert_allclose(pred_params.detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), gold[p + 'logprobs'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=1e-4)
+    op_loss, param_loss = cpu_ref.supervised_loss(pred_params, logp, y, gt_params, opt)
+    assert abs(op_loss.item() - float(gold[p + 'op_loss'])) < 1e-4
+    assert abs(param_loss.item() - float(gold[p + 'param_loss'])) < 1e-4
+    (op_loss + param_loss).backward()
+    names = list(gold['param_names'])
+    params = dict(model.named_parameters())
+    gn = np.array([0.0 if params[n].grad is None else params[n].grad.double().norm().item() for n in names])
+    ref = gold[p + 'grad_norm']
+    big = ref > 1e-3 * ref.max()
+    np.testing.assert_allclose(gn[big], ref[big], rtol=2e-2)
+
+
+def test_trainer_alternates_and_learns():
+    """Two reference-style iterations (supervised then episode) run end to end and change the weights."""
+    from t2onet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    model, opt = make_model(dev)
+    model.train()
+    tr = Trainer(model, opt)
+    x = synth.requests(B, L, 41).to(dev)
+    img = synth.images(B, H, W, 42).to(dev)
+    y = synth.op_targets(B, 45).to(dev)
+    img_y = synth.uniform((B, 6, 3, H, W), 46).to(dev)
+    gt = synth.uniform((B, 5, 24), 47, -1, 1).to(dev)
+    w0 = model.decoder.out_linear.weight.detach().clone()
+    op_loss, param_loss = tr.step((img, img_y, x, y, gt))
+    l1 = tr.step((img, img_y, x, y, gt))
+    assert torch.isfinite(op_loss) and torch.isfinite(param_loss) and torch.isfinite(l1)
+    assert not torch.equal(w0, model.decoder.out_linear.weight.detach())
+    assert tr.grads.flat.numel() == 22165917

@@ -67,7 +67,8 @@ def test_episode_and_l1_step(gold, sd, mode):
     loss.backward()
     names = list(gold['param_names'])
     gn = np.array([0.0 if leaf[n].grad is None else leaf[n].grad.double().norm().item() for n in names])
-    np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-9)
+    # (entries that are pure rounding noise, e.g. weights feeding a train-mode BatchNorm, are below atol)
+    np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-6 * gold[p + 'grad_norm'].max())
     assert [leaf[n].grad is None for n in names] == list(gold[p + 'grad_none'])
     if mode == 'train':
         np.testing.assert_allclose(leaf['bn1.running_mean'].numpy(), gold['bn1_running_mean_after'], rtol=1e-5, atol=1e-7)
@@ -96,4 +97,5 @@ def test_supervised_step(gold, sd, mode):
     (op_loss + param_loss).backward()
     names = list(gold['param_names'])
     gn = np.array([0.0 if leaf[n].grad is None else leaf[n].grad.double().norm().item() for n in names])
-    np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-9)
+    # (entries that are pure rounding noise, e.g. weights feeding a train-mode BatchNorm, are below atol)
+    np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-6 * gold[p + 'grad_norm'].max())
