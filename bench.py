@@ -171,6 +171,56 @@ def cpu_baseline(B_sample, H, W, reps=3):
                       '(%.2f s each)' % (B_sample, H, W, reps, med)}
 
 
+def train_step_bench(device, dist, world, B, H, W, steps, warmup):
+    """BASELINE.json configs[2]/[3]: the episode/L1 train step of train_seq2seqL1.py:74-88 (request
+    encoder + 5 x (ResNet features + attention decoder step + sampled per-sample operator) +
+    END-image select + L1 + backward + one flat gradient all-reduce + Adam), FiveK-shaped synthetic
+    batch, random-init weights, fp32."""
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    opt = t2onet_amd.default_options()
+    torch.manual_seed(10 + (dist.get_rank() if dist is not None else 0))
+    model = Actor(opt).to(device).train()
+    if dist is not None:                                   # identical replicas
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    tr = Trainer(model, opt)
+    g = torch.Generator().manual_seed(10)
+    img = torch.rand(B, 3, H, W, generator=g).to(device)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(device)
+    n = torch.randint(1, 16, (B,), generator=g)
+    x = torch.zeros(B, 17, dtype=torch.long)
+    for b in range(B):
+        k = int(n[b])
+        x[b, 0] = 1
+        x[b, 1:1 + k] = torch.randint(4, 918, (k,), generator=g)
+        x[b, 1 + k] = 2
+    lengths = (x != 0).sum(1)
+    x = x.to(device)
+    for _ in range(warmup):
+        tr.episode_step(x, img, tgt, lengths=lengths)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.episode_step(x, img, tgt, lengths=lengths)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {'images_per_sec': round(world * B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 2),
+            'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()),
+            'workload': 'episode/L1 train step (train_seq2seqL1.py:74-88), bs=%d/GPU %dx%d fp32, sampled ops, '
+                        'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -180,6 +230,9 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16)
+    ap.add_argument('--train-steps', type=int, default=0,
+                    help='also time this many full episode/L1 train steps (BASELINE configs[2]/[3]) -> "train_step"')
+    ap.add_argument('--train-warmup', type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -236,6 +289,10 @@ def main():
     total_bytes = sum(algorithmic_bytes(n, P) for n in kernels)
     sum_ms = sum(k['ms'] for k in kernels.values())
 
+    train = None
+    if args.train_steps > 0:
+        train = train_step_bench(device, dist, world, B, H, W, args.train_steps, args.train_warmup)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         n_gpus = world
@@ -261,6 +318,8 @@ def main():
             'kernels': kernels,
             'loss': loss_value,
         }
+        if train is not None:
+            line['train_step'] = train
         if not args.no_cpu_baseline and n_gpus == 1:
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, H, W)
         print(json.dumps(line))

@@ -9,5 +9,6 @@ rocminfo 2>/dev/null | grep -m1 -E "gfx9" > $OUT/gpu.txt; nproc >> $OUT/gpu.txt;
 echo "== pytest -m gpu" ; timeout 1500 python -m pytest tests -m gpu -q --tb=short --maxfail=20 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 25 $OUT/pytest_gpu.log
 echo "== smoke"; timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 3 $OUT/smoke.log
 echo "== bench"; timeout 900 python bench.py --steps 30 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -n 5 $OUT/bench.err
+echo "== train step"; timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 5 > $OUT/bench_train.json 2> $OUT/bench_train.err; echo "train rc=$?"; python -c "import json,sys; d=json.loads(open('$OUT/bench_train.json').read().strip().splitlines()[-1]); print(d.get('train_step'))"; tail -n 3 $OUT/bench_train.err
 echo "== rocprofv3"; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?"
 find $OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -r head -n 40
