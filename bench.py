@@ -133,7 +133,7 @@ def algorithmic_bytes(name, P):
     return 36 * P
 
 
-def cpu_baseline(B_sample, H, W, reps=3):
+def cpu_baseline(B_sample, H, W, reps=7):
     """Oracle timed on the host cores: same sequence, fwd + L1 + bwd, on a bounded sample."""
     from oracle import cpu_ref
     img, tgt, params = make_inputs(B_sample, H, W, 'cpu')
@@ -229,7 +229,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=16)
+    ap.add_argument('--cpu-sample', type=int, default=64)
     ap.add_argument('--train-steps', type=int, default=0,
                     help='also time this many full episode/L1 train steps (BASELINE configs[2]/[3]) -> "train_step"')
     ap.add_argument('--train-warmup', type=int, default=2)

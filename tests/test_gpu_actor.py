@@ -1,6 +1,12 @@
 """The actor on the GPU (HIP executor + attention kernels, MIOpen/hipBLASLt for conv/LSTM/GEMM)
 against outputs of the reference itself (tests/golden/actor.npz from tools/gen_golden.py).
 
+Images are compared at 5e-4: the predicted operator parameters already differ from the
+reference's CPU run by up to ~1e-4 (they come out of the library ResNet/LSTM), and e.g.
+sharpness multiplies a parameter difference by up to 4 on a pixel; the hand-written kernels
+themselves are pinned at 1e-5 in test_gpu_operators.py.  Backward is only checked in train mode:
+MIOpen (like cuDNN) refuses an RNN backward in eval mode.
+
 Operator indices must be identical (argmax mode); floating-point outputs within 1e-4 of the
 reference's CPU run here: they pass through a 21-conv ResNet and two LSTMs whose library
 kernels (MIOpen vs oneDNN) round differently, before reaching the hand-written kernels."""
@@ -45,11 +51,13 @@ def test_episode_l1_step_matches_reference(gold, mode):
     state, pred_imgs, pred_ops, pred_params = model.episode_forward(x, img, None, reinforce_sample=0)
     np.testing.assert_array_equal(pred_ops.cpu().numpy(), gold[p + 'pred_ops'])             # bit-exact indices
     np.testing.assert_allclose(torch.stack(pred_params, 0).detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=5e-4)
     np.testing.assert_allclose(pred_imgs.detach().double().mean((2, 3, 4)).cpu().numpy(), gold[p + 'imgs_mean'], rtol=0, atol=1e-5)
     assert state['imgs'].shape == pred_imgs.shape and len(state['hidden']) == 6 and state['masks'] is None
     loss = T.l1_loss(select_end_images(pred_imgs, pred_ops, opt.end_id), tgt)
     assert abs(loss.item() - float(gold[p + 'loss'])) < 1e-5                                    # L1 deviation <= 1e-5
+    if mode == 'eval':
+        return
     loss.backward()
     names = list(gold['param_names'])
     params = dict(model.named_parameters())
@@ -81,10 +89,12 @@ def test_supervised_step_matches_reference(gold, mode):
     pred_imgs, pred_params, logp = model.supervised_forward(x, y, img, img_y, gt_params, None)
     np.testing.assert_allclose(pred_params.detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(logp.detach().cpu().numpy(), gold[p + 'logprobs'], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=5e-4)
     op_loss, param_loss = cpu_ref.supervised_loss(pred_params, logp, y, gt_params, opt)
     assert abs(op_loss.item() - float(gold[p + 'op_loss'])) < 1e-4
     assert abs(param_loss.item() - float(gold[p + 'param_loss'])) < 1e-4
+    if mode == 'eval':
+        return
     (op_loss + param_loss).backward()
     names = list(gold['param_names'])
     params = dict(model.named_parameters())
