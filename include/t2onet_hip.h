@@ -104,6 +104,22 @@ int t2o_sequence_bwd(const int* ops, int K, const float* img, const float* param
                      float* gimg, float* gparams, float* gbuf,
                      void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 
+/* ---- the same, FUSED: runs of pointwise operators execute in registers in one kernel pair;
+ * only the image at segment boundaries (before/after each sharpness, every 8 operators) goes
+ * through HBM.  out (B,3,H,W) = final image.  seg_bufs: t2o_fused_sequence_buffers(ops,K) images
+ * of scratch (B,3,H,W each), written by fwd and read by bwd.  Same results as t2o_sequence_*
+ * (bit-identical images; parameter gradients equal up to summation order). */
+int t2o_fused_sequence_buffers(const int* ops, int K);
+int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float* params,
+                           const float* target, float* out, float* loss, float* seg_bufs,
+                           void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+/* backward: either (target, gloss) -- fused L1, gout = NULL -- or target = NULL and gout =
+ * gradient w.r.t. the final image.  gbuf: scratch of 2 images. */
+int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float* params,
+                           const float* target, const float* gloss, const float* gout,
+                           float* gimg, float* gparams, const float* seg_bufs, float* gbuf,
+                           void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+
 /* ---- dot-product attention core, models/attention.py:37-40 ----
  * q (B,D), ctx (B,L,D) -> attn (B,L) = softmax_l(q . ctx_l) over ALL L rows (no padding
  * mask, as the reference), mix (B,D) = sum_l attn_l ctx_l.   D % 64 == 0, D <= 1024, L <= 64 */

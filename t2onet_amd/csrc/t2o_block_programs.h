@@ -450,6 +450,332 @@ T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const
   }
 }
 
+// ===================================================================== fused pointwise chain
+// A known operator list (executor benchmark, planner) applied in ONE pass: the image is read
+// once, the K pointwise operators run in registers, the result is written once.  Sharpness
+// (a stencil) ends a chain segment; the host splits sequences at it (t2o_kernels.hip).
+//
+// Curves use a per-sample table in LDS: knots k[c][8], running sums P[c][j] = sum_{i<j} k_i/8
+// accumulated in the reference's order, sum[c] and scale[c].  For a pixel value x in segment
+// i* = floor(8x):  total = P[i*] + clamp(x - i*/8, 0, 1/8) * k[i*]  -- bit-identical to the
+// reference's 8-term loop (the terms before i* are exactly k_i/8, the ones after are exactly 0),
+// at a quarter of the arithmetic.
+constexpr int kMaxChain = 8;
+constexpr int kTabStride = 64;           // floats per operator in the LDS table
+constexpr int kTabK = 0, kTabP = 24, kTabSum = 51, kTabScale = 54;
+constexpr int kAccStride = 65;           // floats per slot row of the LDS accumulators (64 quads + pad)
+
+struct ChainArgs {
+  const float* img;        // (B,3,H,W) segment input
+  const float* params;     // (Ktotal,B,24) parameters of the whole sequence; operator k uses row src[k]
+  const float* gout;       // backward: gradient w.r.t. the segment output (null when L1 fused)
+  const float* target;     // fused L1 target or null
+  const float* gloss;      // fused L1 backward: device scalar
+  float* out;              // forward: segment output
+  float* gimg;             // backward: gradient w.r.t. the segment input (or null)
+  float* partials;         // backward: (B, nblk, S) raw parameter-gradient sums
+  float* loss_partials;    // fused L1 forward: (B, nblk)
+  int ops[kMaxChain];
+  int src[kMaxChain];            // index of operator k in the sequence's params / gparams
+  int slot_off[kMaxChain + 1];   // first accumulator slot of operator k; S = slot_off[K]
+  int K, B, H, W, iters, nblk;
+  float inv_n;
+};
+
+T2O_HD bool is_curve(int op) { return op == OP_COLOR || op == OP_TONE; }
+
+// One thread per operator builds that operator's table row.
+T2O_HD void chain_build_table(const ChainArgs& a, int b, int k, float* tab) {
+  float* t = tab + k * kTabStride;
+  const float* p = a.params + ((size_t)a.src[k] * a.B + b) * kMaxParam;
+  const int op = a.ops[k];
+  if (!is_curve(op)) { t[0] = p[0]; return; }
+  for (int c = 0; c < 3; ++c) {
+    const float* row = op == OP_COLOR ? p + c * kCurveSteps : p;
+    float s = 0.0f, run = 0.0f;
+    for (int i = 0; i < kCurveSteps; ++i) {
+      t[kTabK + c * kCurveSteps + i] = row[i];
+      t[kTabP + c * (kCurveSteps + 1) + i] = run;
+      run = run + (1.0f / kCurveSteps) * row[i];
+      s = s + row[i];
+    }
+    t[kTabP + c * (kCurveSteps + 1) + kCurveSteps] = run;
+    s = s + 1e-10f;
+    t[kTabSum + c] = s;
+    t[kTabScale + c] = (1.0f / s) * (float)kCurveSteps;
+  }
+}
+
+// segment index and clamped offset inside it
+T2O_HD void curve_locate(float x, int& i, float& frac) {
+  const float x8 = fminf(fmaxf(x * (float)kCurveSteps, 0.0f), (float)kCurveSteps - 0.5f);
+  i = (int)x8;
+  frac = fminf(fmaxf(x - (float)i / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+}
+
+// pre-clamp output of a curve operator for channel c
+T2O_HD float curve_lut_fwd(const float* t, bool color, int c, float x) {
+  const int cc = color ? c : 0;
+  int i; float frac;
+  curve_locate(x, i, frac);
+  const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * t[kTabK + cc * kCurveSteps + i];
+  return color ? total * t[kTabScale + cc] : (total * (float)kCurveSteps) / t[kTabSum + cc];
+}
+
+// forward of chain operator `op` on one pixel (pre-clamp); t = this operator's table row
+T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
+  Rgb o;
+  switch (op) {
+    case OP_BRIGHTNESS: return brightness_fwd(x, t[0]);
+    case OP_CONTRAST:   return contrast_fwd(x, t[0]);
+    case OP_SATURATION: return saturation_fwd(x, t[0]);
+    case OP_COLOR:
+    case OP_TONE:
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) o.c[c] = curve_lut_fwd(t, op == OP_COLOR, c, x.c[c]);
+      return o;
+    case OP_WHITE: o.c[0] = o.c[1] = o.c[2] = 1.0f; return o;
+    default: return x;
+  }
+}
+
+// backward of chain operator `op` on one pixel: g = gradient w.r.t. the CLAMPED output;
+// returns the gradient w.r.t. the input, adds raw parameter sums to red[0..n)
+T2O_HD Rgb chain_op_bwd(int op, const Rgb& x, const float* t, const Rgb& g, float* red) {
+  Rgb gx;
+  if (is_curve(op)) {
+    const bool color = op == OP_COLOR;
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      const int cc = color ? c : 0;
+      const float* kk = t + kTabK + cc * kCurveSteps;
+      int i; float frac;
+      curve_locate(x.c[c], i, frac);
+      const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * kk[i];
+      const float z = color ? total * t[kTabScale + cc] : (total * (float)kCurveSteps) / t[kTabSum + cc];
+      const float dz = (z >= 0.0f && z <= 1.0f) ? g.c[c] : 0.0f;
+      const float d = x.c[c] - (float)i / kCurveSteps;
+      float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
+      if (d == 0.0f && i > 0) slope += kk[i - 1];                   // on a knot both neighbours pass (inclusive clamp)
+      gx.c[c] = dz * t[kTabScale + cc] * slope;
+      float* r = red + cc * kCurveSteps;
+      T2O_UNROLL
+      for (int j = 0; j < kCurveSteps; ++j)
+        r[j] += dz * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+    }
+    return gx;
+  }
+  if (op == OP_WHITE) { gx.c[0] = gx.c[1] = gx.c[2] = 0.0f; return gx; }
+  const Rgb r = chain_op_fwd(op, x, t);
+  Rgb dz;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) dz.c[c] = (r.c[c] >= 0.0f && r.c[c] <= 1.0f) ? g.c[c] : 0.0f;
+  Curve unused;
+  float p0[1] = {t[0]};
+  return pointwise_bwd(op, x, p0, unused, dz, red);
+}
+
+template <int V, bool L1>
+T2O_HD float chain_fwd_thread(const ChainArgs& a, int b, int blk, int tid, const float* tab) {
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const unsigned groups = hw / V;
+  const size_t sb = (size_t)b * 3 * hw;
+  const float* xin = a.img + sb;
+  float* o = a.out + sb;
+  float l1 = 0.0f;
+  for (int it = 0; it < a.iters; ++it) {
+    const unsigned g = ((unsigned)blk * a.iters + it) * kThreads + tid;
+    if (g >= groups) break;
+    const unsigned px = g * V;
+    float x[3][V];
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) load_vec<V>(xin + c * hw + px, x[c]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int k = 0; k < a.K; ++k) {                 // a real loop: the forward keeps no per-operator state
+      T2O_RELOAD_FENCE();
+      {
+        const int op = a.ops[k];
+        T2O_UNROLL
+        for (int i = 0; i < V; ++i) {
+          Rgb xi = {{x[0][i], x[1][i], x[2][i]}};
+          const Rgb r = chain_op_fwd(op, xi, tab + k * kTabStride);
+          T2O_UNROLL
+          for (int c = 0; c < 3; ++c) x[c][i] = clamp01(r.c[c]);
+        }
+      }
+    }
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) store_vec<V>(o + c * hw + px, x[c]);
+    if (L1) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        float t[V];
+        load_vec<V>(a.target + sb + c * hw + px, t);
+        T2O_UNROLL
+        for (int i = 0; i < V; ++i) l1 += fabsf(x[c][i] - t[i]);
+      }
+    }
+  }
+  return l1;
+}
+
+// ACC::add(slot, value) accumulates a raw parameter sum (device: quad reduce + LDS; host: array).
+// `sv` = per-thread save area in LDS for the input of every operator: element
+// ((k*3 + c)*V + i) of thread tid lives at sv[(((k*3 + c)*V + i) * kThreads) + tid] (bank-conflict
+// free), so both operator loops are real loops with a run-time k: compact code, few registers.
+template <int V>
+T2O_HD int chain_save_floats(int K) { return K * 3 * V * kThreads; }
+
+template <int V, bool L1, class ACC>
+T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* sv, ACC& acc) {
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const unsigned groups = hw / V;
+  const size_t sb = (size_t)b * 3 * hw;
+  const float* xin = a.img + sb;
+  const float* gin = (L1 ? a.target : a.gout) + sb;
+  const float gs = L1 ? a.gloss[0] * a.inv_n : 0.0f;
+  for (int it = 0; it < a.iters; ++it) {
+    const unsigned g = ((unsigned)blk * a.iters + it) * kThreads + tid;
+    const bool live = g < groups;                 // dead threads still take part in the quad reductions
+    const unsigned px = live ? g * V : 0;
+    float x[3][V], gg[3][V];
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      load_vec<V>(xin + c * hw + px, x[c]);
+      load_vec<V>(gin + c * hw + px, gg[c]);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int k = 0; k < a.K; ++k) {
+      T2O_RELOAD_FENCE();
+      const int op = a.ops[k];
+      T2O_UNROLL
+      for (int i = 0; i < V; ++i) {
+        Rgb xi = {{x[0][i], x[1][i], x[2][i]}};
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) sv[((k * 3 + c) * V + i) * kThreads + tid] = xi.c[c];
+        const Rgb r = chain_op_fwd(op, xi, tab + k * kTabStride);
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) x[c][i] = clamp01(r.c[c]);
+      }
+    }
+    if (L1) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        T2O_UNROLL
+        for (int i = 0; i < V; ++i) gg[c][i] = sign_of(x[c][i] - gg[c][i]) * gs;
+      }
+    }
+    if (!live) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        T2O_UNROLL
+        for (int i = 0; i < V; ++i) gg[c][i] = 0.0f;
+      }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int k = a.K - 1; k >= 0; --k) {
+      T2O_RELOAD_FENCE();
+      const int op = a.ops[k];
+      float red[kRedSlots];
+      T2O_UNROLL
+      for (int j = 0; j < kRedSlots; ++j) red[j] = 0.0f;
+      T2O_UNROLL
+      for (int i = 0; i < V; ++i) {
+        Rgb xi, gi = {{gg[0][i], gg[1][i], gg[2][i]}};
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) xi.c[c] = sv[((k * 3 + c) * V + i) * kThreads + tid];
+        const Rgb gx = chain_op_bwd(op, xi, tab + k * kTabStride, gi, red);
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) gg[c][i] = gx.c[c];
+      }
+      const int n = op == OP_COLOR ? 24 : op == OP_TONE ? 8 : op == OP_WHITE ? 0 : 1;
+      T2O_UNROLL
+      for (int j = 0; j < kRedSlots; ++j)
+        if (j < n) acc.add(a.slot_off[k] + j, red[j]);
+    }
+    if (a.gimg && live) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) store_vec<V>(a.gimg + sb + c * hw + px, gg[c]);
+    }
+  }
+}
+
+// ===================================================================== sequence planning (host)
+// A sequence is cut into segments: maximal runs of pointwise operators (<= kMaxChain) that one
+// fused kernel pair handles, and single sharpness operators (stencil kernels).  Identity (-1)
+// entries are dropped.  Only segment boundaries are materialised in HBM.
+struct Segment {
+  int first, count;     // operators [first, first+count) of the ORIGINAL list (count == 1 for sharpness)
+  bool sharp;
+  int ops[kMaxChain];   // chain: the operator ids; identity entries removed
+  int src[kMaxChain];   // chain: index in the original list of each kept operator
+  int n;                // chain: number of kept operators (may be 0: pure copy)
+};
+
+// returns the number of segments (>= 1), or -1 for an unsupported operator id
+inline int plan_segments(const int* ops, int K, Segment* seg, int max_seg) {
+  int ns = 0;
+  Segment cur;
+  cur.first = 0; cur.count = 0; cur.sharp = false; cur.n = 0;
+  for (int k = 0; k < K; ++k) {
+    const int op = ops[k];
+    if (!(op == OP_IDENTITY || (op >= 0 && op <= 7 && op != OP_INPAINT))) return -1;
+    if (op == OP_SHARPNESS || (op != OP_IDENTITY && cur.n == kMaxChain)) {
+      if (cur.n > 0) {
+        if (ns >= max_seg) return -1;
+        seg[ns++] = cur;
+      }
+      cur.first = k; cur.count = 0; cur.sharp = false; cur.n = 0;
+    }
+    if (op == OP_SHARPNESS) {
+      Segment s;
+      s.first = k; s.count = 1; s.sharp = true; s.n = 0;
+      if (ns >= max_seg) return -1;
+      seg[ns++] = s;
+      cur.first = k + 1;
+      continue;
+    }
+    if (op != OP_IDENTITY) { cur.ops[cur.n] = op; cur.src[cur.n] = k; ++cur.n; }
+    ++cur.count;
+  }
+  if (cur.n > 0 || ns == 0) {
+    if (ns >= max_seg) return -1;
+    seg[ns++] = cur;
+  }
+  return ns;
+}
+
+inline void chain_geometry(int B, int H, int W, int forced_iters, int& vec, int& iters, int& nblk) {
+  const size_t hw = (size_t)H * W;
+  vec = (hw % 2 == 0) ? 2 : 1;
+  const size_t groups = hw / vec;
+  size_t it = forced_iters > 0 ? (size_t)forced_iters : (groups * (size_t)B) / ((size_t)kThreads * 4096);
+  if (it < 1) it = 1;
+  if (it > 8) it = 8;
+  iters = (int)it;
+  nblk = (int)((groups + (size_t)kThreads * it - 1) / ((size_t)kThreads * it));
+}
+
+inline void chain_fill(ChainArgs& a, const Segment& s, int B, int H, int W, int iters, int nblk) {
+  a.K = s.n; a.B = B; a.H = H; a.W = W; a.iters = iters; a.nblk = nblk;
+  a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
+  int off = 0;
+  for (int k = 0; k < kMaxChain; ++k) {
+    a.ops[k] = k < s.n ? s.ops[k] : OP_IDENTITY;
+    a.src[k] = k < s.n ? s.src[k] : 0;
+    a.slot_off[k] = off;
+    if (k < s.n) off += (s.ops[k] == OP_COLOR ? 24 : s.ops[k] == OP_TONE ? 8 : s.ops[k] == OP_WHITE ? 0 : 1);
+  }
+  a.slot_off[kMaxChain] = off;
+}
+constexpr int kMaxChainSlots = kMaxChain * kMaxParam;   // 192
+
 // ===================================================================== launch geometry (host)
 struct Geometry {
   int vec;         // 4 when H*W % 4 == 0 (pointwise kernels use 16-byte accesses)

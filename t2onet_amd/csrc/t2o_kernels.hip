@@ -157,6 +157,67 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd(OpArgs a, int tiles) {
   block_reduce_store1(red0, a.partials + ((size_t)b * a.nblk_max + tile) * kRedSlots);
 }
 
+// ------------------------------------------------------------------ fused pointwise chain
+// raw parameter sums: quad (4-lane) DPP reduction, then one owner lane adds into its private LDS cell
+struct LdsAcc {
+  float* acc;
+  __device__ __forceinline__ void add(int slot, float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    if ((threadIdx.x & 3) == 0) acc[slot * kAccStride + (threadIdx.x >> 2)] += v;
+  }
+};
+
+template <int V, bool L1>
+__global__ __launch_bounds__(kThreads) void k_chain_fwd(ChainArgs a) {
+  __shared__ float tab[kMaxChain * kTabStride];
+  int b, blk;
+  wg_coords(a.nblk, b, blk);
+  if ((int)threadIdx.x < a.K) chain_build_table(a, b, threadIdx.x, tab);
+  __syncthreads();
+  const float l1 = chain_fwd_thread<V, L1>(a, b, blk, threadIdx.x, tab);
+  if (L1) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk);
+}
+
+template <int V, bool L1>
+__global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [accumulators: S rows of kAccStride][save area]
+  __shared__ float tab[kMaxChain * kTabStride];
+  int b, blk;
+  wg_coords(a.nblk, b, blk);
+  const int S = a.slot_off[kMaxChain];
+  for (int i = threadIdx.x; i < S * kAccStride; i += kThreads) lds[i] = 0.0f;
+  if ((int)threadIdx.x < a.K) chain_build_table(a, b, threadIdx.x, tab);
+  __syncthreads();
+  LdsAcc acc{lds};
+  chain_bwd_thread<V, L1>(a, b, blk, threadIdx.x, tab, lds + S * kAccStride, acc);
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += kThreads) {
+    float sum = 0.0f;
+    for (int q = 0; q < kThreads / 4; ++q) sum += lds[s * kAccStride + q];
+    a.partials[((size_t)b * a.nblk + blk) * S + s] = sum;
+  }
+}
+
+// one workgroup per sample: per-block sums -> raw sums -> parameter gradients of every chain operator
+__global__ __launch_bounds__(kThreads) void k_chain_finalize(ChainArgs a, float* gparams) {
+  __shared__ float sums[kMaxChainSlots];
+  const int b = blockIdx.x;
+  const int S = a.slot_off[kMaxChain];
+  for (int s = threadIdx.x; s < S; s += kThreads) {
+    float acc = 0.0f;
+    for (int k = 0; k < a.nblk; ++k) acc += a.partials[((size_t)b * a.nblk + k) * S + s];
+    sums[s] = acc;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < a.K) {
+    const int k = threadIdx.x, op = a.ops[k];
+    float* grow = gparams + ((size_t)a.src[k] * a.B + b) * kMaxParam;
+    for (int i = 0; i < kMaxParam; ++i) grow[i] = 0.0f;
+    finalize_param_grad(op, a.params + ((size_t)a.src[k] * a.B + b) * kMaxParam, sums + a.slot_off[k], grow);
+  }
+}
+
 // ------------------------------------------------------------------ finalisation kernels
 // One workgroup per sample: sum the per-block raw sums in a fixed order, then raw sums -> gparam.
 // Thread t owns slot (t % 32) of every 8th block row starting at (t / 32): 96-byte coalesced reads.
@@ -319,8 +380,15 @@ Geometry launch_geometry(int B, int H, int W) {
   return t2o::geometry(B, H, W, forced);
 }
 
-size_t ws_partials_floats(const Geometry& g, int B) { return (size_t)B * g.nblk_max * kRedSlots; }
-size_t ws_loss_floats(const Geometry& g, int B) { return (size_t)B * g.nblk_max; }
+// Workspace = [raw parameter sums][loss partials].  Block rows per sample = the larger of the
+// per-operator geometry and the fused-chain geometry; kMaxChainSlots floats per block row.
+size_t ws_block_rows(const Geometry& g, int B, int H, int W) {
+  int vec, iters, nblk;
+  chain_geometry(B, H, W, env_int("T2O_CHAIN_ITERS", 0), vec, iters, nblk);
+  return (size_t)(g.nblk_max > nblk ? g.nblk_max : nblk);
+}
+size_t ws_partials_floats(const Geometry& g, int B, int H, int W) { return (size_t)B * ws_block_rows(g, B, H, W) * kMaxChainSlots; }
+size_t ws_loss_floats(const Geometry& g, int B, int H, int W) { return (size_t)B * ws_block_rows(g, B, H, W); }
 
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -424,7 +492,7 @@ int run_fwd(int op, const int* op_id, const float* img, const float* param, int 
   if (target) {
     if (!loss) return fail(T2O_EINVAL, "loss is null");
     if (!ws || ws_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
-    a.loss_partials = (float*)ws + ws_partials_floats(g, B);
+    a.loss_partials = (float*)ws + ws_partials_floats(g, B, H, W);
   }
   hipStream_t st = (hipStream_t)stream;
   if (op != OP_SHARPNESS) launch_point_fwd(a, g, st);
@@ -471,7 +539,7 @@ int t2o_op_num_params(int op) { return (op >= 0 && op <= 7) ? op_num_params(op) 
 size_t t2o_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const Geometry g = launch_geometry(B, H, W);
-  size_t f = ws_partials_floats(g, B) + ws_loss_floats(g, B);
+  size_t f = ws_partials_floats(g, B, H, W) + ws_loss_floats(g, B, H, W);
   // plain L1 over the same number of floats uses the partial area too
   const size_t n = (size_t)B * 3 * H * W;
   const size_t l1blk = n / ((size_t)kThreads * 8) + 2;      // k_l1_fwd partials, worst case V = 1
@@ -592,6 +660,112 @@ int t2o_sequence_bwd(const int* ops, int K, const float* img, const float* param
     gcur = gout_next;
   }
   return T2O_OK;
+}
+
+
+int t2o_fused_sequence_buffers(const int* ops, int K) {
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  return ns < 0 ? -1 : ns - 1;
+}
+
+static int fused_chain_launch_fwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
+  const unsigned grid = (unsigned)a.B * a.nblk;
+  if (vec == 2) { if (l1) k_chain_fwd<2, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<2, false><<<grid, kThreads, 0, st>>>(a); }
+  else          { if (l1) k_chain_fwd<1, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<1, false><<<grid, kThreads, 0, st>>>(a); }
+  return 0;
+}
+static int fused_chain_launch_bwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
+  const unsigned grid = (unsigned)a.B * a.nblk;
+  const size_t lds = sizeof(float) * ((size_t)a.slot_off[kMaxChain] * kAccStride +
+                                      (vec == 2 ? chain_save_floats<2>(a.K) : chain_save_floats<1>(a.K)));
+  if (vec == 2) { if (l1) k_chain_bwd<2, true><<<grid, kThreads, lds, st>>>(a); else k_chain_bwd<2, false><<<grid, kThreads, lds, st>>>(a); }
+  else          { if (l1) k_chain_bwd<1, true><<<grid, kThreads, lds, st>>>(a); else k_chain_bwd<1, false><<<grid, kThreads, lds, st>>>(a); }
+  return 0;
+}
+
+int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float* params, const float* target,
+                           float* out, float* loss, float* seg_bufs, void* workspace, size_t workspace_bytes, int B,
+                           int H, int W, void* stream) {
+  if (!ops || K < 0 || !img || !out || (K > 0 && !params)) return fail(T2O_EINVAL, "fused_sequence_fwd: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0) return fail(T2O_EINVAL, "B, H, W must be positive");
+  if (target && !loss) return fail(T2O_EINVAL, "loss is null");
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  if (ns < 0) return fail(T2O_EUNSUPPORTED, "operator index not supported, or more than 64 segments");
+  if (ns > 1 && !seg_bufs) return fail(T2O_EINVAL, "seg_bufs is null (see t2o_fused_sequence_buffers)");
+  if (target && (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W))) return fail(T2O_EWORKSPACE, "workspace too small");
+  static const int forced = env_int("T2O_CHAIN_ITERS", 0);
+  int vec, iters, nblk;
+  chain_geometry(B, H, W, forced, vec, iters, nblk);
+  const Geometry g = launch_geometry(B, H, W);
+  const size_t img_floats = (size_t)B * 3 * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  const float* cur = img;
+  for (int s = 0; s < ns; ++s) {
+    float* dst = (s == ns - 1) ? out : seg_bufs + (size_t)s * img_floats;
+    const bool last = (s == ns - 1) && target;
+    if (seg[s].sharp) {
+      const int k = seg[s].first;
+      const int rc = run_fwd(OP_SHARPNESS, nullptr, cur, params + (size_t)k * B * kMaxParam, kMaxParam, nullptr, 0,
+                             last ? target : nullptr, dst, last ? loss : nullptr, workspace, workspace_bytes, B, H, W, stream);
+      if (rc) return rc;
+    } else {
+      ChainArgs a;
+      memset(&a, 0, sizeof(a));
+      chain_fill(a, seg[s], B, H, W, iters, nblk);
+      a.img = cur; a.params = params; a.out = dst; a.target = last ? target : nullptr;
+      if (last) a.loss_partials = (float*)workspace + ws_partials_floats(g, B, H, W);
+      fused_chain_launch_fwd(a, vec, last, st);
+      if (last) k_l1_finalize<<<1, kThreads, 0, st>>>(a.loss_partials, B * nblk, a.inv_n, loss);
+    }
+    cur = dst;
+  }
+  return check_launch("fused sequence forward");
+}
+
+int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float* params, const float* target,
+                           const float* gloss, const float* gout, float* gimg, float* gparams, const float* seg_bufs,
+                           float* gbuf, void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (!ops || K < 0 || !img || (K > 0 && (!params || !gparams)))
+    return fail(T2O_EINVAL, "fused_sequence_bwd: null pointer");
+  if (target ? !gloss : !gout) return fail(T2O_EINVAL, "fused_sequence_bwd: give (target, gloss) or gout");
+  if (B <= 0 || H <= 0 || W <= 0) return fail(T2O_EINVAL, "B, H, W must be positive");
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  if (ns < 0) return fail(T2O_EUNSUPPORTED, "operator index not supported, or more than 64 segments");
+  if (ns > 1 && (!seg_bufs || !gbuf)) return fail(T2O_EINVAL, "seg_bufs / gbuf is null");
+  if (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
+  static const int forced = env_int("T2O_CHAIN_ITERS", 0);
+  int vec, iters, nblk;
+  chain_geometry(B, H, W, forced, vec, iters, nblk);
+  const size_t img_floats = (size_t)B * 3 * H * W;
+  hipStream_t st = (hipStream_t)stream;
+  if (K > 0) hipMemsetAsync(gparams, 0, sizeof(float) * (size_t)K * B * kMaxParam, st);
+  const float* gcur = nullptr;
+  for (int s = ns - 1; s >= 0; --s) {
+    const float* in = s == 0 ? img : seg_bufs + (size_t)(s - 1) * img_floats;
+    float* gnext = s == 0 ? gimg : gbuf + (size_t)(s & 1) * img_floats;
+    const bool last = (s == ns - 1) && target;     // fused L1: the last segment reads the target instead of a gradient
+    if (s == ns - 1 && !target) gcur = gout;
+    if (seg[s].sharp) {
+      const int k = seg[s].first;
+      const int rc = run_bwd(OP_SHARPNESS, nullptr, in, params + (size_t)k * B * kMaxParam, kMaxParam, nullptr, 0,
+                             last ? nullptr : gcur, last ? target : nullptr, last ? gloss : nullptr, gnext,
+                             gparams + (size_t)k * B * kMaxParam, kMaxParam, workspace, workspace_bytes, B, H, W, stream);
+      if (rc) return rc;
+    } else {
+      ChainArgs a;
+      memset(&a, 0, sizeof(a));
+      chain_fill(a, seg[s], B, H, W, iters, nblk);
+      a.img = in; a.params = params; a.gimg = gnext; a.partials = (float*)workspace;
+      if (last) { a.target = target; a.gloss = gloss; } else { a.gout = gcur; }
+      fused_chain_launch_bwd(a, vec, last, st);
+      if (a.K > 0) k_chain_finalize<<<B, kThreads, 0, st>>>(a, gparams);
+    }
+    gcur = gnext;
+  }
+  return check_launch("fused sequence backward");
 }
 
 int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix, int B, int L, int D, void* stream) {

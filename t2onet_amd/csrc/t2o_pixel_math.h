@@ -46,10 +46,14 @@ __device__ __forceinline__ float t2o_chain(float v, float dep) { asm volatile(""
 // v must have been computed by this point (volatile asms keep their order): stops accumulations
 // from being deferred with their inputs held in registers.
 #define T2O_KEEP(v) asm volatile("" ::"v"(v))
+// Compiler-level memory barrier: values loaded from LDS tables before it are not kept in
+// registers across it (stops loop-invariant table reads being hoisted into 50+ VGPRs).
+#define T2O_RELOAD_FENCE() asm volatile("" ::: "memory")
 #else
 #define T2O_OPAQUE(v) (v)
 #define T2O_CHAIN(v, dep) (v)
 #define T2O_KEEP(v) ((void)0)
+#define T2O_RELOAD_FENCE() ((void)0)
 #endif
 
 namespace t2o {

@@ -78,13 +78,22 @@ class Executor(nn.Module):
         param = self.predict_params(op_ids, features) if features is not None else specified_param
         return T.apply_per_sample(op_ids, img, param, mask), param
 
+    @staticmethod
+    def _pad_params(img, params):
+        if torch.is_tensor(params):
+            return params
+        B = img.shape[0]
+        rows = [torch.cat([p, p.new_zeros(B, PARAM_PAD - p.shape[1])], 1) if p.shape[1] < PARAM_PAD else p for p in params]
+        return torch.stack(rows, 0)
+
     def run_sequence(self, img, ops, params, target):
         """ops: python ints; params: list of (B,n_k) or a (K,B,24) tensor.
-        Returns (loss = mean |out_K - target|, acts (K,B,3,H,W))."""
-        if not torch.is_tensor(params):
-            B = img.shape[0]
-            rows = []
-            for p in params:
-                rows.append(torch.cat([p, p.new_zeros(B, PARAM_PAD - p.shape[1])], 1) if p.shape[1] < PARAM_PAD else p)
-            params = torch.stack(rows, 0)
-        return T.sequence_l1(img, ops, params, target)
+        Returns (loss = mean |out_K - target|, acts (K,B,3,H,W)): every intermediate image is
+        materialised, exactly what K calls of execute() would return."""
+        return T.sequence_l1(img, ops, self._pad_params(img, params), target)
+
+    def run_sequence_fused(self, img, ops, params, target):
+        """Same sequence, same loss and gradients, but runs of per-pixel operators execute in
+        registers (one read of the image, one write): returns (loss, out (B,3,H,W)) -- for callers
+        that only need the end result, like the planner's candidate evaluation."""
+        return T.fused_sequence_l1(img, ops, self._pad_params(img, params), target)

@@ -244,3 +244,55 @@ class _SequenceFn(torch.autograd.Function):
 def sequence_l1(img, ops, params, target):
     """Apply ops[k] with params[k] (K,B,24) in order; returns (mean |out - target|, acts (K,B,3,H,W))."""
     return _SequenceFn.apply(img, params, target, [int(o) for o in ops])
+
+
+class _FusedSequenceFn(torch.autograd.Function):
+    """A known operator list with runs of pointwise operators fused in registers; only the
+    final image (and the images around each sharpness) exist in HBM."""
+
+    @staticmethod
+    def forward(ctx, img, params, target, ops):
+        _need_gpu(img, params, target)
+        img, params, target = _img(img), params.contiguous(), _img(target)
+        B, _, H, W = img.shape
+        K = len(ops)
+        if params.shape != (K, B, PARAM_PAD):
+            raise ValueError('params must be (K,B,24)')
+        lib = _lib.load()
+        c_ops = (ctypes.c_int * max(K, 1))(*ops)
+        nbuf = lib.t2o_fused_sequence_buffers(c_ops, K)
+        if nbuf < 0:
+            raise RuntimeError('unsupported operator in sequence %s' % (ops,))
+        seg = torch.empty((max(nbuf, 1),) + tuple(img.shape), dtype=torch.float32, device=img.device)
+        out = torch.empty_like(img)
+        loss = torch.empty((), dtype=torch.float32, device=img.device)
+        ws = workspace(B, H, W, img.device)
+        rc = lib.t2o_fused_sequence_fwd(c_ops, K, _ptr(img), _ptr(params), _ptr(target), _ptr(out), _ptr(loss),
+                                        _ptr(seg), _ptr(ws), ws.numel(), B, H, W, _stream())
+        _lib.check(rc, 't2o_fused_sequence_fwd')
+        ctx.save_for_backward(img, params, target, seg)
+        ctx.ops = tuple(ops)
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, gloss, _gout):
+        img, params, target, seg = ctx.saved_tensors
+        B, _, H, W = img.shape
+        K = len(ctx.ops)
+        gloss = gloss.contiguous().to(torch.float32)
+        gimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        gparams = torch.empty_like(params)
+        gbuf = torch.empty((2,) + tuple(img.shape), dtype=torch.float32, device=img.device)
+        ws = workspace(B, H, W, img.device)
+        c_ops = (ctypes.c_int * max(K, 1))(*ctx.ops)
+        rc = _lib.load().t2o_fused_sequence_bwd(c_ops, K, _ptr(img), _ptr(params), _ptr(target), _ptr(gloss), None,
+                                                _ptr(gimg), _ptr(gparams), _ptr(seg), _ptr(gbuf), _ptr(ws), ws.numel(),
+                                                B, H, W, _stream())
+        _lib.check(rc, 't2o_fused_sequence_bwd')
+        return gimg, gparams, None, None
+
+
+def fused_sequence_l1(img, ops, params, target):
+    """Like sequence_l1 but fused: returns (mean |out - target|, out (B,3,H,W))."""
+    return _FusedSequenceFn.apply(img, params, target, [int(o) for o in ops])

@@ -56,3 +56,24 @@ def bwd(op, img, param, gout=None, mask=None, op_id=None, target=None, gloss=1.0
                         gparam.shape[1], B, H, W, iters)
     assert rc == 0
     return gimg, gparam
+
+
+def fused(ops, img, params, target, gloss=1.0, iters=0):
+    """Fused sequence forward + backward.  params (K,B,24).  Returns out, loss, gimg, gparams."""
+    img, params, target = _f(img), _f(params), _f(target)
+    B, _, H, W = img.shape
+    K = len(ops)
+    c_ops = (ctypes.c_int * max(K, 1))(*ops)
+    nbuf = lib().emul_fused_buffers(c_ops, K)
+    assert nbuf >= 0
+    seg = np.zeros((max(nbuf, 1),) + img.shape, np.float32)
+    gbuf = np.zeros((2,) + img.shape, np.float32)
+    out = np.empty_like(img)
+    loss = np.zeros(1, np.float32)
+    assert lib().emul_fused_fwd(c_ops, K, _p(img), _p(params), _p(target), _p(out), _p(loss), _p(seg), B, H, W, iters) == 0
+    gimg = np.empty_like(img)
+    gparams = np.zeros_like(params)
+    gl = np.array([gloss], np.float32)
+    assert lib().emul_fused_bwd(c_ops, K, _p(img), _p(params), _p(target), _p(gl), _p(gimg), _p(gparams), _p(seg),
+                                _p(gbuf), B, H, W, iters) == 0
+    return out, float(loss[0]), gimg, gparams

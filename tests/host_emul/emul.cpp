@@ -116,4 +116,104 @@ int emul_bwd(int op, const int* op_id, const float* img, const float* param, int
   return 0;
 }
 
+
+struct HostAcc {
+  float* sums;
+  void add(int slot, float v) { sums[slot] += v; }
+};
+
+// fused sequence, forward: chain segments + sharpness segments, boundaries in seg_bufs
+int emul_fused_fwd(const int* ops, int K, const float* img, const float* params, const float* target, float* out,
+                   float* loss, float* seg_bufs, int B, int H, int W, int forced_iters) {
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  if (ns < 0) return 2;
+  int vec, iters, nblk;
+  chain_geometry(B, H, W, forced_iters, vec, iters, nblk);
+  const size_t img_floats = (size_t)B * 3 * H * W;
+  const float* cur = img;
+  for (int s = 0; s < ns; ++s) {
+    float* dst = (s == ns - 1) ? out : seg_bufs + (size_t)s * img_floats;
+    const bool last = (s == ns - 1) && target;
+    if (seg[s].sharp) {
+      const int k = seg[s].first;
+      emul_fwd(OP_SHARPNESS, nullptr, cur, params + (size_t)k * B * kMaxParam, kMaxParam, nullptr, 0,
+               last ? target : nullptr, dst, loss, B, H, W, forced_iters);
+    } else {
+      ChainArgs a;
+      memset(&a, 0, sizeof(a));
+      chain_fill(a, seg[s], B, H, W, iters, nblk);
+      a.img = cur; a.params = params; a.out = dst; a.target = last ? target : nullptr;
+      double total = 0.0;
+      for (int b = 0; b < B; ++b) {
+        std::vector<float> tab(kMaxChain * kTabStride, 0.0f);
+        for (int k = 0; k < a.K; ++k) chain_build_table(a, b, k, tab.data());
+        for (int blk = 0; blk < nblk; ++blk)
+          for (int tid = 0; tid < kThreads; ++tid) {
+            if (vec == 2) total += last ? chain_fwd_thread<2, true>(a, b, blk, tid, tab.data()) : chain_fwd_thread<2, false>(a, b, blk, tid, tab.data());
+            else total += last ? chain_fwd_thread<1, true>(a, b, blk, tid, tab.data()) : chain_fwd_thread<1, false>(a, b, blk, tid, tab.data());
+          }
+      }
+      if (last) loss[0] = (float)(total * a.inv_n);
+    }
+    cur = dst;
+  }
+  return 0;
+}
+
+int emul_fused_bwd(const int* ops, int K, const float* img, const float* params, const float* target,
+                   const float* gloss, float* gimg, float* gparams, const float* seg_bufs, float* gbuf, int B, int H,
+                   int W, int forced_iters) {
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  if (ns < 0) return 2;
+  int vec, iters, nblk;
+  chain_geometry(B, H, W, forced_iters, vec, iters, nblk);
+  const size_t img_floats = (size_t)B * 3 * H * W;
+  memset(gparams, 0, sizeof(float) * (size_t)K * B * kMaxParam);
+  const float* gcur = nullptr;
+  for (int s = ns - 1; s >= 0; --s) {
+    const float* in = s == 0 ? img : seg_bufs + (size_t)(s - 1) * img_floats;
+    float* gnext = s == 0 ? gimg : gbuf + (size_t)(s & 1) * img_floats;
+    const bool last = s == ns - 1;
+    if (seg[s].sharp) {
+      const int k = seg[s].first;
+      emul_bwd(OP_SHARPNESS, nullptr, in, params + (size_t)k * B * kMaxParam, kMaxParam, nullptr, 0,
+               last ? nullptr : gcur, last ? target : nullptr, gloss, gnext, gparams + (size_t)k * B * kMaxParam,
+               kMaxParam, B, H, W, forced_iters);
+    } else {
+      ChainArgs a;
+      memset(&a, 0, sizeof(a));
+      chain_fill(a, seg[s], B, H, W, iters, nblk);
+      a.img = in; a.params = params; a.gimg = gnext;
+      if (last) { a.target = target; a.gloss = gloss; } else { a.gout = gcur; }
+      for (int b = 0; b < B; ++b) {
+        std::vector<float> tab(kMaxChain * kTabStride, 0.0f);
+        for (int k = 0; k < a.K; ++k) chain_build_table(a, b, k, tab.data());
+        float sums[kMaxChainSlots];
+        for (int i = 0; i < kMaxChainSlots; ++i) sums[i] = 0.0f;
+        HostAcc acc{sums};
+        std::vector<float> sv(chain_save_floats<2>(kMaxChain));
+        for (int blk = 0; blk < nblk; ++blk)
+          for (int tid = 0; tid < kThreads; ++tid) {
+            if (vec == 2) { if (last) chain_bwd_thread<2, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            else { if (last) chain_bwd_thread<1, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<1, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+          }
+        for (int k = 0; k < a.K; ++k) {
+          float* grow = gparams + ((size_t)a.src[k] * B + b) * kMaxParam;
+          finalize_param_grad(a.ops[k], params + ((size_t)a.src[k] * B + b) * kMaxParam, sums + a.slot_off[k], grow);
+        }
+      }
+    }
+    gcur = gnext;
+  }
+  return 0;
+}
+
+int emul_fused_buffers(const int* ops, int K) {
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  return ns < 0 ? -1 : ns - 1;
+}
+
 }  // extern "C"

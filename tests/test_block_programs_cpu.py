@@ -112,3 +112,46 @@ def test_fused_l1(op):
     np.testing.assert_allclose(gi, x.grad.numpy(), rtol=1e-5, atol=1e-8)
     if op >= 0:
         np.testing.assert_allclose(gp, pp.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('ops', [[0, 1, 2, 3, 5, 6], [5, 3, 5, 3, 0, 1, 2, 6], [6, 0, -1, 6, 3], [1], [6], [-1, -1],
+                                 [0, 1, 2, 3, 5, 0, 1, 2, 3, 5, 7, 1]])
+@pytest.mark.parametrize('shape', [(3, 32, 40), (2, 23, 19)])
+def test_fused_sequence_equals_oracle_chain(ops, shape):
+    """The fused sequence (pointwise runs in registers, LDS curve lookup) against the oracle's
+    operator-by-operator chain: images bit-for-bit close (1e-6), loss 1e-6, gradients vs fp64."""
+    B, H, W = shape
+    img = synth.images(B, H, W, 31)
+    tgt = synth.images(B, H, W, 32)
+    params = torch.zeros(len(ops), B, 24)
+    ps64 = []
+    for k, op in enumerate(ops):
+        if op >= 0:
+            n = cpu_ref.OP_NPARAM[op]
+            params[k, :, :n] = synth.op_params(op, B, 300 + k, 'mid')
+            ps64.append(params[k, :, :n].double().clone().requires_grad_(True))
+        else:
+            ps64.append(None)
+    # fp32 oracle chain for the forward, fp64 for the gradients
+    cur = img
+    for k, op in enumerate(ops):
+        if op >= 0:
+            cur = cpu_ref.operator_apply(op, cur, params[k, :, :cpu_ref.OP_NPARAM[op]], None, OPT)
+    ref_loss = (cur - tgt).abs().mean().item()
+    x64 = img.double().clone().requires_grad_(True)
+    c64 = x64
+    for k, op in enumerate(ops):
+        if op >= 0:
+            c64 = operator_apply64(op, c64, ps64[k], None)
+    ((c64 - tgt.double()).abs().mean() * 2.0).backward()
+    out, loss, gimg, gparams = emul.fused(ops, img.numpy(), params.numpy(), tgt.numpy(), gloss=2.0)
+    np.testing.assert_allclose(out, cur.numpy(), rtol=0, atol=2e-6)
+    assert abs(loss - ref_loss) < 1e-6
+    g = x64.grad.numpy()
+    np.testing.assert_allclose(gimg, g, rtol=2e-3, atol=2e-3 * np.abs(g).max())
+    for k, op in enumerate(ops):
+        if op >= 0 and op != 7:
+            gk = ps64[k].grad.numpy()
+            np.testing.assert_allclose(gparams[k, :, :gk.shape[1]], gk, rtol=2e-3, atol=2e-3 * max(np.abs(gk).max(), 1e-4))
+        else:
+            assert np.all(gparams[k] == 0)

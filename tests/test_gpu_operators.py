@@ -259,6 +259,50 @@ def test_full_size_properties(executor, dev):
     assert x.grad.abs().max().item() > 0
 
 
+@pytest.mark.parametrize('ops', [[0, 1, 2, 3, 5, 6], [5, 3, 5, 3, 0, 1, 2, 6], [6, 0, -1, 6, 3], [1], [6], [-1, -1],
+                                 [0, 1, 2, 3, 5, 0, 1, 2, 3, 5, 7, 1]])
+@pytest.mark.parametrize('shape', [(3, 32, 40), (2, 23, 19), (2, 128, 128)])
+def test_fused_sequence_equals_materialised_sequence(executor, dev, ops, shape):
+    """run_sequence_fused (pointwise runs in registers, LDS curve lookup) against run_sequence
+    (one kernel per operator): same final image bit for bit, same loss, same gradients."""
+    B, H, W = shape
+    img = synth.images(B, H, W, 31).to(dev)
+    tgt = synth.images(B, H, W, 32).to(dev)
+    params = torch.zeros(len(ops), B, 24)
+    for k, op in enumerate(ops):
+        if op >= 0:
+            params[k, :, :cpu_ref.OP_NPARAM[op]] = synth.op_params(op, B, 300 + k, 'mid')
+    res = []
+    for fn in (executor.run_sequence, executor.run_sequence_fused):
+        x = img.clone().requires_grad_(True)
+        p = params.to(dev).requires_grad_(True)
+        loss, out = fn(x, ops, p, tgt)
+        (loss * 2.0).backward()
+        res.append((loss.item(), out if out.dim() == 4 else out[-1], x.grad, p.grad))
+    (l0, o0, gx0, gp0), (l1, o1, gx1, gp1) = res
+    assert torch.equal(o0, o1)
+    assert abs(l0 - l1) < 1e-7
+    assert torch.allclose(gx0, gx1, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(gp0, gp1, rtol=2e-4, atol=2e-5 * max(1.0, gp0.abs().max().item()))
+
+
+def test_fused_sequence_golden_chain6(executor, gold, dev):
+    B, H, W = 3, 32, 40
+    ops = [0, 1, 2, 3, 5, 6]
+    x = synth.images(B, H, W, 31).to(dev).requires_grad_(True)
+    tgt = synth.images(B, H, W, 32).to(dev)
+    ps = [synth.op_params(op, B, 300 + k, 'mid').to(dev).requires_grad_(True) for k, op in enumerate(ops)]
+    loss, out = executor.run_sequence_fused(x, ops, ps, tgt)
+    loss.backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), gold['chain6_out'], rtol=0, atol=1e-5)
+    assert abs(loss.item() - float(gold['chain6_loss'])) < 1e-6
+    g = gold['chain6_gimg']
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g, rtol=2e-3, atol=2e-3 * np.abs(g).max())
+    for k, p in enumerate(ps):
+        gk = gold['chain6_gparam%d' % k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), gk, rtol=2e-3, atol=2e-3 * max(np.abs(gk).max(), 1e-6))
+
+
 def test_attention_core(dev):
     import t2onet_amd.functional as T
     for (B, L, D) in [(4, 14, 512), (64, 17, 512), (3, 1, 64), (5, 64, 1024)]:
