@@ -539,33 +539,34 @@ T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
   }
 }
 
-// backward of chain operator `op` on one pixel: g = gradient w.r.t. the CLAMPED output;
-// returns the gradient w.r.t. the input, adds raw parameter sums to red[0..n)
-T2O_HD Rgb chain_op_bwd(int op, const Rgb& x, const float* t, const Rgb& g, float* red) {
+// backward of a curve operator on one pixel (COLOR: per-channel curves, else one shared curve):
+// g = gradient w.r.t. the CLAMPED output; returns the gradient w.r.t. the input, adds raw sums.
+template <bool COLOR>
+T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* red) {
   Rgb gx;
-  if (is_curve(op)) {
-    const bool color = op == OP_COLOR;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    constexpr int kOne = COLOR ? 1 : 0;
+    const int cc = c * kOne;                                         // static after unrolling
+    const float* kk = t + kTabK + cc * kCurveSteps;
+    int i; float frac;
+    curve_locate(x.c[c], i, frac);
+    const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * kk[i];
+    const float z = COLOR ? total * t[kTabScale + cc] : (total * (float)kCurveSteps) / t[kTabSum + cc];
+    const float dz = (z >= 0.0f && z <= 1.0f) ? g.c[c] : 0.0f;
+    const float d = x.c[c] - (float)i / kCurveSteps;
+    float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
+    if (d == 0.0f && i > 0) slope += kk[i - 1];                     // on a knot both neighbours pass (inclusive clamp)
+    gx.c[c] = dz * t[kTabScale + cc] * slope;
     T2O_UNROLL
-    for (int c = 0; c < 3; ++c) {
-      const int cc = color ? c : 0;
-      const float* kk = t + kTabK + cc * kCurveSteps;
-      int i; float frac;
-      curve_locate(x.c[c], i, frac);
-      const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * kk[i];
-      const float z = color ? total * t[kTabScale + cc] : (total * (float)kCurveSteps) / t[kTabSum + cc];
-      const float dz = (z >= 0.0f && z <= 1.0f) ? g.c[c] : 0.0f;
-      const float d = x.c[c] - (float)i / kCurveSteps;
-      float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
-      if (d == 0.0f && i > 0) slope += kk[i - 1];                   // on a knot both neighbours pass (inclusive clamp)
-      gx.c[c] = dz * t[kTabScale + cc] * slope;
-      float* r = red + cc * kCurveSteps;
-      T2O_UNROLL
-      for (int j = 0; j < kCurveSteps; ++j)
-        r[j] += dz * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
-    }
-    return gx;
+    for (int j = 0; j < kCurveSteps; ++j)
+      red[cc * kCurveSteps + j] += dz * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
   }
-  if (op == OP_WHITE) { gx.c[0] = gx.c[1] = gx.c[2] = 0.0f; return gx; }
+  return gx;
+}
+
+// backward of a one-parameter chain operator (brightness / contrast / saturation)
+T2O_HD Rgb chain_scalar_bwd(int op, const Rgb& x, const float* t, const Rgb& g, float* red) {
   const Rgb r = chain_op_fwd(op, x, t);
   Rgb dz;
   T2O_UNROLL
@@ -682,22 +683,36 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
     for (int k = a.K - 1; k >= 0; --k) {
       T2O_RELOAD_FENCE();
       const int op = a.ops[k];
-      float red[kRedSlots];
-      T2O_UNROLL
-      for (int j = 0; j < kRedSlots; ++j) red[j] = 0.0f;
-      T2O_UNROLL
-      for (int i = 0; i < V; ++i) {
-        Rgb xi, gi = {{gg[0][i], gg[1][i], gg[2][i]}};
-        T2O_UNROLL
-        for (int c = 0; c < 3; ++c) xi.c[c] = sv[((k * 3 + c) * V + i) * kThreads + tid];
-        const Rgb gx = chain_op_bwd(op, xi, tab + k * kTabStride, gi, red);
-        T2O_UNROLL
-        for (int c = 0; c < 3; ++c) gg[c][i] = gx.c[c];
+      const float* t = tab + k * kTabStride;
+      const int slot0 = a.slot_off[k];
+      // one specialised body per operator class: static register indices, static slot counts
+#define T2O_CHAIN_BWD_BODY(NRED, CALL)                                                   \
+      {                                                                                  \
+        float red[NRED > 0 ? NRED : 1];                                                  \
+        T2O_UNROLL                                                                       \
+        for (int j = 0; j < NRED; ++j) red[j] = 0.0f;                                    \
+        T2O_UNROLL                                                                       \
+        for (int i = 0; i < V; ++i) {                                                    \
+          Rgb xi, gi = {{gg[0][i], gg[1][i], gg[2][i]}};                                 \
+          T2O_UNROLL                                                                     \
+          for (int c = 0; c < 3; ++c) xi.c[c] = sv[((k * 3 + c) * V + i) * kThreads + tid]; \
+          const Rgb gx = CALL;                                                           \
+          T2O_UNROLL                                                                     \
+          for (int c = 0; c < 3; ++c) gg[c][i] = gx.c[c];                                \
+        }                                                                                \
+        T2O_UNROLL                                                                       \
+        for (int j = 0; j < NRED; ++j) acc.add(slot0 + j, red[j]);                       \
       }
-      const int n = op == OP_COLOR ? 24 : op == OP_TONE ? 8 : op == OP_WHITE ? 0 : 1;
-      T2O_UNROLL
-      for (int j = 0; j < kRedSlots; ++j)
-        if (j < n) acc.add(a.slot_off[k] + j, red[j]);
+      if (op == OP_COLOR) T2O_CHAIN_BWD_BODY(24, chain_curve_bwd<true>(xi, t, gi, red))
+      else if (op == OP_TONE) T2O_CHAIN_BWD_BODY(8, chain_curve_bwd<false>(xi, t, gi, red))
+      else if (op == OP_WHITE) {
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) {
+          T2O_UNROLL
+          for (int i = 0; i < V; ++i) gg[c][i] = 0.0f;
+        }
+      } else T2O_CHAIN_BWD_BODY(1, chain_scalar_bwd(op, xi, t, gi, red))
+#undef T2O_CHAIN_BWD_BODY
     }
     if (a.gimg && live) {
       T2O_UNROLL

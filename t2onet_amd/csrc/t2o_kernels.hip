@@ -164,7 +164,7 @@ struct LdsAcc {
   __device__ __forceinline__ void add(int slot, float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-    if ((threadIdx.x & 3) == 0) acc[slot * kAccStride + (threadIdx.x >> 2)] += v;
+    if ((threadIdx.x & 3) == 0) atomicAdd(&acc[slot * kAccStride + (threadIdx.x >> 2)], v);   // ds_add_f32, sole owner of the cell
   }
 };
 
@@ -199,15 +199,25 @@ __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
   }
 }
 
-// one workgroup per sample: per-block sums -> raw sums -> parameter gradients of every chain operator
+// one workgroup per sample: per-block sums -> raw sums -> parameter gradients of every chain operator.
+// 8 threads per slot walk the block rows (stride 8), then a fixed-order LDS combine.
 __global__ __launch_bounds__(kThreads) void k_chain_finalize(ChainArgs a, float* gparams) {
+  __shared__ float part[8][kMaxChainSlots];
   __shared__ float sums[kMaxChainSlots];
   const int b = blockIdx.x;
   const int S = a.slot_off[kMaxChain];
-  for (int s = threadIdx.x; s < S; s += kThreads) {
+  for (int w = threadIdx.x; w < S * 8; w += kThreads) {
+    const int s = w % S, lane8 = w / S;
     float acc = 0.0f;
-    for (int k = 0; k < a.nblk; ++k) acc += a.partials[((size_t)b * a.nblk + k) * S + s];
-    sums[s] = acc;
+    for (int k = lane8; k < a.nblk; k += 8) acc += a.partials[((size_t)b * a.nblk + k) * S + s];
+    part[lane8][s] = acc;
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += kThreads) {
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += part[j][s];
+    sums[s] = v;
   }
   __syncthreads();
   if ((int)threadIdx.x < a.K) {
