@@ -216,8 +216,15 @@ T2O_HD void pointwise_bwd_thread(const OpArgs& a, int op, int b, int blk, int ti
         for (int c = 0; c < 3; ++c) gx[c][i] = L1 ? sign_of(xi.c[c] - gg[c][i]) * gs : gg[c][i];
         continue;
       }
-      const Rgb r = pointwise_fwd(op, xi, p0, cv);
       Rgb go, gpass;
+      if (!MASKED && !L1 && !clamp_can_act(op, xi)) {      // output provably inside [0,1]: dz = gout
+        go.c[0] = gg[0][i]; go.c[1] = gg[1][i]; go.c[2] = gg[2][i];
+        const Rgb gi = pointwise_bwd(op, xi, p0, cv, go, red);
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) gx[c][i] = gi.c[c];
+        continue;
+      }
+      const Rgb r = pointwise_fwd(op, xi, p0, cv);
       T2O_UNROLL
       for (int c = 0; c < 3; ++c) {
         const float m = MASKED ? (s.mstride ? mk[c][i] : mk[0][i]) : 1.0f;
@@ -567,10 +574,12 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* re
 
 // backward of a one-parameter chain operator (brightness / contrast / saturation)
 T2O_HD Rgb chain_scalar_bwd(int op, const Rgb& x, const float* t, const Rgb& g, float* red) {
-  const Rgb r = chain_op_fwd(op, x, t);
-  Rgb dz;
-  T2O_UNROLL
-  for (int c = 0; c < 3; ++c) dz.c[c] = (r.c[c] >= 0.0f && r.c[c] <= 1.0f) ? g.c[c] : 0.0f;
+  Rgb dz = g;
+  if (clamp_can_act(op, x)) {
+    const Rgb r = chain_op_fwd(op, x, t);
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) dz.c[c] = (r.c[c] >= 0.0f && r.c[c] <= 1.0f) ? g.c[c] : 0.0f;
+  }
   Curve unused;
   float p0[1] = {t[0]};
   return pointwise_bwd(op, x, p0, unused, dz, red);

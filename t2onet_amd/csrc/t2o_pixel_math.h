@@ -41,6 +41,10 @@
 __device__ __forceinline__ float t2o_opaque(float v) { asm volatile("" : "+v"(v)); return v; }
 // v, made to depend on `dep`: work on v cannot start before dep has been computed.
 __device__ __forceinline__ float t2o_chain(float v, float dep) { asm volatile("" : "+v"(v) : "v"(dep)); return v; }
+// a / b by hardware reciprocal (1 ulp): for the closed-form DERIVATIVES only, whose tolerance is
+// 1e-5; every forward formula keeps IEEE division for parity with the reference's rounding.
+__device__ __forceinline__ float t2o_fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#define T2O_FDIV(a, b) t2o_fdiv(a, b)
 #define T2O_OPAQUE(v) t2o_opaque(v)
 #define T2O_CHAIN(v, dep) t2o_chain(v, dep)
 // v must have been computed by this point (volatile asms keep their order): stops accumulations
@@ -50,6 +54,7 @@ __device__ __forceinline__ float t2o_chain(float v, float dep) { asm volatile(""
 // registers across it (stops loop-invariant table reads being hoisted into 50+ VGPRs).
 #define T2O_RELOAD_FENCE() asm volatile("" ::: "memory")
 #else
+#define T2O_FDIV(a, b) ((a) / (b))
 #define T2O_OPAQUE(v) (v)
 #define T2O_CHAIN(v, dep) (v)
 #define T2O_KEEP(v) ((void)0)
@@ -272,9 +277,10 @@ T2O_HD Rgb brightness_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float ve = v + kHsvEps;
   const float t = v * (1.0f + p);
   float a, da_dv, da_dp;
+  const float rve = T2O_FDIV(1.0f, ve);
   if (t < 0.0f)      { a = 0.0f; da_dv = 0.0f; da_dp = 0.0f; }
-  else if (t > 1.0f) { a = 1.0f / ve; da_dv = -a / ve; da_dp = 0.0f; }
-  else               { a = t / ve; da_dv = (1.0f + p) * kHsvEps / (ve * ve); da_dp = v / ve; }
+  else if (t > 1.0f) { a = rve; da_dv = -a * rve; da_dp = 0.0f; }
+  else               { a = t * rve; da_dv = (1.0f + p) * kHsvEps * rve * rve; da_dp = v * rve; }
   const float S = g.c[0] * (x.c[0] + kHsvEps) + g.c[1] * (x.c[1] + kHsvEps) + g.c[2] * (x.c[2] + kHsvEps);
   Rgb gx;
   T2O_UNROLL
@@ -290,7 +296,8 @@ T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   argmaxmin(x, amax, amin, v, mn);
   const float ve = v + kHsvEps;
   const float delta = v - mn;
-  const float s = delta / ve;
+  const float rve = T2O_FDIV(1.0f, ve);
+  const float s = delta / ve;                 // the clamp decision uses the forward's exact s
   const float t = s * (1.0f + p);
   const float u0 = v - x.c[0], u1 = v - x.c[1], u2 = v - x.c[2];
   const float G = g.c[0] + g.c[1] + g.c[2];
@@ -323,8 +330,9 @@ T2O_HD Rgb contrast_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const bool inside = (lum > 0.0f) && (lum < 1.0f);
   const float cl = (-cosf(kPi * L)) * 0.5f + 0.5f;
   const float Le = L + 1e-6f;
-  const float q = cl / Le;
-  const float dq = (0.5f * kPi * sinf(kPi * L) * Le - cl) / (Le * Le);
+  const float rLe = T2O_FDIV(1.0f, Le);
+  const float q = cl * rLe;
+  const float dq = (0.5f * kPi * sinf(kPi * L) * Le - cl) * rLe * rLe;
   const float S = g.c[0] * x.c[0] + g.c[1] * x.c[1] + g.c[2] * x.c[2];
   const float k0 = (1.0f - p) + p * q;
   const float k1 = inside ? p * S * dq : 0.0f;
@@ -363,6 +371,18 @@ T2O_HD Rgb color_bwd(const Rgb& x, const Curve& cv, const Rgb& g, float* red) {
   for (int c = 0; c < 3; ++c)
     gx.c[c] = curve_bwd_1(cv.k[c], cv.scale[c], x.c[c], g.c[c], red + c * kCurveSteps);
   return gx;
+}
+
+// Can the final clamp(0,1) of operator `op` be active for input pixel x?  For brightness and
+// saturation the HSV round trip returns v' * [0,1] factors (resp. v * [0,1] factors): with the
+// input inside [0,1] the output provably is too, in fp32 as well (every factor is a rounded
+// quotient/product of numbers <= 1), so the backward pass needs no forward recompute there.
+T2O_HD bool clamp_can_act(int op, const Rgb& x) {
+  const float mn = fminf(x.c[0], fminf(x.c[1], x.c[2]));
+  const float mx = fmaxf(x.c[0], fmaxf(x.c[1], x.c[2]));
+  if (op == OP_BRIGHTNESS) return !(mn >= 0.0f);
+  if (op == OP_SATURATION) return !(mn >= 0.0f && mx <= 1.0f);
+  return true;
 }
 
 T2O_HD Rgb pointwise_bwd(int op, const Rgb& x, const float* p, const Curve& cv, const Rgb& g, float* red) {

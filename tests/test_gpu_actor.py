@@ -52,7 +52,7 @@ def test_episode_l1_step_matches_reference(gold, mode):
     np.testing.assert_array_equal(pred_ops.cpu().numpy(), gold[p + 'pred_ops'])             # bit-exact indices
     np.testing.assert_allclose(torch.stack(pred_params, 0).detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=5e-4)
-    np.testing.assert_allclose(pred_imgs.detach().double().mean((2, 3, 4)).cpu().numpy(), gold[p + 'imgs_mean'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(pred_imgs.detach().double().mean((2, 3, 4)).cpu().numpy(), gold[p + 'imgs_mean'], rtol=0, atol=1e-4)
     assert state['imgs'].shape == pred_imgs.shape and len(state['hidden']) == 6 and state['masks'] is None
     loss = T.l1_loss(select_end_images(pred_imgs, pred_ops, opt.end_id), tgt)
     assert abs(loss.item() - float(gold[p + 'loss'])) < 1e-5                                    # L1 deviation <= 1e-5
