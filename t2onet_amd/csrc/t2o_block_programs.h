@@ -317,6 +317,12 @@ T2O_HD void sharp_fwd_phase_load(const OpArgs& a, int b, int tile, int tid, floa
   tile_load<V>(a.img + plane_off(a, b, 0), (size_t)a.H * a.W, 3, a.H, a.W, y0, x0, 1, lds, tid);
 }
 
+// 4 horizontally adjacent window elements of plane c starting at tile column j (j % 4 == 0):
+// one 16-byte LDS read (rows are 16-byte aligned, the interior starts at a 16-byte boundary)
+T2O_HD void tile_quad(const float* lds, int halo, int c, int r, int j, float (&q)[4]) {
+  load_vec<4>(lds + c * tile_floats(halo) + (r + halo) * kRowStride + kIntOff + j, q);
+}
+
 template <int V>
 T2O_HD float sharp_fwd_phase_compute(const OpArgs& a, int b, int tile, int tid, const float* lds) {
   int y0, x0;
@@ -328,15 +334,17 @@ T2O_HD float sharp_fwd_phase_compute(const OpArgs& a, int b, int tile, int tid, 
   float l1 = 0.0f;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
-    float o[4];
+    float up[4], ce[4], dn[4], o[4];
+    tile_quad(lds, 1, c, ty - 1, 4 * tx, up);
+    tile_quad(lds, 1, c, ty, 4 * tx, ce);
+    tile_quad(lds, 1, c, ty + 1, 4 * tx, dn);
+    const float L = tile_at(lds, 1, c, ty, 4 * tx - 1), R = tile_at(lds, 1, c, ty, 4 * tx + 4);
     T2O_UNROLL
     for (int i = 0; i < 4; ++i) {
-      const int j = 4 * tx + i;
-      const float xc = tile_at(lds, 1, c, ty, j);
-      const float d = sharp_delta(xc, tile_at(lds, 1, c, ty - 1, j), tile_at(lds, 1, c, ty, j - 1),
-                                  tile_at(lds, 1, c, ty, j + 1), tile_at(lds, 1, c, ty + 1, j));
-      float z = xc + p * d;
-      if (a.mask_ch && gx0 + i < a.W) z = blend(z, xc, mask_at(a, b, c, (size_t)gy * a.W + gx0 + i));
+      const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
+      const float d = sharp_delta(ce[i], up[i], left, right, dn[i]);
+      float z = ce[i] + p * d;
+      if (a.mask_ch && gx0 + i < a.W) z = blend(z, ce[i], mask_at(a, b, c, (size_t)gy * a.W + gx0 + i));
       o[i] = clamp01(z);
     }
     float* dst = a.out + plane_off(a, b, c) + (size_t)gy * a.W + gx0;
@@ -379,81 +387,111 @@ T2O_HD void sharp_bwd_phase_load(const OpArgs& a, int b, int tile, int tid, floa
 }
 
 // Phase 2: at every window position (interior + 1-px halo) replace G by
-// dz = [0 <= z <= 1] * gradient of the clamped output, zero outside the image.
-T2O_HD void sharp_bwd_phase_dz(const OpArgs& a, int b, int tile, int tid, float* lds) {
+// dz = [0 <= z <= 1] * gradient of the clamped output, zero outside the image; interior positions
+// also add do * Laplacian(x) (do = dz * m) to red0, the raw sum of d loss / d p.
+// One quad (4 columns) of one row of all 3 planes:
+T2O_HD void sharp_dz_quad(const OpArgs& a, float p, float gs, int y0, int x0, int r, int j0, int n, float* lds, float& red0) {
+  const float* X = lds + sharp_bwd_x_off();
+  float* G = lds + sharp_bwd_g_off();
+  const float* M = lds + sharp_bwd_m_off();
+  const int gy = y0 + r;
+  const bool interior = r >= 0 && r < kTileH && j0 >= 0 && j0 < kTileW;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    float up[4], ce[4], dn[4], gq[4], mq[4], dz[4];
+    if (n == 4) {
+      tile_quad(X, 2, c, r - 1, j0, up);
+      tile_quad(X, 2, c, r, j0, ce);
+      tile_quad(X, 2, c, r + 1, j0, dn);
+      tile_quad(G, 1, c, r, j0, gq);
+      if (a.mask_ch) tile_quad(M, 1, a.mask_ch == 3 ? c : 0, r, j0, mq);
+    } else {
+      up[0] = tile_at(X, 2, c, r - 1, j0); ce[0] = tile_at(X, 2, c, r, j0); dn[0] = tile_at(X, 2, c, r + 1, j0);
+      gq[0] = tile_at(G, 1, c, r, j0);
+      if (a.mask_ch) mq[0] = tile_at(M, 1, a.mask_ch == 3 ? c : 0, r, j0);
+    }
+    const float L = tile_at(X, 2, c, r, j0 - 1), R = tile_at(X, 2, c, r, j0 + n);
+    T2O_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      if (i < n) {
+        const int gx = x0 + j0 + i;
+        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == n - 1 ? R : ce[i < 3 ? i + 1 : 3];
+        const float d = sharp_delta(ce[i], up[i], left, right, dn[i]);
+        const float m = a.mask_ch ? mq[i] : 1.0f;
+        float z = ce[i] + p * d;
+        if (a.mask_ch) z = blend(z, ce[i], m);
+        const float gz = a.target ? sign_of(clamp01(z) - gq[i]) * gs : gq[i];
+        dz[i] = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
+        if (interior) red0 += dz[i] * m * d;
+      }
+    }
+    float* dst = G + c * tile_floats(1) + (r + 1) * kRowStride + kIntOff + j0;
+    if (n == 4) store_vec<4>(dst, dz); else dst[0] = dz[0];
+  }
+}
+
+template <int V>
+T2O_HD void sharp_bwd_phase_dz(const OpArgs& a, int b, int tile, int tid, float* lds, float& red0) {
   int y0, x0;
   tile_origin(a, tile, y0, x0);
   const float p = a.param[(size_t)b * a.param_stride];
   const float gs = a.target ? a.gloss[0] * a.inv_n : 0.0f;
-  const float* X = lds + sharp_bwd_x_off();
-  float* G = lds + sharp_bwd_g_off();
-  const float* M = lds + sharp_bwd_m_off();
-  const int cols = kTileW + 2, rows = kTileH + 2;
-  for (int i = tid; i < rows * cols; i += kThreads) {
-    const int r = i / cols - 1, j = i % cols - 1;
-    const int gy = y0 + r, gx = x0 + j;
-    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    T2O_UNROLL
-    for (int c = 0; c < 3; ++c) {
-      float dz = 0.0f;
-      if (in) {
-        const float xc = tile_at(X, 2, c, r, j);
-        const float d = sharp_delta(xc, tile_at(X, 2, c, r - 1, j), tile_at(X, 2, c, r, j - 1),
-                                    tile_at(X, 2, c, r, j + 1), tile_at(X, 2, c, r + 1, j));
-        float z = xc + p * d;
-        if (a.mask_ch) z = blend(z, xc, tile_at(M, 1, a.mask_ch == 3 ? c : 0, r, j));
-        const float gv = tile_at(G, 1, c, r, j);
-        const float gz = a.target ? sign_of(clamp01(z) - gv) * gs : gv;
-        dz = (z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
-      }
-      G[c * tile_floats(1) + (r + 1) * kRowStride + kIntOff + j] = dz;
-    }
+  const int rows = kTileH + 2;
+  if (V == 4) {
+    for (int i = tid; i < rows * (kTileW / 4); i += kThreads)             // aligned quads of the 64 interior columns
+      sharp_dz_quad(a, p, gs, y0, x0, i / (kTileW / 4) - 1, 4 * (i % (kTileW / 4)), 4, lds, red0);
+    for (int i = tid; i < rows * 2; i += kThreads)                        // the two halo columns
+      sharp_dz_quad(a, p, gs, y0, x0, i / 2 - 1, (i % 2) ? kTileW : -1, 1, lds, red0);
+  } else {
+    const int cols = kTileW + 2;
+    for (int i = tid; i < rows * cols; i += kThreads)
+      sharp_dz_quad(a, p, gs, y0, x0, i / cols - 1, i % cols - 1, 1, lds, red0);
   }
 }
 
-// Phase 3: gimg = dz (1 - m) + do + p * Laplacian(do), do = dz * m;  red[0] += sum do * Laplacian(x)
+// Phase 3: gimg = dz (1 - m) + do + p * Laplacian(do), do = dz * m
 template <int V>
-T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const float* lds, float& red0) {
+T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const float* lds) {
   int y0, x0;
   tile_origin(a, tile, y0, x0);
   const int ty = tid / (kTileW / 4), tx = tid % (kTileW / 4);
   const int gy = y0 + ty, gx0 = x0 + 4 * tx;
-  if (gy >= a.H || gx0 >= a.W) return;
+  if (gy >= a.H || gx0 >= a.W || !a.gimg) return;
   const float p = a.param[(size_t)b * a.param_stride];
-  const float* X = lds + sharp_bwd_x_off();
   const float* G = lds + sharp_bwd_g_off();
   const float* M = lds + sharp_bwd_m_off();
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
     const int mc = a.mask_ch == 3 ? c : 0;
-    float o[4];
+    float up[4], ce[4], dn[4], o[4], pass[4];
+    tile_quad(G, 1, c, ty - 1, 4 * tx, up);
+    tile_quad(G, 1, c, ty, 4 * tx, ce);
+    tile_quad(G, 1, c, ty + 1, 4 * tx, dn);
+    float L = tile_at(G, 1, c, ty, 4 * tx - 1), R = tile_at(G, 1, c, ty, 4 * tx + 4);
+    T2O_UNROLL
+    for (int i = 0; i < 4; ++i) pass[i] = 0.0f;
+    if (a.mask_ch) {
+      float mu[4], mcq[4], md[4];
+      tile_quad(M, 1, mc, ty - 1, 4 * tx, mu);
+      tile_quad(M, 1, mc, ty, 4 * tx, mcq);
+      tile_quad(M, 1, mc, ty + 1, 4 * tx, md);
+      L *= tile_at(M, 1, mc, ty, 4 * tx - 1);
+      R *= tile_at(M, 1, mc, ty, 4 * tx + 4);
+      T2O_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        pass[i] = ce[i] * (1.0f - mcq[i]);
+        up[i] *= mu[i]; ce[i] *= mcq[i]; dn[i] *= md[i];
+      }
+    }
     T2O_UNROLL
     for (int i = 0; i < 4; ++i) {
-      const int j = 4 * tx + i;
-      float dzc = tile_at(G, 1, c, ty, j), dou = tile_at(G, 1, c, ty - 1, j), dol = tile_at(G, 1, c, ty, j - 1),
-            dor = tile_at(G, 1, c, ty, j + 1), dod = tile_at(G, 1, c, ty + 1, j);
-      float doc = dzc, pass = 0.0f;
-      if (a.mask_ch) {
-        const float m = tile_at(M, 1, mc, ty, j);
-        doc = dzc * m;
-        pass = dzc * (1.0f - m);
-        dou *= tile_at(M, 1, mc, ty - 1, j);
-        dol *= tile_at(M, 1, mc, ty, j - 1);
-        dor *= tile_at(M, 1, mc, ty, j + 1);
-        dod *= tile_at(M, 1, mc, ty + 1, j);
-      }
-      o[i] = pass + (doc + p * sharp_delta(doc, dou, dol, dor, dod));
-      if (gx0 + i < a.W) {
-        const float dx = sharp_delta(tile_at(X, 2, c, ty, j), tile_at(X, 2, c, ty - 1, j), tile_at(X, 2, c, ty, j - 1),
-                                     tile_at(X, 2, c, ty, j + 1), tile_at(X, 2, c, ty + 1, j));
-        red0 += doc * dx;
-      }
+      const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
+      o[i] = pass[i] + (ce[i] + p * sharp_delta(ce[i], up[i], left, right, dn[i]));
     }
-    if (a.gimg) {
-      float* dst = a.gimg + plane_off(a, b, c) + (size_t)gy * a.W + gx0;
-      if (V == 4) store_vec<4>(dst, o);
-      else for (int i = 0; i < 4 && gx0 + i < a.W; ++i) dst[i] = o[i];
-    }
+    float* dst = a.gimg + plane_off(a, b, c) + (size_t)gy * a.W + gx0;
+    if (V == 4) store_vec<4>(dst, o);
+    else for (int i = 0; i < 4 && gx0 + i < a.W; ++i) dst[i] = o[i];
   }
 }
 
@@ -484,8 +522,10 @@ struct ChainArgs {
   float* loss_partials;    // fused L1 forward: (B, nblk)
   int ops[kMaxChain];
   int src[kMaxChain];            // index of operator k in the sequence's params / gparams
-  int slot_off[kMaxChain + 1];   // first accumulator slot of operator k; S = slot_off[K]
+  int slot_off[kMaxChain + 1];   // first raw-sum slot of operator k in `partials`; S = slot_off[kMaxChain]
+  int bin_off[kMaxChain + 1];    // first LDS accumulator cell row of operator k (curves: 16 per curve row)
   int K, B, H, W, iters, nblk;
+  int param_stride, gparam_stride;
   float inv_n;
 };
 
@@ -494,7 +534,7 @@ T2O_HD bool is_curve(int op) { return op == OP_COLOR || op == OP_TONE; }
 // One thread per operator builds that operator's table row.
 T2O_HD void chain_build_table(const ChainArgs& a, int b, int k, float* tab) {
   float* t = tab + k * kTabStride;
-  const float* p = a.params + ((size_t)a.src[k] * a.B + b) * kMaxParam;
+  const float* p = a.params + ((size_t)a.src[k] * a.B + b) * a.param_stride;
   const int op = a.ops[k];
   if (!is_curve(op)) { t[0] = p[0]; return; }
   for (int c = 0; c < 3; ++c) {
@@ -547,9 +587,13 @@ T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
 }
 
 // backward of a curve operator on one pixel (COLOR: per-channel curves, else one shared curve):
-// g = gradient w.r.t. the CLAMPED output; returns the gradient w.r.t. the input, adds raw sums.
-template <bool COLOR>
-T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* red) {
+// g = gradient w.r.t. the CLAMPED output; returns the gradient w.r.t. the input.
+// Parameter sums: with the pixel in segment i*, its clamp terms are t_j = 1/8 (j < i*),
+// frac (j = i*), 0 (j > i*), so instead of 8 multiply-adds per channel it adds dz to cell H[i*]
+// and dz*frac to cell F[i*] of this curve row (cells bin0 + 16*row + {0..7: H, 8..15: F});
+// chain_slot_value() below rebuilds  A_j = F_j + (1/8) sum_{i > j} H_i  per workgroup.
+template <bool COLOR, class ACC>
+T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, ACC& acc, int bin0) {
   Rgb gx;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
@@ -565,11 +609,23 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* re
     float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
     if (d == 0.0f && i > 0) slope += kk[i - 1];                     // on a knot both neighbours pass (inclusive clamp)
     gx.c[c] = dz * t[kTabScale + cc] * slope;
-    T2O_UNROLL
-    for (int j = 0; j < kCurveSteps; ++j)
-      red[cc * kCurveSteps + j] += dz * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+    acc.add_lane(bin0 + cc * 16 + i, dz);
+    acc.add_lane(bin0 + cc * 16 + kCurveSteps + i, dz * frac);
   }
   return gx;
+}
+
+// raw-sum slot s of `partials` from this workgroup's summed accumulator cells bsum[]
+T2O_HD float chain_slot_value(const ChainArgs& a, int s, const float* bsum) {
+  int k = 0;
+  while (k + 1 < kMaxChain && s >= a.slot_off[k + 1]) ++k;
+  const int j = s - a.slot_off[k];
+  if (!is_curve(a.ops[k])) return bsum[a.bin_off[k] + j];
+  const int row = j / kCurveSteps, i = j % kCurveSteps;
+  const float* cell = bsum + a.bin_off[k] + row * 16;
+  float tail = 0.0f;
+  for (int jj = kCurveSteps - 1; jj > i; --jj) tail += cell[jj];
+  return cell[kCurveSteps + i] + (1.0f / kCurveSteps) * tail;
 }
 
 // backward of a one-parameter chain operator (brightness / contrast / saturation)
@@ -693,13 +749,10 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
       T2O_RELOAD_FENCE();
       const int op = a.ops[k];
       const float* t = tab + k * kTabStride;
-      const int slot0 = a.slot_off[k];
-      // one specialised body per operator class: static register indices, static slot counts
-#define T2O_CHAIN_BWD_BODY(NRED, CALL)                                                   \
+      const int bin0 = a.bin_off[k];
+      // one specialised body per operator class
+#define T2O_CHAIN_BWD_BODY(CALL)                                                         \
       {                                                                                  \
-        float red[NRED > 0 ? NRED : 1];                                                  \
-        T2O_UNROLL                                                                       \
-        for (int j = 0; j < NRED; ++j) red[j] = 0.0f;                                    \
         T2O_UNROLL                                                                       \
         for (int i = 0; i < V; ++i) {                                                    \
           Rgb xi, gi = {{gg[0][i], gg[1][i], gg[2][i]}};                                 \
@@ -709,18 +762,20 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
           T2O_UNROLL                                                                     \
           for (int c = 0; c < 3; ++c) gg[c][i] = gx.c[c];                                \
         }                                                                                \
-        T2O_UNROLL                                                                       \
-        for (int j = 0; j < NRED; ++j) acc.add(slot0 + j, red[j]);                       \
       }
-      if (op == OP_COLOR) T2O_CHAIN_BWD_BODY(24, chain_curve_bwd<true>(xi, t, gi, red))
-      else if (op == OP_TONE) T2O_CHAIN_BWD_BODY(8, chain_curve_bwd<false>(xi, t, gi, red))
+      if (op == OP_COLOR) T2O_CHAIN_BWD_BODY((chain_curve_bwd<true>(xi, t, gi, acc, bin0)))
+      else if (op == OP_TONE) T2O_CHAIN_BWD_BODY((chain_curve_bwd<false>(xi, t, gi, acc, bin0)))
       else if (op == OP_WHITE) {
         T2O_UNROLL
         for (int c = 0; c < 3; ++c) {
           T2O_UNROLL
           for (int i = 0; i < V; ++i) gg[c][i] = 0.0f;
         }
-      } else T2O_CHAIN_BWD_BODY(1, chain_scalar_bwd(op, xi, t, gi, red))
+      } else {
+        float red[1] = {0.0f};
+        T2O_CHAIN_BWD_BODY(chain_scalar_bwd(op, xi, t, gi, red))
+        acc.add(bin0, red[0]);
+      }
 #undef T2O_CHAIN_BWD_BODY
     }
     if (a.gimg && live) {
@@ -789,16 +844,23 @@ inline void chain_geometry(int B, int H, int W, int forced_iters, int& vec, int&
 inline void chain_fill(ChainArgs& a, const Segment& s, int B, int H, int W, int iters, int nblk) {
   a.K = s.n; a.B = B; a.H = H; a.W = W; a.iters = iters; a.nblk = nblk;
   a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
-  int off = 0;
+  a.param_stride = kMaxParam; a.gparam_stride = kMaxParam;
+  int off = 0, bin = 0;
   for (int k = 0; k < kMaxChain; ++k) {
     a.ops[k] = k < s.n ? s.ops[k] : OP_IDENTITY;
     a.src[k] = k < s.n ? s.src[k] : 0;
     a.slot_off[k] = off;
-    if (k < s.n) off += (s.ops[k] == OP_COLOR ? 24 : s.ops[k] == OP_TONE ? 8 : s.ops[k] == OP_WHITE ? 0 : 1);
+    a.bin_off[k] = bin;
+    if (k < s.n) {
+      off += (s.ops[k] == OP_COLOR ? 24 : s.ops[k] == OP_TONE ? 8 : s.ops[k] == OP_WHITE ? 0 : 1);
+      bin += (s.ops[k] == OP_COLOR ? 48 : s.ops[k] == OP_TONE ? 16 : s.ops[k] == OP_WHITE ? 0 : 1);
+    }
   }
   a.slot_off[kMaxChain] = off;
+  a.bin_off[kMaxChain] = bin;
 }
-constexpr int kMaxChainSlots = kMaxChain * kMaxParam;   // 192
+constexpr int kMaxChainSlots = kMaxChain * kMaxParam;   // 192 raw-sum slots per block row
+constexpr int kMaxChainBins = kMaxChain * 48;           // 384 LDS accumulator cell rows
 
 // ===================================================================== launch geometry (host)
 struct Geometry {

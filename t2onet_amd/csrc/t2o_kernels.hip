@@ -150,10 +150,10 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd(OpArgs a, int tiles) {
   if (DYN && a.op_id[b] != OP_SHARPNESS) return;
   sharp_bwd_phase_load<V>(a, b, tile, threadIdx.x, lds);
   __syncthreads();
-  sharp_bwd_phase_dz(a, b, tile, threadIdx.x, lds);
-  __syncthreads();
   float red0 = 0.0f;
-  sharp_bwd_phase_out<V>(a, b, tile, threadIdx.x, lds, red0);
+  sharp_bwd_phase_dz<V>(a, b, tile, threadIdx.x, lds, red0);
+  __syncthreads();
+  sharp_bwd_phase_out<V>(a, b, tile, threadIdx.x, lds);
   block_reduce_store1(red0, a.partials + ((size_t)b * a.nblk_max + tile) * kRedSlots);
 }
 
@@ -165,6 +165,10 @@ struct LdsAcc {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
     if ((threadIdx.x & 3) == 0) atomicAdd(&acc[slot * kAccStride + (threadIdx.x >> 2)], v);   // ds_add_f32, sole owner of the cell
+  }
+  // per-lane cell row (curve segment histograms): the 4 lanes of a quad share a cell
+  __device__ __forceinline__ void add_lane(int slot, float v) {
+    atomicAdd(&acc[slot * kAccStride + (threadIdx.x >> 2)], v);
   }
 };
 
@@ -181,22 +185,26 @@ __global__ __launch_bounds__(kThreads) void k_chain_fwd(ChainArgs a) {
 
 template <int V, bool L1>
 __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [accumulators: S rows of kAccStride][save area]
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [accumulator cells: NB rows of kAccStride][save area]
   __shared__ float tab[kMaxChain * kTabStride];
+  __shared__ float bsum[kMaxChainBins];
   int b, blk;
   wg_coords(a.nblk, b, blk);
-  const int S = a.slot_off[kMaxChain];
-  for (int i = threadIdx.x; i < S * kAccStride; i += kThreads) lds[i] = 0.0f;
+  const int S = a.slot_off[kMaxChain], NB = a.bin_off[kMaxChain];
+  for (int i = threadIdx.x; i < NB * kAccStride; i += kThreads) lds[i] = 0.0f;
   if ((int)threadIdx.x < a.K) chain_build_table(a, b, threadIdx.x, tab);
   __syncthreads();
   LdsAcc acc{lds};
-  chain_bwd_thread<V, L1>(a, b, blk, threadIdx.x, tab, lds + S * kAccStride, acc);
+  chain_bwd_thread<V, L1>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
   __syncthreads();
-  for (int s = threadIdx.x; s < S; s += kThreads) {
+  for (int s = threadIdx.x; s < NB; s += kThreads) {            // cell rows -> per-workgroup sums, fixed order
     float sum = 0.0f;
     for (int q = 0; q < kThreads / 4; ++q) sum += lds[s * kAccStride + q];
-    a.partials[((size_t)b * a.nblk + blk) * S + s] = sum;
+    bsum[s] = sum;
   }
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += kThreads)
+    a.partials[((size_t)b * a.nblk + blk) * S + s] = chain_slot_value(a, s, bsum);
 }
 
 // one workgroup per sample: per-block sums -> raw sums -> parameter gradients of every chain operator.
@@ -222,9 +230,10 @@ __global__ __launch_bounds__(kThreads) void k_chain_finalize(ChainArgs a, float*
   __syncthreads();
   if ((int)threadIdx.x < a.K) {
     const int k = threadIdx.x, op = a.ops[k];
-    float* grow = gparams + ((size_t)a.src[k] * a.B + b) * kMaxParam;
-    for (int i = 0; i < kMaxParam; ++i) grow[i] = 0.0f;
-    finalize_param_grad(op, a.params + ((size_t)a.src[k] * a.B + b) * kMaxParam, sums + a.slot_off[k], grow);
+    float* grow = gparams + ((size_t)a.src[k] * a.B + b) * a.gparam_stride;
+    const int nz = a.gparam_stride < kMaxParam ? a.gparam_stride : kMaxParam;
+    for (int i = 0; i < nz; ++i) grow[i] = 0.0f;
+    finalize_param_grad(op, a.params + ((size_t)a.src[k] * a.B + b) * a.param_stride, sums + a.slot_off[k], grow);
   }
 }
 
@@ -511,6 +520,10 @@ int run_fwd(int op, const int* op_id, const float* img, const float* param, int 
   return check_launch("operator forward");
 }
 
+int run_curve_bwd_as_chain(int op, const float* img, const float* param, int param_stride, const float* gout,
+                           const float* target, const float* gloss, float* gimg, float* gparam, int gparam_stride,
+                           void* ws, int B, int H, int W, hipStream_t st);
+
 int run_bwd(int op, const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
             int mask_ch, const float* gout, const float* target, const float* gloss, float* gimg, float* gparam,
             int gparam_stride, void* ws, size_t ws_bytes, int B, int H, int W, void* stream) {
@@ -529,6 +542,12 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   a.iters = g.iters; a.nblk_max = g.nblk_max;
   a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
   hipStream_t st = (hipStream_t)stream;
+  if ((op == OP_COLOR || op == OP_TONE) && !mask && gparam) {
+    // curve operators: the chain kernel's LDS lookup + segment-histogram backward is ~2x lighter
+    static const int off = env_int("T2O_NO_CURVE_CHAIN", 0);
+    if (!off) return run_curve_bwd_as_chain(op, img, param, param_stride, gout, target, gloss, gimg, gparam,
+                                            gparam_stride, ws, B, H, W, st);
+  }
   if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
   if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_bwd(a, g, st);
   if (gparam && op != OP_IDENTITY)
@@ -687,12 +706,35 @@ static int fused_chain_launch_fwd(ChainArgs& a, int vec, bool l1, hipStream_t st
 }
 static int fused_chain_launch_bwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
   const unsigned grid = (unsigned)a.B * a.nblk;
-  const size_t lds = sizeof(float) * ((size_t)a.slot_off[kMaxChain] * kAccStride +
+  const size_t lds = sizeof(float) * ((size_t)a.bin_off[kMaxChain] * kAccStride +
                                       (vec == 2 ? chain_save_floats<2>(a.K) : chain_save_floats<1>(a.K)));
   if (vec == 2) { if (l1) k_chain_bwd<2, true><<<grid, kThreads, lds, st>>>(a); else k_chain_bwd<2, false><<<grid, kThreads, lds, st>>>(a); }
   else          { if (l1) k_chain_bwd<1, true><<<grid, kThreads, lds, st>>>(a); else k_chain_bwd<1, false><<<grid, kThreads, lds, st>>>(a); }
   return 0;
 }
+
+}  // extern "C"  (helpers below live in the anonymous namespace)
+namespace {
+int run_curve_bwd_as_chain(int op, const float* img, const float* param, int param_stride, const float* gout,
+                           const float* target, const float* gloss, float* gimg, float* gparam, int gparam_stride,
+                           void* ws, int B, int H, int W, hipStream_t st) {
+  static const int forced = env_int("T2O_CHAIN_ITERS", 0);
+  int vec, iters, nblk;
+  chain_geometry(B, H, W, forced, vec, iters, nblk);
+  Segment sg;
+  sg.first = 0; sg.count = 1; sg.sharp = false; sg.n = 1; sg.ops[0] = op; sg.src[0] = 0;
+  ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  chain_fill(a, sg, B, H, W, iters, nblk);
+  a.param_stride = param_stride; a.gparam_stride = gparam_stride;
+  a.img = img; a.params = param; a.gimg = gimg; a.partials = (float*)ws;
+  if (target) { a.target = target; a.gloss = gloss; } else { a.gout = gout; }
+  fused_chain_launch_bwd(a, vec, target != nullptr, st);
+  k_chain_finalize<<<B, kThreads, 0, st>>>(a, gparam);
+  return check_launch("curve operator backward");
+}
+}  // namespace
+extern "C" {
 
 int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float* params, const float* target,
                            float* out, float* loss, float* seg_bufs, void* workspace, size_t workspace_bytes, int B,

@@ -103,10 +103,13 @@ int emul_bwd(int op, const int* op_id, const float* img, const float* param, int
           if (g.vec_tile == 4) sharp_bwd_phase_load<4>(a, b, tile, tid, lds.data());
           else sharp_bwd_phase_load<1>(a, b, tile, tid, lds.data());
         }
-        for (int tid = 0; tid < kThreads; ++tid) sharp_bwd_phase_dz(a, b, tile, tid, lds.data());
         for (int tid = 0; tid < kThreads; ++tid) {
-          if (g.vec_tile == 4) sharp_bwd_phase_out<4>(a, b, tile, tid, lds.data(), sums[0]);
-          else sharp_bwd_phase_out<1>(a, b, tile, tid, lds.data(), sums[0]);
+          if (g.vec_tile == 4) sharp_bwd_phase_dz<4>(a, b, tile, tid, lds.data(), sums[0]);
+          else sharp_bwd_phase_dz<1>(a, b, tile, tid, lds.data(), sums[0]);
+        }
+        for (int tid = 0; tid < kThreads; ++tid) {
+          if (g.vec_tile == 4) sharp_bwd_phase_out<4>(a, b, tile, tid, lds.data());
+          else sharp_bwd_phase_out<1>(a, b, tile, tid, lds.data());
         }
       }
     }
@@ -120,6 +123,7 @@ int emul_bwd(int op, const int* op_id, const float* img, const float* param, int
 struct HostAcc {
   float* sums;
   void add(int slot, float v) { sums[slot] += v; }
+  void add_lane(int slot, float v) { sums[slot] += v; }
 };
 
 // fused sequence, forward: chain segments + sharpness segments, boundaries in seg_bufs
@@ -190,15 +194,17 @@ int emul_fused_bwd(const int* ops, int K, const float* img, const float* params,
       for (int b = 0; b < B; ++b) {
         std::vector<float> tab(kMaxChain * kTabStride, 0.0f);
         for (int k = 0; k < a.K; ++k) chain_build_table(a, b, k, tab.data());
-        float sums[kMaxChainSlots];
+        float sums[kMaxChainSlots], bins[kMaxChainBins];
         for (int i = 0; i < kMaxChainSlots; ++i) sums[i] = 0.0f;
-        HostAcc acc{sums};
+        for (int i = 0; i < kMaxChainBins; ++i) bins[i] = 0.0f;
+        HostAcc acc{bins};
         std::vector<float> sv(chain_save_floats<2>(kMaxChain));
         for (int blk = 0; blk < nblk; ++blk)
           for (int tid = 0; tid < kThreads; ++tid) {
             if (vec == 2) { if (last) chain_bwd_thread<2, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
             else { if (last) chain_bwd_thread<1, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<1, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
           }
+        for (int sl = 0; sl < a.slot_off[kMaxChain]; ++sl) sums[sl] = chain_slot_value(a, sl, bins);
         for (int k = 0; k < a.K; ++k) {
           float* grow = gparams + ((size_t)a.src[k] * B + b) * kMaxParam;
           finalize_param_grad(a.ops[k], params + ((size_t)a.src[k] * B + b) * kMaxParam, sums + a.slot_off[k], grow);

@@ -9,7 +9,7 @@ out = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, '*', '*', '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        name = r['Kernel_Name'].split('(')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+        name = r['Kernel_Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
         if not name.startswith('k_'):
             continue
         acc[name][r['Counter_Name']].append(float(r['Counter_Value']))
@@ -17,6 +17,7 @@ rows = []
 for k in sorted(acc):
     d = {c: sum(v) / len(v) for c, v in acc[k].items()}
     rows.append((k, d))
+    dur = [float(x) for x in acc[k].get('_dur', [])]
     print(k)
     for c in sorted(d):
         print('    %-24s %14.1f' % (c, d[c]))
