@@ -587,13 +587,12 @@ T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
 }
 
 // backward of a curve operator on one pixel (COLOR: per-channel curves, else one shared curve):
-// g = gradient w.r.t. the CLAMPED output; returns the gradient w.r.t. the input.
-// Parameter sums: with the pixel in segment i*, its clamp terms are t_j = 1/8 (j < i*),
-// frac (j = i*), 0 (j > i*), so instead of 8 multiply-adds per channel it adds dz to cell H[i*]
-// and dz*frac to cell F[i*] of this curve row (cells bin0 + 16*row + {0..7: H, 8..15: F});
-// chain_slot_value() below rebuilds  A_j = F_j + (1/8) sum_{i > j} H_i  per workgroup.
-template <bool COLOR, class ACC>
-T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, ACC& acc, int bin0) {
+// g = gradient w.r.t. the CLAMPED output; returns the gradient w.r.t. the input, adds the raw
+// sums red[8*row + j] += dz * t_j.  (A segment-histogram variant -- two LDS float atomics per
+// channel instead of 8 multiply-adds -- measured 3x SLOWER on MI355X: ds_add_f32 with per-lane
+// addresses runs at roughly one lane per 3 cycles per CU.  Kept out.)
+template <bool COLOR>
+T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* red) {
   Rgb gx;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
@@ -609,24 +608,15 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, ACC& acc,
     float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
     if (d == 0.0f && i > 0) slope += kk[i - 1];                     // on a knot both neighbours pass (inclusive clamp)
     gx.c[c] = dz * t[kTabScale + cc] * slope;
-    acc.add_lane(bin0 + cc * 16 + i, dz);
-    acc.add_lane(bin0 + cc * 16 + kCurveSteps + i, dz * frac);
+    T2O_UNROLL
+    for (int j = 0; j < kCurveSteps; ++j)
+      red[cc * kCurveSteps + j] += dz * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
   }
   return gx;
 }
 
-// raw-sum slot s of `partials` from this workgroup's summed accumulator cells bsum[]
-T2O_HD float chain_slot_value(const ChainArgs& a, int s, const float* bsum) {
-  int k = 0;
-  while (k + 1 < kMaxChain && s >= a.slot_off[k + 1]) ++k;
-  const int j = s - a.slot_off[k];
-  if (!is_curve(a.ops[k])) return bsum[a.bin_off[k] + j];
-  const int row = j / kCurveSteps, i = j % kCurveSteps;
-  const float* cell = bsum + a.bin_off[k] + row * 16;
-  float tail = 0.0f;
-  for (int jj = kCurveSteps - 1; jj > i; --jj) tail += cell[jj];
-  return cell[kCurveSteps + i] + (1.0f / kCurveSteps) * tail;
-}
+// raw-sum slot s of `partials` from this workgroup's summed accumulator cells
+T2O_HD float chain_slot_value(const ChainArgs& a, int s, const float* bsum) { return bsum[s]; }
 
 // backward of a one-parameter chain operator (brightness / contrast / saturation)
 T2O_HD Rgb chain_scalar_bwd(int op, const Rgb& x, const float* t, const Rgb& g, float* red) {
@@ -750,9 +740,12 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
       const int op = a.ops[k];
       const float* t = tab + k * kTabStride;
       const int bin0 = a.bin_off[k];
-      // one specialised body per operator class
-#define T2O_CHAIN_BWD_BODY(CALL)                                                         \
+      // one specialised body per operator class: static register indices, static slot counts
+#define T2O_CHAIN_BWD_BODY(NRED, CALL)                                                   \
       {                                                                                  \
+        float red[NRED];                                                                 \
+        T2O_UNROLL                                                                       \
+        for (int j = 0; j < NRED; ++j) red[j] = 0.0f;                                    \
         T2O_UNROLL                                                                       \
         for (int i = 0; i < V; ++i) {                                                    \
           Rgb xi, gi = {{gg[0][i], gg[1][i], gg[2][i]}};                                 \
@@ -762,20 +755,17 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
           T2O_UNROLL                                                                     \
           for (int c = 0; c < 3; ++c) gg[c][i] = gx.c[c];                                \
         }                                                                                \
+        acc.template add_n<NRED>(bin0, red);                                             \
       }
-      if (op == OP_COLOR) T2O_CHAIN_BWD_BODY((chain_curve_bwd<true>(xi, t, gi, acc, bin0)))
-      else if (op == OP_TONE) T2O_CHAIN_BWD_BODY((chain_curve_bwd<false>(xi, t, gi, acc, bin0)))
+      if (op == OP_COLOR) T2O_CHAIN_BWD_BODY(24, chain_curve_bwd<true>(xi, t, gi, red))
+      else if (op == OP_TONE) T2O_CHAIN_BWD_BODY(8, chain_curve_bwd<false>(xi, t, gi, red))
       else if (op == OP_WHITE) {
         T2O_UNROLL
         for (int c = 0; c < 3; ++c) {
           T2O_UNROLL
           for (int i = 0; i < V; ++i) gg[c][i] = 0.0f;
         }
-      } else {
-        float red[1] = {0.0f};
-        T2O_CHAIN_BWD_BODY(chain_scalar_bwd(op, xi, t, gi, red))
-        acc.add(bin0, red[0]);
-      }
+      } else T2O_CHAIN_BWD_BODY(1, chain_scalar_bwd(op, xi, t, gi, red))
 #undef T2O_CHAIN_BWD_BODY
     }
     if (a.gimg && live) {
@@ -850,17 +840,17 @@ inline void chain_fill(ChainArgs& a, const Segment& s, int B, int H, int W, int 
     a.ops[k] = k < s.n ? s.ops[k] : OP_IDENTITY;
     a.src[k] = k < s.n ? s.src[k] : 0;
     a.slot_off[k] = off;
-    a.bin_off[k] = bin;
+    a.bin_off[k] = off;
     if (k < s.n) {
       off += (s.ops[k] == OP_COLOR ? 24 : s.ops[k] == OP_TONE ? 8 : s.ops[k] == OP_WHITE ? 0 : 1);
-      bin += (s.ops[k] == OP_COLOR ? 48 : s.ops[k] == OP_TONE ? 16 : s.ops[k] == OP_WHITE ? 0 : 1);
+      bin = off;                                  // accumulator cells == raw-sum slots
     }
   }
   a.slot_off[kMaxChain] = off;
   a.bin_off[kMaxChain] = bin;
 }
 constexpr int kMaxChainSlots = kMaxChain * kMaxParam;   // 192 raw-sum slots per block row
-constexpr int kMaxChainBins = kMaxChain * 48;           // 384 LDS accumulator cell rows
+constexpr int kMaxChainBins = kMaxChainSlots;
 
 // ===================================================================== launch geometry (host)
 struct Geometry {

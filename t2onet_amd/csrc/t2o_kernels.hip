@@ -161,14 +161,23 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd(OpArgs a, int tiles) {
 // raw parameter sums: quad (4-lane) DPP reduction, then one owner lane adds into its private LDS cell
 struct LdsAcc {
   float* acc;
-  __device__ __forceinline__ void add(int slot, float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-    if ((threadIdx.x & 3) == 0) atomicAdd(&acc[slot * kAccStride + (threadIdx.x >> 2)], v);   // ds_add_f32, sole owner of the cell
-  }
-  // per-lane cell row (curve segment histograms): the 4 lanes of a quad share a cell
-  __device__ __forceinline__ void add_lane(int slot, float v) {
-    atomicAdd(&acc[slot * kAccStride + (threadIdx.x >> 2)], v);
+  // N raw sums of this thread: 4-lane (quad) DPP reduction, then the quad's first lane adds into
+  // the quad's private LDS cells with plain read-add-write (sole owner: no atomics, fixed order).
+  template <int N>
+  __device__ __forceinline__ void add_n(int slot0, float (&v)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      v[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j]), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+      v[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j]), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    }
+    if ((threadIdx.x & 3) == 0) {
+      float* cell = acc + slot0 * kAccStride + (threadIdx.x >> 2);
+      float old[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) old[j] = cell[j * kAccStride];
+#pragma unroll
+      for (int j = 0; j < N; ++j) cell[j * kAccStride] = old[j] + v[j];
+    }
   }
 };
 

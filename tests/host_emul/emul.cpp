@@ -49,6 +49,12 @@ void point_bwd_block(const OpArgs& a, int op, int b, int blk, float* sums) {
             : ((M) ? ((L) ? FN<1, true, true>(__VA_ARGS__) : FN<1, true, false>(__VA_ARGS__))      \
                    : ((L) ? FN<1, false, true>(__VA_ARGS__) : FN<1, false, false>(__VA_ARGS__))))
 
+struct HostAcc {
+  float* sums;
+  template <int N>
+  void add_n(int slot0, float (&v)[N]) { for (int j = 0; j < N; ++j) sums[slot0 + j] += v[j]; }
+};
+
 }  // namespace
 
 extern "C" {
@@ -120,11 +126,6 @@ int emul_bwd(int op, const int* op_id, const float* img, const float* param, int
 }
 
 
-struct HostAcc {
-  float* sums;
-  void add(int slot, float v) { sums[slot] += v; }
-  void add_lane(int slot, float v) { sums[slot] += v; }
-};
 
 // fused sequence, forward: chain segments + sharpness segments, boundaries in seg_bufs
 int emul_fused_fwd(const int* ops, int K, const float* img, const float* params, const float* target, float* out,
