@@ -551,8 +551,9 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   a.iters = g.iters; a.nblk_max = g.nblk_max;
   a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
   hipStream_t st = (hipStream_t)stream;
-  if ((op == OP_COLOR || op == OP_TONE) && !mask && gparam) {
-    // curve operators: the chain kernel's LDS lookup + segment-histogram backward is ~2x lighter
+  if (op == OP_COLOR && !mask && gparam) {
+    // color curve: the one-operator chain kernel (LDS curve lookup for the forward recompute) measured
+    // 54 us vs 61 us for k_point_bwd<3> at bs=64 256x256; the tone curve is faster in k_point_bwd<5>
     static const int off = env_int("T2O_NO_CURVE_CHAIN", 0);
     if (!off) return run_curve_bwd_as_chain(op, img, param, param_stride, gout, target, gloss, gimg, gparam,
                                             gparam_stride, ws, B, H, W, st);

@@ -283,10 +283,18 @@ T2O_HD Rgb brightness_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   else               { a = t * rve; da_dv = (1.0f + p) * kHsvEps * rve * rve; da_dp = v * rve; }
   const float S = g.c[0] * (x.c[0] + kHsvEps) + g.c[1] * (x.c[1] + kHsvEps) + g.c[2] * (x.c[2] + kHsvEps);
   Rgb gx;
+  red[0] += S * da_dp;
+  if (v == mn) {
+    // grey pixel (r == g == b): s = 0, every output channel is v' and depends on the input only
+    // through max(), which PyTorch routes to the FIRST channel (argmax of equal values).
+    const float dv = (t < 0.0f || t > 1.0f) ? 0.0f : (1.0f + p);
+    gx.c[0] = (g.c[0] + g.c[1] + g.c[2]) * dv;
+    gx.c[1] = gx.c[2] = 0.0f;
+    return gx;
+  }
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) gx.c[c] = a * g.c[c];
   add_at(gx, amax, S * da_dv);
-  red[0] += S * da_dp;
   return gx;
 }
 
@@ -303,6 +311,10 @@ T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float G = g.c[0] + g.c[1] + g.c[2];
   const float GU = g.c[0] * u0 + g.c[1] * u1 + g.c[2] * u2;
   Rgb gx;
+  if (delta == 0.0f) {                  // grey pixel: out = v on every channel, via max() only (first channel)
+    gx.c[0] = G; gx.c[1] = gx.c[2] = 0.0f;
+    return gx;
+  }
   if (t < 0.0f) {                       // s' = 0: every channel becomes v
     gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
     add_at(gx, amax, G);
@@ -327,7 +339,8 @@ T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
 T2O_HD Rgb contrast_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float lum = luminance(x);
   const float L = fminf(fmaxf(lum, 0.0f), 1.0f);
-  const bool inside = (lum > 0.0f) && (lum < 1.0f);
+  // torch.min(torch.max(lum, 0), 1): elementwise max/min split the gradient 1/2 - 1/2 at a tie
+  const float inside = (lum > 0.0f && lum < 1.0f) ? 1.0f : ((lum == 0.0f || lum == 1.0f) ? 0.5f : 0.0f);
   const float cl = (-cosf(kPi * L)) * 0.5f + 0.5f;
   const float Le = L + 1e-6f;
   const float rLe = T2O_FDIV(1.0f, Le);
@@ -335,7 +348,7 @@ T2O_HD Rgb contrast_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float dq = (0.5f * kPi * sinf(kPi * L) * Le - cl) * rLe * rLe;
   const float S = g.c[0] * x.c[0] + g.c[1] * x.c[1] + g.c[2] * x.c[2];
   const float k0 = (1.0f - p) + p * q;
-  const float k1 = inside ? p * S * dq : 0.0f;
+  const float k1 = inside * p * S * dq;
   Rgb gx;
   gx.c[0] = g.c[0] * k0 + k1 * 0.27f;
   gx.c[1] = g.c[1] * k0 + k1 * 0.67f;

@@ -135,6 +135,48 @@ def test_vs_oracle_ragged_sizes(executor, dev, op, shape):
         np.testing.assert_allclose(pp.grad.cpu().numpy(), gp64.numpy(), rtol=2e-4, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize('op', OPS)
+def test_edge_cases_ties_follow_pytorch(executor, dev, op):
+    """Black / white / grey pixels, values on curve knots, flat saturated regions: PyTorch's tie
+    conventions (inclusive clamp, first-index max/min, 1/2-1/2 elementwise max/min)."""
+    from tests.test_block_programs_cpu import edge_image, oracle_fwd_bwd
+    img = edge_image()
+    B, _, H, W = img.shape
+    gout = synth.uniform((B, 3, H, W), 92, -1.0, 1.0)
+    for setting in ['mid', 'strong']:
+        p = synth.op_params(op, B, 600 + op, setting)
+        o_ref, gi_ref, gp_ref = oracle_fwd_bwd(op, img, p, None, gout)
+        x = img.to(dev).requires_grad_(True)
+        pp = p.to(dev).requires_grad_(True)
+        out, _ = executor.execute(x, op, None, specified_param=pp)
+        out.backward(gout.to(dev))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.numpy(), rtol=0, atol=1e-6)
+        gi, gi_ref = x.grad.cpu().numpy(), gi_ref.numpy()
+        if op in (0, 2):
+            gi[:, :, 7:9, :] = gi_ref[:, :, 7:9, :]        # two-channel ties: documented one-sided-derivative choice
+        np.testing.assert_allclose(gi, gi_ref, rtol=1e-4, atol=5e-5 if op in (0, 2) else 2e-6)
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), gp_ref.numpy(), rtol=1e-4,
+                                   atol=1e-4 * max(1.0, float(gp_ref.abs().max())))
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (1, 1, 7), (2, 5, 1), (1, 3, 5), (1, 2, 130)])
+def test_tiny_and_ragged_shapes(executor, dev, shape):
+    B, H, W = shape
+    img = synth.images(B, H, W, 93)
+    gout = synth.uniform((B, 3, H, W), 94, -1.0, 1.0)
+    for op in OPS:
+        p = synth.op_params(op, B, 700 + op, 'mid')
+        o_ref = cpu_ref.operator_apply(op, img, p, None, OPT)
+        _, gi64, gp64 = _oracle64(op, img, p, None, gout)
+        x = img.to(dev).requires_grad_(True)
+        pp = p.to(dev).requires_grad_(True)
+        out, _ = executor.execute(x, op, None, specified_param=pp)
+        out.backward(gout.to(dev))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), gi64.numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), gp64.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(gp64.abs().max())))
+
+
 def test_per_sample_operators_one_launch(executor, dev):
     B, H, W = 9, 40, 72
     img = synth.images(B, H, W, 71)
