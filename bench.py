@@ -243,6 +243,9 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
     opt = t2onet_amd.default_options()
     torch.manual_seed(10 + (dist.get_rank() if dist is not None else 0))
     model = Actor(opt).to(device).train()
+    # NHWC convolutions are 20 % faster in MIOpen fp32 on MI355X (tools/bench_resnet.py: 12.2 vs 14.7 ms
+    # per ResNet forward+backward at bs=64 256x256); numerics are unchanged (same fp32 math)
+    model.vis_encoder.to(memory_format=torch.channels_last)
     if dist is not None:                                   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
