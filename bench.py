@@ -245,7 +245,7 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
     model = Actor(opt).to(device).train()
     # NHWC convolutions are 20 % faster in MIOpen fp32 on MI355X (tools/bench_resnet.py: 12.2 vs 14.7 ms
     # per ResNet forward+backward at bs=64 256x256); numerics are unchanged (same fp32 math)
-    model.vis_encoder.to(memory_format=torch.channels_last)
+    model.use_channels_last()
     if dist is not None:                                   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)

@@ -64,7 +64,17 @@ class Actor(nn.Module):
         self.bn1 = nn.BatchNorm1d(512)
 
     # ------------------------------------------------------------------ helpers
+    def use_channels_last(self, on=True):
+        """Run the ResNet in NHWC: MIOpen's fp32 NHWC kernels are ~20 % faster on MI355X
+        (tools/bench_resnet.py).  Same fp32 arithmetic; state_dict shapes are unchanged."""
+        self._nhwc = bool(on)
+        self.vis_encoder.to(memory_format=torch.channels_last if on else torch.contiguous_format)
+        return self
+
     def image_features(self, img):
+        if getattr(self, '_nhwc', False):
+            # the operators work on NCHW planes; give MIOpen a packed NHWC copy (12 B/pixel, once per step)
+            img = img.contiguous(memory_format=torch.channels_last)
         return F.relu(self.bn1(self.vis_encoder(img)))                 # actor.py:142-143, :215-216
 
     def divide_op_group(self, ops):
