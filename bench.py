@@ -194,6 +194,19 @@ def hbm_min_bytes(name, P):
     return 36 * P
 
 
+def pmc_traffic(kernel, P):
+    """HBM bytes per launch from the rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    separate passes: tools/gpu_pmc.sh), stored per pixel in profiles/pmc_traffic.json.  bench.py
+    cannot run the profiler on itself, so this is the last committed measurement, not a live one."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            per_px = json.load(f)['bytes_per_pixel'].get(kernel)
+        return None if per_px is None else int(per_px * P)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(B_sample, H, W, reps=7):
     """Oracle timed on the host cores: same sequence, fwd + L1 + bwd, on a bounded sample."""
     from oracle import cpu_ref
@@ -243,9 +256,8 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
     opt = t2onet_amd.default_options()
     torch.manual_seed(10 + (dist.get_rank() if dist is not None else 0))
     model = Actor(opt).to(device).train()
-    # NHWC convolutions are 20 % faster in MIOpen fp32 on MI355X (tools/bench_resnet.py: 12.2 vs 14.7 ms
-    # per ResNet forward+backward at bs=64 256x256); numerics are unchanged (same fp32 math)
-    model.use_channels_last()
+    # (NHWC: the ResNet alone is 20 % faster, tools/bench_resnet.py, but the whole step measured
+    # slower -- 122 vs 94 ms -- so the default stays NCHW; Actor.use_channels_last() switches)
     if dist is not None:                                   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
@@ -307,7 +319,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:          # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
@@ -378,7 +390,7 @@ def main():
                                    'per-pixel operators fused in registers, sharpness+L1 stencil kernels' % (B, H, W, OPS),
                        'global_batch': n_gpus * B, 'parallelism': 'batch shards, no collective on the executor path'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['GBps'], 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'unit': 'GB/s', 'frac': round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, P),
                          'algorithmic_bytes_per_launch': algorithmic_bytes(dom, P),
                          'avg_launch_ms': kernels[dom]['ms'],
                          'note': 'algorithmic bytes = SURVEY 8(d) per-operator figure x operator applications in the '

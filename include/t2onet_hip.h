@@ -120,6 +120,14 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
                            float* gimg, float* gparams, const float* seg_bufs, float* gbuf,
                            void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 
+/* ---- SSIM (evaluation metric, forward only): utils/ssim/__init__.py:20-40 ----
+ * 11x11 Gaussian window (sigma 1.5), zero padding, C1 = 1e-4, C2 = 9e-4.
+ * out[b] = mean over (C,H,W) of the SSIM map of sample b (size_average=False of the reference;
+ * its size_average=True is the mean of out).  workspace: t2o_ssim_workspace_bytes(B,C,H,W). */
+size_t t2o_ssim_workspace_bytes(int B, int C, int H, int W);
+int t2o_ssim_fwd(const float* img1, const float* img2, float* out,
+                 void* workspace, size_t workspace_bytes, int B, int C, int H, int W, void* stream);
+
 /* ---- dot-product attention core, models/attention.py:37-40 ----
  * q (B,D), ctx (B,L,D) -> attn (B,L) = softmax_l(q . ctx_l) over ALL L rows (no padding
  * mask, as the reference), mix (B,D) = sum_l attn_l ctx_l.   D % 64 == 0, D <= 1024, L <= 64 */

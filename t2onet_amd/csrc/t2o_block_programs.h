@@ -775,6 +775,88 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
   }
 }
 
+// ===================================================================== SSIM (evaluation metric)
+// utils/ssim/__init__.py:20-40: 11x11 Gaussian window (sigma 1.5, zero padding 5) over x, y,
+// x^2, y^2, xy per channel; C1 = 0.01^2, C2 = 0.03^2; mean of the SSIM map.  The 2-D window is the
+// outer product of a normalised 1-D Gaussian, so it is applied separably: rows, then columns.
+constexpr int kSsimWin = 11, kSsimPad = 5;
+constexpr int kSsimTile = 32;                          // 32 x 32 outputs per workgroup
+constexpr int kSsimIn = kSsimTile + 2 * kSsimPad;      // 42 x 42 input window
+constexpr int kSsimInStride = kSsimIn + 1;             // LDS row strides (odd: no bank conflicts on column walks)
+constexpr int kSsimHStride = kSsimTile + 1;
+
+struct SsimArgs {
+  const float* a;        // (B,C,H,W)
+  const float* b;
+  float* partials;       // (B*C, tiles)
+  float g[kSsimWin];     // normalised 1-D Gaussian
+  int B, C, H, W, tiles_x, tiles;
+};
+
+T2O_HD int ssim_lds_floats() { return 2 * kSsimIn * kSsimInStride + 5 * kSsimIn * kSsimHStride; }
+
+inline void ssim_window(float* g) {                     // utils/ssim/__init__.py:7-10
+  float s = 0.0f;
+  for (int i = 0; i < kSsimWin; ++i) {
+    g[i] = expf(-(float)((i - kSsimWin / 2) * (i - kSsimWin / 2)) / (2.0f * 1.5f * 1.5f));
+    s += g[i];
+  }
+  for (int i = 0; i < kSsimWin; ++i) g[i] /= s;
+}
+
+// phase 1: load the two 42x42 input windows (zero outside the image)
+T2O_HD void ssim_phase_load(const SsimArgs& s, int plane, int tile, int tid, float* lds) {
+  const int y0 = (tile / s.tiles_x) * kSsimTile - kSsimPad, x0 = (tile % s.tiles_x) * kSsimTile - kSsimPad;
+  const size_t base = (size_t)plane * s.H * s.W;
+  for (int i = tid; i < kSsimIn * kSsimIn; i += kThreads) {
+    const int r = i / kSsimIn, c = i % kSsimIn, gy = y0 + r, gx = x0 + c;
+    const bool in = gy >= 0 && gy < s.H && gx >= 0 && gx < s.W;
+    lds[r * kSsimInStride + c] = in ? s.a[base + (size_t)gy * s.W + gx] : 0.0f;
+    lds[kSsimIn * kSsimInStride + r * kSsimInStride + c] = in ? s.b[base + (size_t)gy * s.W + gx] : 0.0f;
+  }
+}
+
+// phase 2: horizontal pass -> 5 maps of 42 rows x 32 columns
+T2O_HD void ssim_phase_rows(const SsimArgs& s, int tid, float* lds) {
+  const float* A = lds;
+  const float* Bm = lds + kSsimIn * kSsimInStride;
+  float* Hm = lds + 2 * kSsimIn * kSsimInStride;
+  for (int i = tid; i < kSsimIn * kSsimTile; i += kThreads) {
+    const int r = i / kSsimTile, c = i % kSsimTile;
+    float m1 = 0.0f, m2 = 0.0f, e11 = 0.0f, e22 = 0.0f, e12 = 0.0f;
+    for (int k = 0; k < kSsimWin; ++k) {
+      const float x = A[r * kSsimInStride + c + k], y = Bm[r * kSsimInStride + c + k], w = s.g[k];
+      m1 += w * x; m2 += w * y; e11 += w * (x * x); e22 += w * (y * y); e12 += w * (x * y);
+    }
+    float* o = Hm + r * kSsimHStride + c;
+    o[0] = m1; o[kSsimIn * kSsimHStride] = m2; o[2 * kSsimIn * kSsimHStride] = e11;
+    o[3 * kSsimIn * kSsimHStride] = e22; o[4 * kSsimIn * kSsimHStride] = e12;
+  }
+}
+
+// phase 3: vertical pass + SSIM map; returns this thread's sum over its in-image outputs
+T2O_HD float ssim_phase_cols(const SsimArgs& s, int tile, int tid, const float* lds) {
+  const float* Hm = lds + 2 * kSsimIn * kSsimInStride;
+  const int y0 = (tile / s.tiles_x) * kSsimTile, x0 = (tile % s.tiles_x) * kSsimTile;
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  float sum = 0.0f;
+  for (int i = tid; i < kSsimTile * kSsimTile; i += kThreads) {
+    const int r = i / kSsimTile, c = i % kSsimTile;
+    if (y0 + r >= s.H || x0 + c >= s.W) continue;
+    float v[5];
+    for (int m = 0; m < 5; ++m) {
+      float acc = 0.0f;
+      for (int k = 0; k < kSsimWin; ++k) acc += s.g[k] * Hm[m * kSsimIn * kSsimHStride + (r + k) * kSsimHStride + c];
+      v[m] = acc;
+    }
+    const float mu1 = v[0], mu2 = v[1];
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = v[2] - mu1_sq, s2 = v[3] - mu2_sq, s12 = v[4] - mu12;
+    sum += ((2.0f * mu12 + C1) * (2.0f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+  }
+  return sum;
+}
+
 // ===================================================================== sequence planning (host)
 // A sequence is cut into segments: maximal runs of pointwise operators (<= kMaxChain) that one
 // fused kernel pair handles, and single sharpness operators (stencil kernels).  Identity (-1)

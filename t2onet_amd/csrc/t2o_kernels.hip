@@ -337,6 +337,29 @@ __global__ __launch_bounds__(kThreads) void k_l1_bwd(const float* pred, const fl
   }
 }
 
+// ------------------------------------------------------------------ SSIM forward (evaluation)
+__global__ __launch_bounds__(kThreads) void k_ssim_fwd(SsimArgs s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int plane, tile;
+  wg_coords(s.tiles, plane, tile);
+  ssim_phase_load(s, plane, tile, threadIdx.x, lds);
+  __syncthreads();
+  ssim_phase_rows(s, threadIdx.x, lds);
+  __syncthreads();
+  const float v = ssim_phase_cols(s, tile, threadIdx.x, lds);
+  block_reduce_store1(v, s.partials + (size_t)plane * s.tiles + tile);
+}
+
+// out[b] = mean over (C,H,W) of the SSIM map of sample b
+__global__ __launch_bounds__(kThreads) void k_ssim_finalize(const float* partials, int per_sample, float inv, float* out) {
+  float acc = 0.0f;
+  for (int k = threadIdx.x; k < per_sample; k += kThreads) acc += partials[(size_t)blockIdx.x * per_sample + k];
+  __shared__ float out1;
+  block_reduce_store1(acc, &out1);
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = out1 * inv;
+}
+
 // ------------------------------------------------------------------ attention core
 // One wave per sample.  Lane l (< L) owns score / probability l; every lane owns D/64 columns.
 __global__ __launch_bounds__(kThreads) void k_attn_fwd(const float* q, const float* ctx, float* attn, float* mix,
@@ -828,6 +851,30 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
     gcur = gnext;
   }
   return check_launch("fused sequence backward");
+}
+
+size_t t2o_ssim_workspace_bytes(int B, int C, int H, int W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t tiles = (size_t)((W + kSsimTile - 1) / kSsimTile) * ((H + kSsimTile - 1) / kSsimTile);
+  return sizeof(float) * (size_t)B * C * tiles;
+}
+
+int t2o_ssim_fwd(const float* img1, const float* img2, float* out, void* workspace, size_t workspace_bytes, int B, int C,
+                 int H, int W, void* stream) {
+  if (!img1 || !img2 || !out) return fail(T2O_EINVAL, "ssim_fwd: null pointer");
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(T2O_EINVAL, "B, C, H, W must be positive");
+  if (!workspace || workspace_bytes < t2o_ssim_workspace_bytes(B, C, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
+  SsimArgs s;
+  memset(&s, 0, sizeof(s));
+  s.a = img1; s.b = img2; s.partials = (float*)workspace;
+  ssim_window(s.g);
+  s.B = B; s.C = C; s.H = H; s.W = W;
+  s.tiles_x = (W + kSsimTile - 1) / kSsimTile;
+  s.tiles = s.tiles_x * ((H + kSsimTile - 1) / kSsimTile);
+  hipStream_t st = (hipStream_t)stream;
+  k_ssim_fwd<<<(unsigned)(B * C * s.tiles), kThreads, sizeof(float) * ssim_lds_floats(), st>>>(s);
+  k_ssim_finalize<<<B, kThreads, 0, st>>>(s.partials, C * s.tiles, 1.0f / ((float)C * (float)H * (float)W), out);
+  return check_launch("ssim forward");
 }
 
 int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix, int B, int L, int D, void* stream) {

@@ -296,3 +296,20 @@ class _FusedSequenceFn(torch.autograd.Function):
 def fused_sequence_l1(img, ops, params, target):
     """Like sequence_l1 but fused: returns (mean |out - target|, out (B,3,H,W))."""
     return _FusedSequenceFn.apply(img, params, target, [int(o) for o in ops])
+
+
+def ssim(img1, img2, size_average=True):
+    """SSIM of utils/ssim/__init__.py (11x11 Gaussian, sigma 1.5), forward only (evaluation metric).
+    Returns a scalar (size_average) or one value per sample."""
+    _need_gpu(img1, img2)
+    if img1.shape != img2.shape or img1.dim() != 4:
+        raise ValueError('ssim expects two (B,C,H,W) tensors of the same shape')
+    img1, img2 = img1.contiguous(), img2.contiguous()
+    B, C, H, W = img1.shape
+    lib = _lib.load()
+    out = torch.empty(B, dtype=torch.float32, device=img1.device)
+    ws = torch.empty(max(lib.t2o_ssim_workspace_bytes(B, C, H, W), 4), dtype=torch.uint8, device=img1.device)
+    with torch.no_grad():
+        rc = lib.t2o_ssim_fwd(_ptr(img1), _ptr(img2), _ptr(out), _ptr(ws), ws.numel(), B, C, H, W, _stream())
+    _lib.check(rc, 't2o_ssim_fwd')
+    return out.mean() if size_average else out

@@ -77,3 +77,11 @@ def fused(ops, img, params, target, gloss=1.0, iters=0):
     assert lib().emul_fused_bwd(c_ops, K, _p(img), _p(params), _p(target), _p(gl), _p(gimg), _p(gparams), _p(seg),
                                 _p(gbuf), B, H, W, iters) == 0
     return out, float(loss[0]), gimg, gparams
+
+
+def ssim(a, b):
+    a, b = _f(a), _f(b)
+    B, C, H, W = a.shape
+    out = np.zeros(B, np.float32)
+    assert lib().emul_ssim(_p(a), _p(b), _p(out), B, C, H, W) == 0
+    return out

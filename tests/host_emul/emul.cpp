@@ -217,6 +217,29 @@ int emul_fused_bwd(const int* ops, int K, const float* img, const float* params,
   return 0;
 }
 
+int emul_ssim(const float* a, const float* b, float* out, int B, int C, int H, int W) {
+  SsimArgs s;
+  memset(&s, 0, sizeof(s));
+  s.a = a; s.b = b;
+  ssim_window(s.g);
+  s.B = B; s.C = C; s.H = H; s.W = W;
+  s.tiles_x = (W + kSsimTile - 1) / kSsimTile;
+  s.tiles = s.tiles_x * ((H + kSsimTile - 1) / kSsimTile);
+  std::vector<float> lds(ssim_lds_floats());
+  for (int bb = 0; bb < B; ++bb) {
+    double total = 0.0;
+    for (int c = 0; c < C; ++c)
+      for (int tile = 0; tile < s.tiles; ++tile) {
+        const int plane = bb * C + c;
+        for (int tid = 0; tid < kThreads; ++tid) ssim_phase_load(s, plane, tile, tid, lds.data());
+        for (int tid = 0; tid < kThreads; ++tid) ssim_phase_rows(s, tid, lds.data());
+        for (int tid = 0; tid < kThreads; ++tid) total += ssim_phase_cols(s, tile, tid, lds.data());
+      }
+    out[bb] = (float)(total / ((double)C * H * W));
+  }
+  return 0;
+}
+
 int emul_fused_buffers(const int* ops, int K) {
   Segment seg[64];
   const int ns = plan_segments(ops, K, seg, 64);

@@ -209,3 +209,16 @@ def test_tiny_and_ragged_shapes(shape):
         gi, gp = emul.bwd(op, img.numpy(), p.numpy(), gout.numpy())
         np.testing.assert_allclose(gi, gi64.numpy(), rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(gp, gp64.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(gp64.abs().max())))
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 48, 40), (2, 3, 33, 70), (1, 1, 5, 7)])
+def test_ssim_block_program(shape, golden_dir):
+    import os
+    B, C, H, W = shape
+    a = synth.uniform(shape, 51)
+    b = (a + synth.uniform(shape, 52, -0.1, 0.1)).clamp(0, 1)
+    ref = cpu_ref.ssim(a, b, size_average=False)
+    np.testing.assert_allclose(emul.ssim(a.numpy(), b.numpy()), ref.numpy(), rtol=1e-5, atol=1e-6)
+    if shape == (1, 3, 48, 40):            # the golden value computed by the reference's own utils/ssim
+        g = np.load(os.path.join(golden_dir, 'ssim.npz'))
+        assert abs(float(emul.ssim(a.numpy(), b.numpy())[0]) - float(g['ssim'])) < 1e-5

@@ -122,3 +122,21 @@ def test_trainer_alternates_and_learns():
     assert torch.isfinite(op_loss) and torch.isfinite(param_loss) and torch.isfinite(l1)
     assert not torch.equal(w0, model.decoder.out_linear.weight.detach())
     assert tr.grads.flat.numel() == 22165917
+
+
+def test_evaluation_loop_full_resolution():
+    """test() of test_seq2seqL1.py at inference shapes (bs=1, non-square, short side 600 -> here a
+    smaller 150x225 so the test stays quick): runs end to end and reports L1 / SSIM."""
+    from t2onet_amd.evaluate import test as evaluate
+    dev = torch.device('cuda:0')
+    model, opt = make_model(dev)
+    opt.print_every = 100
+    batches = []
+    for i in range(3):
+        x = synth.requests(1, L, 60 + i)
+        img_x = synth.images(1, 150, 225, 70 + i)
+        img_y = (img_x + synth.uniform((1, 3, 150, 225), 80 + i, -0.05, 0.05)).clamp(0, 1)
+        batches.append((img_x, img_y, x, ['req']))
+    init_d, d = evaluate(model, batches, opt, is_test=True, verbose=False)
+    ref_init = float(np.mean([(a - b).abs().mean().item() for a, b, _, _ in batches]))
+    assert abs(init_d - ref_init) < 1e-6 and 0.0 <= d <= 1.0

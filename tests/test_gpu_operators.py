@@ -365,3 +365,17 @@ def test_attention_core(dev):
         np.testing.assert_allclose(m2.detach().cpu().numpy(), mix.detach().numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(qd.grad.cpu().numpy(), q64.grad.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(cd.grad.cpu().numpy(), c64.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 48, 40), (2, 3, 33, 70), (1, 1, 5, 7), (1, 3, 397, 600)])
+def test_ssim_kernel(dev, golden_dir, shape):
+    import t2onet_amd.functional as T
+    a = synth.uniform(shape, 51)
+    b = (a + synth.uniform(shape, 52, -0.1, 0.1)).clamp(0, 1)
+    ref = cpu_ref.ssim(a, b, size_average=False)
+    out = T.ssim(a.to(dev), b.to(dev), size_average=False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(T.ssim(a.to(dev), b.to(dev)).item() - ref.mean().item()) < 1e-6
+    if shape == (1, 3, 48, 40):
+        g = np.load(os.path.join(golden_dir, 'ssim.npz'))
+        assert abs(out[0].item() - float(g['ssim'])) < 1e-5
