@@ -902,9 +902,9 @@ inline int plan_segments(const int* ops, int K, Segment* seg, int max_seg) {
   return ns;
 }
 
-inline void chain_geometry(int B, int H, int W, int forced_iters, int& vec, int& iters, int& nblk) {
+inline void chain_geometry(int B, int H, int W, int forced_iters, int& vec, int& iters, int& nblk, int forced_vec = 0) {
   const size_t hw = (size_t)H * W;
-  vec = (hw % 2 == 0) ? 2 : 1;
+  vec = (hw % 2 == 0 && forced_vec != 1) ? 2 : 1;
   const size_t groups = hw / vec;
   size_t it = forced_iters > 0 ? (size_t)forced_iters : (groups * (size_t)B) / ((size_t)kThreads * 4096);
   if (it < 1) it = 1;

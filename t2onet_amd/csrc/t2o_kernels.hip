@@ -277,6 +277,7 @@ __global__ __launch_bounds__(kThreads) void k_finalize_params(OpArgs a, float* g
   }
   __syncthreads();
   if (threadIdx.x == 0) finalize_param_grad(op, a.param + (size_t)b * a.param_stride, sums, grow);
+  if ((int)threadIdx.x >= np && (int)threadIdx.x < kMaxParam && (int)threadIdx.x < gparam_stride) grow[threadIdx.x] = 0.0f;
 }
 
 // loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order)
@@ -361,29 +362,36 @@ __global__ __launch_bounds__(kThreads) void k_ssim_finalize(const float* partial
 }
 
 // ------------------------------------------------------------------ attention core
-// One wave per sample.  Lane l (< L) owns score / probability l; every lane owns D/64 columns.
+// One workgroup (4 waves) per sample.  Scores: wave w takes encoder rows w, w+4, ... (lanes stride
+// the D columns, shuffle reduction); softmax over all L rows from LDS; mix / gradients: one thread
+// per column.  L <= 64, D <= 1024.
 __global__ __launch_bounds__(kThreads) void k_attn_fwd(const float* q, const float* ctx, float* attn, float* mix,
                                                        int B, int L, int D) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (b >= B) return;
+  __shared__ float sc[64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* qb = q + (size_t)b * D;
   const float* cb = ctx + (size_t)b * L * D;
-  float mine = -INFINITY;
-  for (int l = 0; l < L; ++l) {
+  for (int l = wave; l < L; l += kThreads / 64) {
     float part = 0.0f;
     for (int e = lane; e < D; e += 64) part += qb[e] * cb[(size_t)l * D + e];
     const float s = wave_sum(part);
-    if (lane == l) mine = s;
+    if (lane == 0) sc[l] = s;
   }
-  const float mx = wave_max(mine);
-  const float ex = lane < L ? expf(mine - mx) : 0.0f;
-  const float den = wave_sum(ex);
-  const float prob = ex / den;
-  if (lane < L) attn[(size_t)b * L + lane] = prob;
-  for (int e = lane; e < D; e += 64) {
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int l = 0; l < L; ++l) mx = fmaxf(mx, sc[l]);
+  float den = 0.0f;
+  for (int l = 0; l < L; ++l) den += expf(sc[l] - mx);
+  __syncthreads();
+  if ((int)threadIdx.x < L) {
+    const float pr = expf(sc[threadIdx.x] - mx) / den;
+    sc[threadIdx.x] = pr;
+    attn[(size_t)b * L + threadIdx.x] = pr;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < D; e += kThreads) {
     float acc = 0.0f;
-    for (int l = 0; l < L; ++l) acc += __shfl(prob, l, 64) * cb[(size_t)l * D + e];
+    for (int l = 0; l < L; ++l) acc += sc[l] * cb[(size_t)l * D + e];
     mix[(size_t)b * D + e] = acc;
   }
 }
@@ -391,30 +399,29 @@ __global__ __launch_bounds__(kThreads) void k_attn_fwd(const float* q, const flo
 __global__ __launch_bounds__(kThreads) void k_attn_bwd(const float* q, const float* ctx, const float* attn,
                                                        const float* gmix, const float* gattn, float* gq, float* gctx,
                                                        int B, int L, int D) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (b >= B) return;
+  __shared__ float pr[64], ga[64], gs[64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* qb = q + (size_t)b * D;
   const float* cb = ctx + (size_t)b * L * D;
   const float* gm = gmix + (size_t)b * D;
-  const float prob = lane < L ? attn[(size_t)b * L + lane] : 0.0f;
-  float ga = 0.0f;                                 // d loss / d prob_l on lane l
-  for (int l = 0; l < L; ++l) {
+  for (int l = wave; l < L; l += kThreads / 64) {       // d loss / d prob_l
     float part = 0.0f;
     for (int e = lane; e < D; e += 64) part += gm[e] * cb[(size_t)l * D + e];
     const float s = wave_sum(part);
-    if (lane == l) ga = s;
+    if (lane == 0) ga[l] = s + (gattn ? gattn[(size_t)b * L + l] : 0.0f);
   }
-  if (gattn && lane < L) ga += gattn[(size_t)b * L + lane];
-  const float dot = wave_sum(prob * ga);
-  const float gs = prob * (ga - dot);              // d loss / d score_l (softmax backward)
-  for (int e = lane; e < D; e += 64) {
-    float acc = 0.0f;
+  if ((int)threadIdx.x < L) pr[threadIdx.x] = attn[(size_t)b * L + threadIdx.x];
+  __syncthreads();
+  float dot = 0.0f;
+  for (int l = 0; l < L; ++l) dot += pr[l] * ga[l];
+  if ((int)threadIdx.x < L) gs[threadIdx.x] = pr[threadIdx.x] * (ga[threadIdx.x] - dot);   // softmax backward
+  __syncthreads();
+  for (int e = threadIdx.x; e < D; e += kThreads) {
     const float qe = qb[e], ge = gm[e];
+    float acc = 0.0f;
     for (int l = 0; l < L; ++l) {
-      const float gsl = __shfl(gs, l, 64), pl = __shfl(prob, l, 64);
-      acc += gsl * cb[(size_t)l * D + e];
-      gctx[((size_t)b * L + l) * D + e] = pl * ge + gsl * qe;
+      acc += gs[l] * cb[(size_t)l * D + e];
+      gctx[((size_t)b * L + l) * D + e] = pr[l] * ge + gs[l] * qe;
     }
     gq[(size_t)b * D + e] = acc;
   }
@@ -435,7 +442,7 @@ Geometry launch_geometry(int B, int H, int W) {
 // per-operator geometry and the fused-chain geometry; kMaxChainSlots floats per block row.
 size_t ws_block_rows(const Geometry& g, int B, int H, int W) {
   int vec, iters, nblk;
-  chain_geometry(B, H, W, env_int("T2O_CHAIN_ITERS", 0), vec, iters, nblk);
+  chain_geometry(B, H, W, env_int("T2O_CHAIN_ITERS", 0), vec, iters, nblk, env_int("T2O_CHAIN_VEC", 0));
   return (size_t)(g.nblk_max > nblk ? g.nblk_max : nblk);
 }
 size_t ws_partials_floats(const Geometry& g, int B, int H, int W) { return (size_t)B * ws_block_rows(g, B, H, W) * kMaxChainSlots; }
@@ -753,7 +760,7 @@ int run_curve_bwd_as_chain(int op, const float* img, const float* param, int par
                            void* ws, int B, int H, int W, hipStream_t st) {
   static const int forced = env_int("T2O_CHAIN_ITERS", 0);
   int vec, iters, nblk;
-  chain_geometry(B, H, W, forced, vec, iters, nblk);
+  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CHAIN_VEC", 0));
   Segment sg;
   sg.first = 0; sg.count = 1; sg.sharp = false; sg.n = 1; sg.ops[0] = op; sg.src[0] = 0;
   ChainArgs a;
@@ -782,7 +789,7 @@ int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float*
   if (target && (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W))) return fail(T2O_EWORKSPACE, "workspace too small");
   static const int forced = env_int("T2O_CHAIN_ITERS", 0);
   int vec, iters, nblk;
-  chain_geometry(B, H, W, forced, vec, iters, nblk);
+  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CHAIN_VEC", 0));
   const Geometry g = launch_geometry(B, H, W);
   const size_t img_floats = (size_t)B * 3 * H * W;
   hipStream_t st = (hipStream_t)stream;
@@ -823,10 +830,12 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
   if (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
   static const int forced = env_int("T2O_CHAIN_ITERS", 0);
   int vec, iters, nblk;
-  chain_geometry(B, H, W, forced, vec, iters, nblk);
+  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CHAIN_VEC", 0));
   const size_t img_floats = (size_t)B * 3 * H * W;
   hipStream_t st = (hipStream_t)stream;
-  if (K > 0) hipMemsetAsync(gparams, 0, sizeof(float) * (size_t)K * B * kMaxParam, st);
+  bool has_identity = false;                     // identity rows are written by no kernel
+  for (int k = 0; k < K; ++k) has_identity = has_identity || ops[k] == OP_IDENTITY;
+  if (has_identity) hipMemsetAsync(gparams, 0, sizeof(float) * (size_t)K * B * kMaxParam, st);
   const float* gcur = nullptr;
   for (int s = ns - 1; s >= 0; --s) {
     const float* in = s == 0 ? img : seg_bufs + (size_t)(s - 1) * img_floats;
@@ -881,8 +890,7 @@ int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix, int 
   if (!q || !ctx || !attn || !mix) return fail(T2O_EINVAL, "attn_fwd: null pointer");
   if (B <= 0 || L <= 0 || L > 64 || D <= 0 || D % 64 != 0 || D > 1024)
     return fail(T2O_EINVAL, "attn: need 1 <= L <= 64, D % 64 == 0, D <= 1024");
-  const unsigned grid = (unsigned)((B + kThreads / 64 - 1) / (kThreads / 64));
-  k_attn_fwd<<<grid, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, mix, B, L, D);
+  k_attn_fwd<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, mix, B, L, D);
   return check_launch("attention forward");
 }
 
@@ -891,8 +899,7 @@ int t2o_attn_bwd(const float* q, const float* ctx, const float* attn, const floa
   if (!q || !ctx || !attn || !gmix || !gq || !gctx) return fail(T2O_EINVAL, "attn_bwd: null pointer");
   if (B <= 0 || L <= 0 || L > 64 || D <= 0 || D % 64 != 0 || D > 1024)
     return fail(T2O_EINVAL, "attn: need 1 <= L <= 64, D % 64 == 0, D <= 1024");
-  const unsigned grid = (unsigned)((B + kThreads / 64 - 1) / (kThreads / 64));
-  k_attn_bwd<<<grid, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, gmix, gattn, gq, gctx, B, L, D);
+  k_attn_bwd<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, gmix, gattn, gq, gctx, B, L, D);
   return check_launch("attention backward");
 }
 
