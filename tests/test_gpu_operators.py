@@ -379,3 +379,29 @@ def test_ssim_kernel(dev, golden_dir, shape):
     if shape == (1, 3, 48, 40):
         g = np.load(os.path.join(golden_dir, 'ssim.npz'))
         assert abs(out[0].item() - float(g['ssim'])) < 1e-5
+
+
+def test_config5_shape_fused_equals_materialised(executor, dev):
+    """BASELINE config 5 per-GPU shape: 16 images 512x512, 8 operators (curve-heavy, repeats allowed)."""
+    B, H, W = 16, 512, 512
+    ops = [5, 3, 5, 3, 0, 1, 2, 6]
+    g = torch.Generator().manual_seed(12)
+    img = torch.rand(B, 3, H, W, generator=g).to(dev)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
+    params = torch.zeros(len(ops), B, 24)
+    rng = {5: (8, .5, 1.5), 3: (24, .5, 1.5), 0: (1, -.3, .3), 1: (1, -.3, .3), 2: (1, -.3, .3), 6: (1, 0., 1.)}
+    for k, op in enumerate(ops):
+        n, lo, hi = rng[op]
+        params[k, :, :n] = torch.rand(B, n, generator=g) * (hi - lo) + lo
+    res = []
+    for fn in (executor.run_sequence, executor.run_sequence_fused):
+        x = img.clone().requires_grad_(True)
+        p = params.to(dev).requires_grad_(True)
+        loss, out = fn(x, ops, p, tgt)
+        loss.backward()
+        res.append((loss.item(), out if out.dim() == 4 else out[-1], x.grad, p.grad))
+    (l0, o0, gx0, gp0), (l1, o1, gx1, gp1) = res
+    assert torch.equal(o0, o1) and abs(l0 - l1) < 1e-7
+    assert torch.allclose(gx0, gx1, rtol=1e-5, atol=1e-10)
+    assert torch.allclose(gp0, gp1, rtol=5e-4, atol=5e-5 * max(1.0, gp0.abs().max().item()))
+    assert o0.min().item() >= 0.0 and o0.max().item() <= 1.0
