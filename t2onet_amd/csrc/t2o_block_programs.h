@@ -587,12 +587,13 @@ T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
 }
 
 // backward of a curve operator on one pixel (COLOR: per-channel curves, else one shared curve):
-// g = gradient w.r.t. the CLAMPED output; returns the gradient w.r.t. the input, adds the raw
-// sums red[8*row + j] += dz * t_j.  (A segment-histogram variant -- two LDS float atomics per
-// channel instead of 8 multiply-adds -- measured 3x SLOWER on MI355X: ds_add_f32 with per-lane
-// addresses runs at roughly one lane per 3 cycles per CU.  Kept out.)
+// dz = gradient w.r.t. the PRE-clamp output (already zeroed where the clamp was active);
+// returns the gradient w.r.t. the input, adds the raw sums red[8*row + j] += dz * t_j.
+// (A segment-histogram variant -- two LDS float atomics per channel instead of 8 multiply-adds --
+// measured 3x SLOWER on MI355X: ds_add_f32 with per-lane addresses runs at roughly one lane per
+// 3 cycles per CU.  Kept out.)
 template <bool COLOR>
-T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* red) {
+T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* red) {
   Rgb gx;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
@@ -601,16 +602,13 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* re
     const float* kk = t + kTabK + cc * kCurveSteps;
     int i; float frac;
     curve_locate(x.c[c], i, frac);
-    const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * kk[i];
-    const float z = COLOR ? total * t[kTabScale + cc] : (total * (float)kCurveSteps) / t[kTabSum + cc];
-    const float dz = (z >= 0.0f && z <= 1.0f) ? g.c[c] : 0.0f;
     const float d = x.c[c] - (float)i / kCurveSteps;
     float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
     if (d == 0.0f && i > 0) slope += kk[i - 1];                     // on a knot both neighbours pass (inclusive clamp)
-    gx.c[c] = dz * t[kTabScale + cc] * slope;
+    gx.c[c] = dz.c[c] * t[kTabScale + cc] * slope;
     T2O_UNROLL
     for (int j = 0; j < kCurveSteps; ++j)
-      red[cc * kCurveSteps + j] += dz * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+      red[cc * kCurveSteps + j] += dz.c[c] * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
   }
   return gx;
 }
@@ -618,14 +616,8 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& g, float* re
 // raw-sum slot s of `partials` from this workgroup's summed accumulator cells
 T2O_HD float chain_slot_value(const ChainArgs& a, int s, const float* bsum) { return bsum[s]; }
 
-// backward of a one-parameter chain operator (brightness / contrast / saturation)
-T2O_HD Rgb chain_scalar_bwd(int op, const Rgb& x, const float* t, const Rgb& g, float* red) {
-  Rgb dz = g;
-  if (clamp_can_act(op, x)) {
-    const Rgb r = chain_op_fwd(op, x, t);
-    T2O_UNROLL
-    for (int c = 0; c < 3; ++c) dz.c[c] = (r.c[c] >= 0.0f && r.c[c] <= 1.0f) ? g.c[c] : 0.0f;
-  }
+// backward of a one-parameter chain operator (brightness / contrast / saturation); dz as above
+T2O_HD Rgb chain_scalar_bwd(int op, const Rgb& x, const float* t, const Rgb& dz, float* red) {
   Curve unused;
   float p0[1] = {t[0]};
   return pointwise_bwd(op, x, p0, unused, dz, red);
@@ -697,6 +689,9 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
     const bool live = g < groups;                 // dead threads still take part in the quad reductions
     const unsigned px = live ? g * V : 0;
     float x[3][V], gg[3][V];
+    unsigned pass[V];                              // bit 3k+c: the clamp after operator k passed channel c
+    T2O_UNROLL
+    for (int i = 0; i < V; ++i) pass[i] = 0u;
     T2O_UNROLL
     for (int c = 0; c < 3; ++c) {
       load_vec<V>(xin + c * hw + px, x[c]);
@@ -715,7 +710,10 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
         for (int c = 0; c < 3; ++c) sv[((k * 3 + c) * V + i) * kThreads + tid] = xi.c[c];
         const Rgb r = chain_op_fwd(op, xi, tab + k * kTabStride);
         T2O_UNROLL
-        for (int c = 0; c < 3; ++c) x[c][i] = clamp01(r.c[c]);
+        for (int c = 0; c < 3; ++c) {
+          pass[i] |= (r.c[c] >= 0.0f && r.c[c] <= 1.0f) ? (1u << (3 * k + c)) : 0u;   // clamp(0,1) backward is inclusive
+          x[c][i] = clamp01(r.c[c]);
+        }
       }
     }
     if (L1) {
@@ -748,9 +746,12 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
         for (int j = 0; j < NRED; ++j) red[j] = 0.0f;                                    \
         T2O_UNROLL                                                                       \
         for (int i = 0; i < V; ++i) {                                                    \
-          Rgb xi, gi = {{gg[0][i], gg[1][i], gg[2][i]}};                                 \
+          Rgb xi, gi;                                                                    \
           T2O_UNROLL                                                                     \
-          for (int c = 0; c < 3; ++c) xi.c[c] = sv[((k * 3 + c) * V + i) * kThreads + tid]; \
+          for (int c = 0; c < 3; ++c) {                                                  \
+            xi.c[c] = sv[((k * 3 + c) * V + i) * kThreads + tid];                        \
+            gi.c[c] = ((pass[i] >> (3 * k + c)) & 1u) ? gg[c][i] : 0.0f;                 \
+          }                                                                              \
           const Rgb gx = CALL;                                                           \
           T2O_UNROLL                                                                     \
           for (int c = 0; c < 3; ++c) gg[c][i] = gx.c[c];                                \

@@ -341,11 +341,13 @@ T2O_HD Rgb contrast_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float L = fminf(fmaxf(lum, 0.0f), 1.0f);
   // torch.min(torch.max(lum, 0), 1): elementwise max/min split the gradient 1/2 - 1/2 at a tie
   const float inside = (lum > 0.0f && lum < 1.0f) ? 1.0f : ((lum == 0.0f || lum == 1.0f) ? 0.5f : 0.0f);
-  const float cl = (-cosf(kPi * L)) * 0.5f + 0.5f;
+  float sn, cs;
+  sincosf(kPi * L, &sn, &cs);                  // one shared argument reduction
+  const float cl = (-cs) * 0.5f + 0.5f;
   const float Le = L + 1e-6f;
   const float rLe = T2O_FDIV(1.0f, Le);
   const float q = cl * rLe;
-  const float dq = (0.5f * kPi * sinf(kPi * L) * Le - cl) * rLe * rLe;
+  const float dq = (0.5f * kPi * sn * Le - cl) * rLe * rLe;
   const float S = g.c[0] * x.c[0] + g.c[1] * x.c[1] + g.c[2] * x.c[2];
   const float k0 = (1.0f - p) + p * q;
   const float k1 = inside * p * S * dq;
