@@ -280,6 +280,48 @@ __global__ __launch_bounds__(kThreads) void k_finalize_params(OpArgs a, float* g
   if ((int)threadIdx.x >= np && (int)threadIdx.x < kMaxParam && (int)threadIdx.x < gparam_stride) grow[threadIdx.x] = 0.0f;
 }
 
+// The same for every operator of a materialised sequence in ONE launch: operator k keeps its
+// per-block rows in its own region of the workspace.
+struct MultiFinalize {
+  const float* params;     // (K,B,24)
+  float* gparams;          // (K,B,24)
+  const float* partials;   // K regions of region_floats
+  size_t region_floats;
+  int ops[kMaxChain];
+  int nblk[kMaxChain];
+  int K, B, nblk_max;
+};
+
+__global__ __launch_bounds__(kThreads) void k_finalize_params_multi(MultiFinalize m) {
+  __shared__ float part[kThreads / 32][32];
+  __shared__ float sums[kRedSlots];
+  const int k = blockIdx.x / m.B, b = blockIdx.x % m.B;
+  const int slot = threadIdx.x & 31, chunk = threadIdx.x >> 5;
+  const int op = m.ops[k];
+  float* grow = m.gparams + ((size_t)k * m.B + b) * kMaxParam;
+  const int np = op_num_params(op);
+  if (op == OP_IDENTITY || op == OP_WHITE || np == 0) {
+    if ((int)threadIdx.x < kMaxParam) grow[threadIdx.x] = 0.0f;
+    return;
+  }
+  const int n = nred_of(op), nb = m.nblk[k];
+  const float* base = m.partials + (size_t)k * m.region_floats + (size_t)b * m.nblk_max * kRedSlots;
+  float acc = 0.0f;
+  if (slot < n)
+    for (int r = chunk; r < nb; r += kThreads / 32) acc += base[(size_t)r * kRedSlots + slot];
+  part[chunk][slot] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    float v = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kThreads / 32; ++c) v += part[c][threadIdx.x];
+    sums[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) finalize_param_grad(op, m.params + ((size_t)k * m.B + b) * kMaxParam, sums, grow);
+  if ((int)threadIdx.x >= np && (int)threadIdx.x < kMaxParam) grow[threadIdx.x] = 0.0f;
+}
+
 // loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order)
 __global__ __launch_bounds__(kThreads) void k_finalize_loss(OpArgs a, float* loss, int nblk_point, int nblk_sharp) {
   float acc = 0.0f;
@@ -565,28 +607,47 @@ int run_curve_bwd_as_chain(int op, const float* img, const float* param, int par
 
 int run_bwd(int op, const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
             int mask_ch, const float* gout, const float* target, const float* gloss, float* gimg, float* gparam,
-            int gparam_stride, void* ws, size_t ws_bytes, int B, int H, int W, void* stream) {
+            int gparam_stride, void* ws, size_t ws_bytes, int B, int H, int W, void* stream,
+            float* partials_region = nullptr, int* nblk_out = nullptr) {
   if (int rc = check_common(op, op_id, img, param, param_stride, mask, mask_ch, B, H, W)) return rc;
   if (!target && !gout) return fail(T2O_EINVAL, "gout is null");
   if (target && !gloss) return fail(T2O_EINVAL, "gloss is null");
   if (!ws || ws_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
   if (gparam && gparam_stride < (op == OP_DYNAMIC ? kMaxParam : op_num_params(op)))
     return fail(T2O_EINVAL, "gparam_stride too small");
-  const Geometry g = launch_geometry(B, H, W);
+  Geometry g = launch_geometry(B, H, W);
+  if (op == OP_COLOR || op == OP_TONE) {
+    // the 24 / 8 per-thread raw sums cost a wave + LDS reduction per workgroup: give each thread 4x the
+    // pixels (48 vs 60 us for the color curve at bs=64 256x256); block rows only shrink, so the
+    // workspace bound still holds
+    static const int mult = env_int("T2O_CURVE_BWD_ITERS", 4);
+    const size_t groups = (size_t)H * W / g.vec;
+    int it = g.iters * (mult > 0 ? mult : 1);
+    if (it > 8) it = 8;
+    g.iters = it;
+    g.nblk_point = (int)((groups + (size_t)kThreads * it - 1) / ((size_t)kThreads * it));
+  }
   OpArgs a;
   memset(&a, 0, sizeof(a));
   a.img = img; a.param = param; a.mask = mask; a.op_id = op_id; a.gout = gout; a.target = target; a.gloss = gloss;
-  a.gimg = gimg; a.partials = (float*)ws;
+  a.gimg = gimg; a.partials = partials_region ? partials_region : (float*)ws;
   a.op = op; a.param_stride = param_stride; a.mask_ch = mask_ch; a.B = B; a.H = H; a.W = W;
   a.iters = g.iters; a.nblk_max = g.nblk_max;
   a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
   hipStream_t st = (hipStream_t)stream;
-  if (op == OP_COLOR && !mask && gparam) {
-    // color curve: the one-operator chain kernel (LDS curve lookup for the forward recompute) measured
-    // 54 us vs 61 us for k_point_bwd<3> at bs=64 256x256; the tone curve is faster in k_point_bwd<5>
-    static const int off = env_int("T2O_NO_CURVE_CHAIN", 0);
-    if (!off) return run_curve_bwd_as_chain(op, img, param, param_stride, gout, target, gloss, gimg, gparam,
-                                            gparam_stride, ws, B, H, W, st);
+  if (partials_region) {                        // the caller finalises every operator of the sequence at once
+    if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
+    else launch_sharp_bwd(a, g, st);
+    if (nblk_out) *nblk_out = (op == OP_SHARPNESS) ? g.nblk_sharp : g.nblk_point;
+    return check_launch("operator backward");
+  }
+  if ((op == OP_COLOR || op == OP_TONE) && !mask && gparam) {
+    // curve operators can run as a one-operator chain (LDS curve lookup, clamp bits from the forward
+    // sweep).  T2O_CURVE_CHAIN: 0 = never (default: no faster than k_point_bwd at 4x pixels per thread), 1 = color only, 2 = both
+    static const int mode = env_int("T2O_CURVE_CHAIN", 0);
+    if (mode >= 2 || (mode == 1 && op == OP_COLOR))
+      return run_curve_bwd_as_chain(op, img, param, param_stride, gout, target, gloss, gimg, gparam, gparam_stride,
+                                    ws, B, H, W, st);
   }
   if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
   if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_bwd(a, g, st);
@@ -711,26 +772,39 @@ int t2o_sequence_bwd(const int* ops, int K, const float* img, const float* param
                      size_t workspace_bytes, int B, int H, int W, void* stream) {
   if (!ops || K <= 0 || !params || !acts || !target || !gloss || !gparams || !gbuf)
     return fail(T2O_EINVAL, "sequence_bwd: null pointer or K <= 0");
+  if (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
   const size_t img_floats = (size_t)B * 3 * H * W;
+  const Geometry g = launch_geometry(B, H, W);
+  // one finalize launch for the whole sequence: the workspace holds kMaxChainSlots floats per block row,
+  // i.e. kMaxChain regions of kRedSlots -- operator k keeps its rows in region k
+  const bool multi = K <= kMaxChain;
+  const size_t region = (size_t)B * ws_block_rows(g, B, H, W) * kRedSlots;
+  MultiFinalize mf;
+  memset(&mf, 0, sizeof(mf));
+  mf.params = params; mf.gparams = gparams; mf.partials = (const float*)workspace; mf.region_floats = region;
+  mf.K = K; mf.B = B; mf.nblk_max = g.nblk_max;
   const float* gcur = nullptr;
   for (int k = K - 1; k >= 0; --k) {
     const float* in = k == 0 ? img : acts + (size_t)(k - 1) * img_floats;
     const float* p = params + (size_t)k * B * kMaxParam;
     float* gp = gparams + (size_t)k * B * kMaxParam;
     float* gout_next = (k == 0) ? gimg : gbuf + (size_t)(k & 1) * img_floats;
-    int rc;
-    if (k == K - 1)
-      rc = run_bwd(ops[k], nullptr, in, p, kMaxParam, nullptr, 0, nullptr, target, gloss, gout_next, gp, kMaxParam,
-                   workspace, workspace_bytes, B, H, W, stream);
-    else
-      rc = run_bwd(ops[k], nullptr, in, p, kMaxParam, nullptr, 0, gcur, nullptr, nullptr, gout_next, gp, kMaxParam,
-                   workspace, workspace_bytes, B, H, W, stream);
+    const bool last = k == K - 1;
+    float* reg = (multi && ops[k] != OP_IDENTITY) ? (float*)workspace + (size_t)k * region : nullptr;
+    int nb = 0;
+    const int rc = run_bwd(ops[k], nullptr, in, p, kMaxParam, nullptr, 0, last ? nullptr : gcur, last ? target : nullptr,
+                           last ? gloss : nullptr, gout_next, gp, kMaxParam, workspace, workspace_bytes, B, H, W, stream,
+                           reg, &nb);
     if (rc) return rc;
+    if (multi) { mf.ops[k] = ops[k]; mf.nblk[k] = nb; }
     gcur = gout_next;
+  }
+  if (multi) {
+    k_finalize_params_multi<<<(unsigned)(K * B), kThreads, 0, (hipStream_t)stream>>>(mf);
+    return check_launch("sequence backward finalize");
   }
   return T2O_OK;
 }
-
 
 int t2o_fused_sequence_buffers(const int* ops, int K) {
   Segment seg[64];
@@ -760,7 +834,7 @@ int run_curve_bwd_as_chain(int op, const float* img, const float* param, int par
                            void* ws, int B, int H, int W, hipStream_t st) {
   static const int forced = env_int("T2O_CHAIN_ITERS", 0);
   int vec, iters, nblk;
-  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CHAIN_BWD_VEC", 1));
+  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CURVE_CHAIN_VEC", 2));   // one operator: pixel pairs
   Segment sg;
   sg.first = 0; sg.count = 1; sg.sharp = false; sg.n = 1; sg.ops[0] = op; sg.src[0] = 0;
   ChainArgs a;
