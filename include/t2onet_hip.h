@@ -120,6 +120,15 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
                            float* gimg, float* gparams, const float* seg_bufs, float* gbuf,
                            void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 
+/* ---- planner candidate sweep (utils/beam_search.py:65-91: one executor call + .item() per
+ * evaluated parameter): loss[c] = mean |clamp(process(img, params[c])) - target| for C candidate
+ * parameter rows of ONE per-pixel operator (0,1,2,3,5,7) against ONE image pair (3,H,W), in a
+ * single launch; the image is read once per 8 candidates. */
+size_t t2o_candidates_workspace_bytes(int C, int H, int W);
+int t2o_op_candidates_l1(int op, const float* img, const float* target, const float* params, int C,
+                         int param_stride, float* loss, void* workspace, size_t workspace_bytes,
+                         int H, int W, void* stream);
+
 /* ---- SSIM (evaluation metric, forward only): utils/ssim/__init__.py:20-40 ----
  * 11x11 Gaussian window (sigma 1.5), zero padding, C1 = 1e-4, C2 = 9e-4.
  * out[b] = mean over (C,H,W) of the SSIM map of sample b (size_average=False of the reference;

@@ -411,11 +411,13 @@ T2O_HD void sharp_dz_quad(const OpArgs& a, float p, float gs, int y0, int x0, in
       if (a.mask_ch) mq[0] = tile_at(M, 1, a.mask_ch == 3 ? c : 0, r, j0);
     }
     const float L = tile_at(X, 2, c, r, j0 - 1), R = tile_at(X, 2, c, r, j0 + n);
+    // an aligned quad (n == 4, W % 4 == 0) is entirely inside or outside the image
+    const bool row_in = gy >= 0 && gy < a.H;
+    const bool quad_in = row_in && x0 + j0 >= 0 && x0 + j0 < a.W;
     T2O_UNROLL
     for (int i = 0; i < 4; ++i) {
       if (i < n) {
-        const int gx = x0 + j0 + i;
-        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const bool in = n == 4 ? quad_in : (row_in && x0 + j0 + i >= 0 && x0 + j0 + i < a.W);
         const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == n - 1 ? R : ce[i < 3 ? i + 1 : 3];
         const float d = sharp_delta(ce[i], up[i], left, right, dn[i]);
         const float m = a.mask_ch ? mq[i] : 1.0f;
@@ -856,6 +858,74 @@ T2O_HD float ssim_phase_cols(const SsimArgs& s, int tile, int tid, const float* 
     sum += ((2.0f * mu12 + C1) * (2.0f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
   }
   return sum;
+}
+
+// ===================================================================== planner: candidate sweep
+// Operation planning (utils/beam_search.py:65-91) fits one operator's parameter by minimising
+// dist(execute(img, op, param), target) with one executor call + one `.item()` per evaluation.
+// Here C candidate parameter rows are evaluated against ONE image pair in a single launch: a
+// workgroup keeps its pixels in registers and walks a group of candidates (curve tables in LDS).
+constexpr int kCandPerBlock = 8;      // candidates per workgroup
+constexpr int kCandPix = 8;           // pixels per thread
+
+struct CandArgs {
+  const float* img;       // (3,H,W)
+  const float* target;    // (3,H,W)
+  const float* params;    // (C, param_stride)
+  float* partials;        // (C, nblk) per-workgroup sums of |out - target|
+  int op, C, param_stride, H, W, nblk;
+};
+
+T2O_HD void cand_build_table(const CandArgs& a, int cand, float* t) {
+  const float* p = a.params + (size_t)cand * a.param_stride;
+  if (!is_curve(a.op)) { t[0] = p[0]; return; }
+  for (int c = 0; c < 3; ++c) {
+    const float* row = a.op == OP_COLOR ? p + c * kCurveSteps : p;
+    float s = 0.0f, run = 0.0f;
+    for (int i = 0; i < kCurveSteps; ++i) {
+      t[kTabK + c * kCurveSteps + i] = row[i];
+      t[kTabP + c * (kCurveSteps + 1) + i] = run;
+      run = run + (1.0f / kCurveSteps) * row[i];
+      s = s + row[i];
+    }
+    t[kTabP + c * (kCurveSteps + 1) + kCurveSteps] = run;
+    s = s + 1e-10f;
+    t[kTabSum + c] = s;
+    t[kTabScale + c] = (1.0f / s) * (float)kCurveSteps;
+  }
+}
+
+// sum over this thread's pixels of |clamp(op(x; candidate)) - target| for candidate slot j of the group
+T2O_HD float cand_eval(const CandArgs& a, const float* t, const float (&x)[3][kCandPix], const float (&tg)[3][kCandPix],
+                       int npx) {
+  float s = 0.0f;
+  for (int i = 0; i < kCandPix; ++i) {
+    if (i < npx) {
+      Rgb xi = {{x[0][i], x[1][i], x[2][i]}};
+      const Rgb r = chain_op_fwd(a.op, xi, t);
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) s += fabsf(clamp01(r.c[c]) - tg[c][i]);
+    }
+  }
+  return s;
+}
+
+// loads this thread's pixels (strided by 256 inside the block's chunk); returns how many are valid
+T2O_HD int cand_load(const CandArgs& a, int blk, int tid, float (&x)[3][kCandPix], float (&tg)[3][kCandPix]) {
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  int n = 0;
+  T2O_UNROLL
+  for (int i = 0; i < kCandPix; ++i) {
+    const unsigned px = ((unsigned)blk * kCandPix + i) * kThreads + tid;
+    const bool ok = px < hw;
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      x[c][i] = ok ? a.img[c * hw + px] : 0.0f;
+      tg[c][i] = ok ? a.target[c * hw + px] : 0.0f;
+    }
+    n += ok ? 1 : 0;
+  }
+  return n;     // valid pixels are the first n (px grows with i)
 }
 
 // ===================================================================== sequence planning (host)

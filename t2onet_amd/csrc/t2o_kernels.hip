@@ -403,6 +403,37 @@ __global__ __launch_bounds__(kThreads) void k_ssim_finalize(const float* partial
   if (threadIdx.x == 0) out[blockIdx.x] = out1 * inv;
 }
 
+// ------------------------------------------------------------------ planner: candidate sweep
+// grid = nblk pixel chunks x ceil(C / kCandPerBlock) candidate groups
+__global__ __launch_bounds__(kThreads) void k_candidates_l1(CandArgs a) {
+  __shared__ float tab[kCandPerBlock * kTabStride];
+  __shared__ float wsum[kCandPerBlock][kThreads / 64];
+  const int blk = blockIdx.x % a.nblk, group = blockIdx.x / a.nblk;
+  const int c0 = group * kCandPerBlock;
+  if ((int)threadIdx.x < kCandPerBlock && c0 + (int)threadIdx.x < a.C)
+    cand_build_table(a, c0 + threadIdx.x, tab + threadIdx.x * kTabStride);
+  float x[3][kCandPix], tg[3][kCandPix];
+  const int npx = cand_load(a, blk, threadIdx.x, x, tg);
+  __syncthreads();
+  for (int j = 0; j < kCandPerBlock; ++j) {
+    if (c0 + j >= a.C) break;
+    const float s = wave_sum(cand_eval(a, tab + j * kTabStride, x, tg, npx));
+    if ((threadIdx.x & 63) == 0) wsum[j][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < kCandPerBlock && c0 + (int)threadIdx.x < a.C) {
+    const int j = threadIdx.x;
+    a.partials[(size_t)(c0 + j) * a.nblk + blk] = ((wsum[j][0] + wsum[j][1]) + wsum[j][2]) + wsum[j][3];
+  }
+}
+
+__global__ __launch_bounds__(64) void k_candidates_finalize(const float* partials, int nblk, float inv_n, float* loss) {
+  float acc = 0.0f;
+  for (int k = threadIdx.x; k < nblk; k += 64) acc += partials[(size_t)blockIdx.x * nblk + k];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) loss[blockIdx.x] = acc * inv_n;
+}
+
 // ------------------------------------------------------------------ attention core
 // One workgroup (4 waves) per sample.  Scores: wave w takes encoder rows w, w+4, ... (lanes stride
 // the D columns, shuffle reduction); softmax over all L rows from LDS; mix / gradients: one thread
@@ -936,6 +967,32 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
     gcur = gnext;
   }
   return check_launch("fused sequence backward");
+}
+
+size_t t2o_candidates_workspace_bytes(int C, int H, int W) {
+  if (C <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t nblk = ((size_t)H * W + (size_t)kThreads * kCandPix - 1) / ((size_t)kThreads * kCandPix);
+  return sizeof(float) * (size_t)C * nblk;
+}
+
+int t2o_op_candidates_l1(int op, const float* img, const float* target, const float* params, int C, int param_stride,
+                         float* loss, void* workspace, size_t workspace_bytes, int H, int W, void* stream) {
+  if (!img || !target || !params || !loss) return fail(T2O_EINVAL, "candidates_l1: null pointer");
+  if (C <= 0 || H <= 0 || W <= 0) return fail(T2O_EINVAL, "C, H, W must be positive");
+  if (op == OP_SHARPNESS || op == OP_IDENTITY || !op_supported(op))
+    return fail(T2O_EUNSUPPORTED, "candidate sweep supports the per-pixel operators (0,1,2,3,5,7)");
+  if (param_stride < op_num_params(op)) return fail(T2O_EINVAL, "param_stride < number of operator parameters");
+  if (!workspace || workspace_bytes < t2o_candidates_workspace_bytes(C, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
+  CandArgs a;
+  memset(&a, 0, sizeof(a));
+  a.img = img; a.target = target; a.params = params; a.partials = (float*)workspace;
+  a.op = op; a.C = C; a.param_stride = param_stride; a.H = H; a.W = W;
+  a.nblk = (int)(((size_t)H * W + (size_t)kThreads * kCandPix - 1) / ((size_t)kThreads * kCandPix));
+  const unsigned groups = (unsigned)((C + kCandPerBlock - 1) / kCandPerBlock);
+  hipStream_t st = (hipStream_t)stream;
+  k_candidates_l1<<<(unsigned)a.nblk * groups, kThreads, 0, st>>>(a);
+  k_candidates_finalize<<<(unsigned)C, 64, 0, st>>>(a.partials, a.nblk, 1.0f / (3.0f * (float)H * (float)W), loss);
+  return check_launch("candidate sweep");
 }
 
 size_t t2o_ssim_workspace_bytes(int B, int C, int H, int W) {

@@ -313,3 +313,21 @@ def ssim(img1, img2, size_average=True):
         rc = lib.t2o_ssim_fwd(_ptr(img1), _ptr(img2), _ptr(out), _ptr(ws), ws.numel(), B, C, H, W, _stream())
     _lib.check(rc, 't2o_ssim_fwd')
     return out.mean() if size_average else out
+
+
+def candidates_l1(op, img, target, params):
+    """loss[c] = mean |execute(img, op, params[c]) - target| for C candidate rows, one launch.
+    img/target (1,3,H,W) or (3,H,W); params (C,n).  Per-pixel operators only (not sharpness)."""
+    _need_gpu(img, target, params)
+    img = img.reshape(3, *img.shape[-2:]).contiguous()
+    target = target.reshape(3, *target.shape[-2:]).contiguous()
+    params = params.contiguous()
+    C = params.shape[0]
+    H, W = img.shape[-2:]
+    lib = _lib.load()
+    loss = torch.empty(C, dtype=torch.float32, device=img.device)
+    ws = torch.empty(max(lib.t2o_candidates_workspace_bytes(C, H, W), 4), dtype=torch.uint8, device=img.device)
+    rc = lib.t2o_op_candidates_l1(int(op), _ptr(img), _ptr(target), _ptr(params), C, params.shape[1], _ptr(loss),
+                                  _ptr(ws), ws.numel(), H, W, _stream())
+    _lib.check(rc, 't2o_op_candidates_l1')
+    return loss

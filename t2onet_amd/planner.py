@@ -1,0 +1,149 @@
+"""Operation planning on the GPU (utils/beam_search.py:65-264 -- SURVEY.md 8(f) rank 1).
+
+The reference fits one operator's parameter per candidate step with scipy Nelder-Mead at batch 1:
+every objective evaluation is an `executor.execute(..., specified_param=...)` plus a `.item()`
+host sync (`get_param_naive`, beam_search.py:65-91).  Same surface here (`get_param`, `execute`,
+`get_dist`, `beam_search` with the reference's arguments), plus a GPU-native optimiser:
+
+  optimizer='sweep'   1-parameter per-pixel operators: three rounds of a 64-candidate sweep
+                      (t2o_op_candidates_l1: the image pair is read once per 8 candidates), each
+                      round shrinking the bracket around the best candidate -> 3 launches, 3 syncs;
+                      curve operators (8 / 24 parameters) and sharpness: Adam on the fused
+                      operator+L1 forward/backward kernels with no per-iteration sync.
+  'Nelder-Mead' | 'adam' | 'lbfgs'  the reference's procedures, objective evaluated by the HIP kernels.
+
+Only dist_type 'L1' is supported (the discriminator distances belong to the out-of-scope
+T2ONet+D variant).
+"""
+import numpy as np
+import torch
+
+from . import functional as T
+
+PER_PIXEL_SWEEP_OPS = (0, 1, 2)        # one parameter, bounded range: bracket sweep
+SWEEP_C = 64
+
+
+def get_dist(x1, x2, dist_type='L1'):
+    if dist_type != 'L1':
+        raise NotImplementedError("only dist_type 'L1' is on this path")
+    return T.l1_loss(x1, x2)                       # == (x1 - x2).norm(1) / x1.numel()  (beam_search.py:163-165)
+
+
+def execute(I, operation, param, executor):
+    img, _ = executor.execute(I, operation, None, features=None, specified_param=param, has_noise=False)
+    return img
+
+
+def _initial_param(operation, executor):
+    n = executor.get_param_num(operation)
+    if operation in (0, 1, 2, 6):
+        return torch.zeros(n)
+    if operation in (3, 5):
+        return torch.ones(n)
+    raise AssertionError('the operation is not global operation')          # beam_search.py:147
+
+
+def _fit_sweep_1d(I0, I1, operation, executor, rounds=3):
+    ub, lb, _ = executor.get_param_bnd(operation)
+    lo, hi = float(lb), float(ub)
+    best = None
+    for _ in range(rounds):
+        cand = torch.linspace(lo, hi, SWEEP_C, device=I0.device).view(-1, 1)
+        loss = T.candidates_l1(operation, I0, I1, cand)
+        i = int(torch.argmin(loss))                                      # the only host sync of the round
+        best = cand[i:i + 1]
+        step = (hi - lo) / (SWEEP_C - 1)
+        lo, hi = max(float(lb), float(best) - step), min(float(ub), float(best) + step)
+    return best.clone(), True
+
+
+def _fit_adam(I0, I1, operation, executor, param0, steps=300, lr=2e-2, check_every=50, tol=1e-6):
+    param = param0.clone().to(I0.device).requires_grad_(True)
+    opt = torch.optim.Adam([param], lr=lr)
+    prev = None
+    for it in range(steps):
+        opt.zero_grad()
+        loss, _ = executor.run_sequence_fused(I0, [operation], [param], I1)
+        loss.backward()
+        opt.step()
+        if (it + 1) % check_every == 0:                                  # one sync per check_every iterations
+            cur = loss.item()
+            if prev is not None and prev - cur < tol:
+                break
+            prev = cur
+    return param.detach(), True
+
+
+def _fit_scipy(I0, I1, operation, executor, param0, method):
+    from scipy.optimize import minimize
+
+    def func(p):                                                         # beam_search.py:76-86
+        param = torch.tensor([p], dtype=torch.float, device=I0.device)
+        return get_dist(execute(I0, operation, param, executor), I1).item()
+    res = minimize(func, param0.numpy(), method=method)
+    return torch.tensor([list(res.x)], dtype=torch.float, device=I0.device), bool(res.success)
+
+
+def get_param(I0, I1, txt, operation, executor, discriminator=None, dist_type='L1', optimizer='sweep'):
+    """Parameter of `operation` that best maps I0 to I1 -> (param (1,n), success_flag)."""
+    if dist_type != 'L1' or discriminator is not None:
+        raise NotImplementedError("only dist_type 'L1' without a discriminator is on this path")
+    param0 = _initial_param(operation, executor)
+    if optimizer == 'Nelder-Mead':
+        return _fit_scipy(I0, I1, operation, executor, param0, 'Nelder-Mead')
+    if optimizer == 'sweep' and operation in PER_PIXEL_SWEEP_OPS:
+        return _fit_sweep_1d(I0, I1, operation, executor)
+    if optimizer in ('sweep', 'adam'):
+        lr = 1e-2 if optimizer == 'adam' else 2e-2
+        return _fit_adam(I0, I1, operation, executor, param0.view(1, -1).repeat(I0.shape[0], 1), lr=lr)
+    if optimizer == 'lbfgs':
+        param = param0.view(1, -1).repeat(I0.shape[0], 1).to(I0.device).requires_grad_(True)
+        opt = torch.optim.LBFGS([param], lr=1)
+
+        def closure():
+            opt.zero_grad()
+            loss, _ = executor.run_sequence_fused(I0, [operation], [param], I1)
+            loss.backward()
+            return loss
+        opt.step(closure)
+        return param.detach(), True
+    raise ValueError('unknown optimizer %r' % (optimizer,))
+
+
+def beam_search(I_0, I_gt, txt, executor, discriminator, beam_size, operations, operation_names, max_step, err,
+                dist_type='L1', optimizer='sweep', replace=False):
+    """Beam search over operator sequences (beam_search.py:196-264).  Returns (actions, Is):
+    per surviving sequence the list of (name, param list, dist) and the list of intermediate images."""
+    min_dist = float('inf')
+    sequences = [[[], float('inf')]]
+    I_buff = [I_0]
+    for _ in range(max_step):
+        all_candidates, I_tmp_list, tmp_min_dists = [], [], []
+        no_update, finished = True, False
+        for j, I in enumerate(I_buff):
+            used = [operation_names.index(v[0]) for v in sequences[j][0]]
+            for operation in operations:
+                if not replace and operation in used:
+                    continue
+                param, _ = get_param(I, I_gt, txt, operation, executor, None, dist_type, optimizer)
+                I_out = execute(I, operation, param, executor)
+                dist = get_dist(I_out, I_gt, dist_type).item()
+                if dist < min_dist:
+                    tmp_min_dists.append(dist)
+                    all_candidates.append([sequences[j][0] + [(operation_names[operation], param[0].tolist(), dist, I_out)], dist])
+                    I_tmp_list.append(I_out)
+                    no_update = False
+                    finished = finished or dist < err
+        min_dist = min(tmp_min_dists) if tmp_min_dists else min_dist
+        if len(all_candidates) < beam_size:
+            all_candidates += sequences
+            I_tmp_list += I_buff
+        order = np.argsort(np.array([v[1] for v in all_candidates]))
+        sequences = [all_candidates[i] for i in order][:beam_size]
+        I_buff = [I_tmp_list[i] for i in order][:beam_size]
+        if no_update or finished:
+            break
+    actions = [[act[:-1] for act in seq[0]] for seq in sequences]
+    Is = [[act[-1] for act in seq[0]] for seq in sequences]
+    return actions, Is
