@@ -79,7 +79,7 @@ def _fit_scipy(I0, I1, operation, executor, param0, method):
     from scipy.optimize import minimize
 
     def func(p):                                                         # beam_search.py:76-86
-        param = torch.tensor([p], dtype=torch.float, device=I0.device)
+        param = torch.tensor(np.asarray(p, dtype=np.float32)[None], device=I0.device)
         return get_dist(execute(I0, operation, param, executor), I1).item()
     res = minimize(func, param0.numpy(), method=method)
     return torch.tensor([list(res.x)], dtype=torch.float, device=I0.device), bool(res.success)
