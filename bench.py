@@ -306,8 +306,9 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=64)
-    ap.add_argument('--train-steps', type=int, default=0,
-                    help='also time this many full episode/L1 train steps (BASELINE configs[2]/[3]) -> "train_step"')
+    ap.add_argument('--train-steps', type=int, default=3,
+                    help='also time this many full episode/L1 train steps (BASELINE configs[2]/[3], with the flat '
+                         'gradient all-reduce when N > 1) -> "train_step"; 0 to skip')
     ap.add_argument('--train-warmup', type=int, default=2)
     args = ap.parse_args()
 
@@ -372,7 +373,10 @@ def main():
 
     train = None
     if args.train_steps > 0:
-        train = train_step_bench(device, dist, world, B, H, W, args.train_steps, args.train_warmup)
+        try:                                   # secondary measurement: never let it take the headline line down
+            train = train_step_bench(device, dist, world, B, H, W, args.train_steps, args.train_warmup)
+        except Exception as e:                 # noqa: BLE001
+            train = {'error': '%s: %s' % (type(e).__name__, e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
