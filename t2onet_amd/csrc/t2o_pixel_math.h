@@ -270,8 +270,78 @@ T2O_HD void argmaxmin(const Rgb& x, int& amax, int& amin, float& vmax, float& vm
   if (x.c[2] < vmin) { vmin = x.c[2]; amin = 2; }
 }
 
+// Exact autograd of the HSV round trip, used where channels tie (r == g, g == b, r == b): there
+// brightness / saturation are not differentiable and PyTorch's answer is the derivative of the
+// BRANCH the forward took (first-index max/min, the hue sector floor() picked).  The closed forms
+// below equal it everywhere else, at half the arithmetic.  sat = false: V = clamp(v (1+P)), S = s;
+// sat = true: V = v, S = clamp(s (1+P)).  out_c = V (1 - w_c S), w_c in {0, 1, f, 1-f} by sector.
+T2O_HD Rgb hsv_literal_bwd(bool sat, const Rgb& x, float P, const Rgb& g, float* red) {
+  const float r = x.c[0], gr = x.c[1], b = x.c[2];
+  float M = r; int a = 0;
+  if (gr > M) { M = gr; a = 1; }
+  if (b > M) { M = b; a = 2; }
+  float m = r; int im = 0;
+  if (gr < m) { m = gr; im = 1; }
+  if (b < m) { m = b; im = 2; }
+  const float delta = M - m;
+  const float ve = M + kHsvEps;
+  const float s = delta / ve;
+  const float ds = (delta == 0.0f) ? 1.0f : delta;
+  const float rc = M - r, gc = M - gr, bc = M - b;
+  const float hn = a == 0 ? (bc - gc) : a == 1 ? ((rc - bc) + 2.0f * ds) : ((gc - rc) + 4.0f * ds);
+  float h = hn / ds;
+  h = h / 6.0f;
+  h = h - truncf(h);
+  if (h < 0.0f) h += 1.0f;
+  const float H = kTwoPi * h;
+  const float h6 = (H / kTwoPi) * 6.0f;
+  const float hi = rem6(floorf(h6));
+  const float f = rem6(h6) - hi;
+  const int k = (int)hi;
+  // forward clamp of the scaled quantity
+  const float tq = (sat ? s : M) * (1.0f + P);
+  const bool in = tq >= 0.0f && tq <= 1.0f;
+  const float V = sat ? M : clamp01(tq);
+  const float S = sat ? clamp01(tq) : s;
+  // role of each output channel in sector k:  0 = v, 1 = p, 2 = q (w = f), 3 = t (w = 1 - f)
+  //            sector:   0  1  2  3  4  5
+  const int roleR = k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 1 : k == 3 ? 1 : k == 4 ? 3 : 0;
+  const int roleG = k == 0 ? 3 : k == 1 ? 0 : k == 2 ? 0 : k == 3 ? 2 : k == 4 ? 1 : 1;
+  const int roleB = k == 0 ? 1 : k == 1 ? 1 : k == 2 ? 3 : k == 3 ? 0 : k == 4 ? 0 : 2;
+  const int role[3] = {roleR, roleG, roleB};
+  float GV = 0.0f, GS = 0.0f, Gf = 0.0f;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    const float w = role[c] == 0 ? 0.0f : role[c] == 1 ? 1.0f : role[c] == 2 ? f : 1.0f - f;
+    const float sg = role[c] == 2 ? 1.0f : role[c] == 3 ? -1.0f : 0.0f;
+    GV += g.c[c] * (1.0f - w * S);
+    GS += g.c[c] * w;
+    Gf += g.c[c] * sg;
+  }
+  GS *= -V;
+  Gf *= -V * S;
+  float Gv, Gs;
+  if (sat) { Gv = GV; Gs = in ? GS * (1.0f + P) : 0.0f; red[0] += in ? GS * s : 0.0f; }
+  else     { Gv = in ? GV * (1.0f + P) : 0.0f; Gs = GS; red[0] += in ? GV * M : 0.0f; }
+  float Gd = Gs / ve;                         // d / d delta through s
+  Gv += -Gs * delta / (ve * ve);
+  const float Ghn = Gf / ds;
+  if (delta != 0.0f) Gd += -Gf * hn / (ds * ds) + (a == 1 ? 2.0f * Ghn : a == 2 ? 4.0f * Ghn : 0.0f);
+  Rgb gx;
+  gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
+  // hn = (g - b), (b - r) + 2 ds, (r - g) + 4 ds for argmax = r, g, b
+  add_at(gx, a == 0 ? 1 : a == 1 ? 2 : 0, Ghn);
+  add_at(gx, a == 0 ? 2 : a == 1 ? 0 : 1, -Ghn);
+  add_at(gx, a, Gd + Gv);
+  add_at(gx, im, -Gd);
+  return gx;
+}
+
+T2O_HD bool has_channel_tie(const Rgb& x) { return x.c[0] == x.c[1] || x.c[1] == x.c[2] || x.c[0] == x.c[2]; }
+
 // out_c = v' (x_c + eps) / (v + eps),  v' = clamp(v (1 + p), 0, 1)
 T2O_HD Rgb brightness_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
+  if (has_channel_tie(x)) return hsv_literal_bwd(false, x, p, g, red);
   int amax, amin; float v, mn;
   argmaxmin(x, amax, amin, v, mn);
   const float ve = v + kHsvEps;
@@ -284,14 +354,6 @@ T2O_HD Rgb brightness_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float S = g.c[0] * (x.c[0] + kHsvEps) + g.c[1] * (x.c[1] + kHsvEps) + g.c[2] * (x.c[2] + kHsvEps);
   Rgb gx;
   red[0] += S * da_dp;
-  if (v == mn) {
-    // grey pixel (r == g == b): s = 0, every output channel is v' and depends on the input only
-    // through max(), which PyTorch routes to the FIRST channel (argmax of equal values).
-    const float dv = (t < 0.0f || t > 1.0f) ? 0.0f : (1.0f + p);
-    gx.c[0] = (g.c[0] + g.c[1] + g.c[2]) * dv;
-    gx.c[1] = gx.c[2] = 0.0f;
-    return gx;
-  }
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) gx.c[c] = a * g.c[c];
   add_at(gx, amax, S * da_dv);
@@ -300,6 +362,7 @@ T2O_HD Rgb brightness_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
 
 // out_c = v (1 - s' (v - x_c) / delta),  s' = clamp(s (1 + p), 0, 1),  s = delta / (v + eps)
 T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
+  if (has_channel_tie(x)) return hsv_literal_bwd(true, x, p, g, red);
   int amax, amin; float v, mn;
   argmaxmin(x, amax, amin, v, mn);
   const float ve = v + kHsvEps;
@@ -311,10 +374,6 @@ T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float G = g.c[0] + g.c[1] + g.c[2];
   const float GU = g.c[0] * u0 + g.c[1] * u1 + g.c[2] * u2;
   Rgb gx;
-  if (delta == 0.0f) {                  // grey pixel: out = v on every channel, via max() only (first channel)
-    gx.c[0] = G; gx.c[1] = gx.c[2] = 0.0f;
-    return gx;
-  }
   if (t < 0.0f) {                       // s' = 0: every channel becomes v
     gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
     add_at(gx, amax, G);
