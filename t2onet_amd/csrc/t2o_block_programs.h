@@ -509,7 +509,7 @@ T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const
 // at a quarter of the arithmetic.
 constexpr int kMaxChain = 8;
 constexpr int kTabStride = 64;           // floats per operator in the LDS table
-constexpr int kTabK = 0, kTabP = 24, kTabSum = 51, kTabScale = 54;
+constexpr int kTabK = 0, kTabP = 24, kTabSum = 51, kTabScale = 54, kTabRsum = 57;
 constexpr int kAccStride = 65;           // floats per slot row of the LDS accumulators (64 quads + pad)
 
 struct ChainArgs {
@@ -551,7 +551,8 @@ T2O_HD void chain_build_table(const ChainArgs& a, int b, int k, float* tab) {
     t[kTabP + c * (kCurveSteps + 1) + kCurveSteps] = run;
     s = s + 1e-10f;
     t[kTabSum + c] = s;
-    t[kTabScale + c] = (1.0f / s) * (float)kCurveSteps;
+    t[kTabRsum + c] = 1.0f / s;
+    t[kTabScale + c] = t[kTabRsum + c] * (float)kCurveSteps;
   }
 }
 
@@ -568,7 +569,8 @@ T2O_HD float curve_lut_fwd(const float* t, bool color, int c, float x) {
   int i; float frac;
   curve_locate(x, i, frac);
   const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * t[kTabK + cc * kCurveSteps + i];
-  return color ? total * t[kTabScale + cc] : (total * (float)kCurveSteps) / t[kTabSum + cc];
+  return color ? total * t[kTabScale + cc]
+               : div_by(total * (float)kCurveSteps, t[kTabSum + cc], t[kTabRsum + cc]);
 }
 
 // forward of chain operator `op` on one pixel (pre-clamp); t = this operator's table row
@@ -891,7 +893,8 @@ T2O_HD void cand_build_table(const CandArgs& a, int cand, float* t) {
     t[kTabP + c * (kCurveSteps + 1) + kCurveSteps] = run;
     s = s + 1e-10f;
     t[kTabSum + c] = s;
-    t[kTabScale + c] = (1.0f / s) * (float)kCurveSteps;
+    t[kTabRsum + c] = 1.0f / s;
+    t[kTabScale + c] = t[kTabRsum + c] * (float)kCurveSteps;
   }
 }
 
