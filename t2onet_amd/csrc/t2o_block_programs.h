@@ -323,13 +323,35 @@ T2O_HD void tile_quad(const float* lds, int halo, int c, int r, int j, float (&q
   load_vec<4>(lds + c * tile_floats(halo) + (r + halo) * kRowStride + kIntOff + j, q);
 }
 
+// Left / right neighbours of an aligned quad.  The lanes of a 16-lane DPP row hold the 16 quads of
+// one tile row, so the neighbours are the adjacent lanes' end elements (one DPP move each); only
+// the first / last quad of the row reads the halo column from LDS.  (Reading both from LDS on every
+// lane is a stride-4 access: all 64 lanes on 8 banks.)  Host emulation reads LDS.
+struct Sides { float L, R; };
+T2O_HD Sides quad_sides(const float* lds, int halo, int c, int r, int j0, const float (&ce)[4]) {
+  Sides s;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ce[3]), 0x111, 0xF, 0xF, true));  // row_shr:1
+  const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ce[0]), 0x101, 0xF, 0xF, true)); // row_shl:1
+  // one LDS read per lane: the left halo column for the first quad, else the right one (a broadcast
+  // for the 15 lanes that do not need it)
+  const float e = tile_at(lds, halo, c, r, j0 == 0 ? -1 : kTileW);
+  s.L = j0 == 0 ? e : l;
+  s.R = j0 == kTileW - 4 ? e : rr;
+#else
+  s.L = tile_at(lds, halo, c, r, j0 - 1);
+  s.R = tile_at(lds, halo, c, r, j0 + 4);
+#endif
+  return s;
+}
+
 template <int V>
 T2O_HD float sharp_fwd_phase_compute(const OpArgs& a, int b, int tile, int tid, const float* lds) {
   int y0, x0;
   tile_origin(a, tile, y0, x0);
   const int ty = tid / (kTileW / 4), tx = tid % (kTileW / 4);
   const int gy = y0 + ty, gx0 = x0 + 4 * tx;
-  if (gy >= a.H || gx0 >= a.W) return 0.0f;
+  const bool live = gy < a.H && gx0 < a.W;     // every lane runs the DPP exchanges; only stores are predicated
   const float p = a.param[(size_t)b * a.param_stride];
   float l1 = 0.0f;
   T2O_UNROLL
@@ -338,15 +360,17 @@ T2O_HD float sharp_fwd_phase_compute(const OpArgs& a, int b, int tile, int tid, 
     tile_quad(lds, 1, c, ty - 1, 4 * tx, up);
     tile_quad(lds, 1, c, ty, 4 * tx, ce);
     tile_quad(lds, 1, c, ty + 1, 4 * tx, dn);
-    const float L = tile_at(lds, 1, c, ty, 4 * tx - 1), R = tile_at(lds, 1, c, ty, 4 * tx + 4);
+    const Sides sd = quad_sides(lds, 1, c, ty, 4 * tx, ce);
+    const float L = sd.L, R = sd.R;
     T2O_UNROLL
     for (int i = 0; i < 4; ++i) {
       const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
       const float d = sharp_delta(ce[i], up[i], left, right, dn[i]);
       float z = ce[i] + p * d;
-      if (a.mask_ch && gx0 + i < a.W) z = blend(z, ce[i], mask_at(a, b, c, (size_t)gy * a.W + gx0 + i));
+      if (a.mask_ch && live && gx0 + i < a.W) z = blend(z, ce[i], mask_at(a, b, c, (size_t)gy * a.W + gx0 + i));
       o[i] = clamp01(z);
     }
+    if (!live) continue;
     float* dst = a.out + plane_off(a, b, c) + (size_t)gy * a.W + gx0;
     const float* tg = a.target ? a.target + plane_off(a, b, c) + (size_t)gy * a.W + gx0 : nullptr;
     if (V == 4) {
@@ -390,49 +414,51 @@ T2O_HD void sharp_bwd_phase_load(const OpArgs& a, int b, int tile, int tid, floa
 // dz = [0 <= z <= 1] * gradient of the clamped output, zero outside the image; interior positions
 // also add do * Laplacian(x) (do = dz * m) to red0, the raw sum of d loss / d p.
 // One quad (4 columns) of one row of all 3 planes:
-T2O_HD void sharp_dz_quad(const OpArgs& a, float p, float gs, int y0, int x0, int r, int j0, int n, float* lds, float& red0) {
+T2O_HD void sharp_dz_quad(const OpArgs& a, float p, float gs, int y0, int x0, int c, int r, int j0, int n, float* lds,
+                          float& red0) {
   const float* X = lds + sharp_bwd_x_off();
   float* G = lds + sharp_bwd_g_off();
   const float* M = lds + sharp_bwd_m_off();
   const int gy = y0 + r;
   const bool interior = r >= 0 && r < kTileH && j0 >= 0 && j0 < kTileW;
-  T2O_UNROLL
-  for (int c = 0; c < 3; ++c) {
-    float up[4], ce[4], dn[4], gq[4], mq[4], dz[4];
-    if (n == 4) {
-      tile_quad(X, 2, c, r - 1, j0, up);
-      tile_quad(X, 2, c, r, j0, ce);
-      tile_quad(X, 2, c, r + 1, j0, dn);
-      tile_quad(G, 1, c, r, j0, gq);
-      if (a.mask_ch) tile_quad(M, 1, a.mask_ch == 3 ? c : 0, r, j0, mq);
-    } else {
-      up[0] = tile_at(X, 2, c, r - 1, j0); ce[0] = tile_at(X, 2, c, r, j0); dn[0] = tile_at(X, 2, c, r + 1, j0);
-      gq[0] = tile_at(G, 1, c, r, j0);
-      if (a.mask_ch) mq[0] = tile_at(M, 1, a.mask_ch == 3 ? c : 0, r, j0);
-    }
-    const float L = tile_at(X, 2, c, r, j0 - 1), R = tile_at(X, 2, c, r, j0 + n);
-    // an aligned quad (n == 4, W % 4 == 0) is entirely inside or outside the image
-    const bool row_in = gy >= 0 && gy < a.H;
-    const bool quad_in = row_in && x0 + j0 >= 0 && x0 + j0 < a.W;
-    T2O_UNROLL
-    for (int i = 0; i < 4; ++i) {
-      if (i < n) {
-        const bool in = n == 4 ? quad_in : (row_in && x0 + j0 + i >= 0 && x0 + j0 + i < a.W);
-        const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == n - 1 ? R : ce[i < 3 ? i + 1 : 3];
-        const float d = sharp_delta(ce[i], up[i], left, right, dn[i]);
-        const float m = a.mask_ch ? mq[i] : 1.0f;
-        float z = ce[i] + p * d;
-        if (a.mask_ch) z = blend(z, ce[i], m);
-        const float gz = a.target ? sign_of(clamp01(z) - gq[i]) * gs : gq[i];
-        dz[i] = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
-        if (interior) red0 += dz[i] * m * d;
-      }
-    }
-    float* dst = G + c * tile_floats(1) + (r + 1) * kRowStride + kIntOff + j0;
-    if (n == 4) store_vec<4>(dst, dz); else dst[0] = dz[0];
+  float up[4], ce[4], dn[4], gq[4], mq[4], dz[4];
+  if (n == 4) {
+    tile_quad(X, 2, c, r - 1, j0, up);
+    tile_quad(X, 2, c, r, j0, ce);
+    tile_quad(X, 2, c, r + 1, j0, dn);
+    tile_quad(G, 1, c, r, j0, gq);
+    if (a.mask_ch) tile_quad(M, 1, a.mask_ch == 3 ? c : 0, r, j0, mq);
+  } else {
+    up[0] = tile_at(X, 2, c, r - 1, j0); ce[0] = tile_at(X, 2, c, r, j0); dn[0] = tile_at(X, 2, c, r + 1, j0);
+    gq[0] = tile_at(G, 1, c, r, j0);
+    if (a.mask_ch) mq[0] = tile_at(M, 1, a.mask_ch == 3 ? c : 0, r, j0);
   }
+  float L, R;
+  if (n == 4) { const Sides sd = quad_sides(X, 2, c, r, j0, ce); L = sd.L; R = sd.R; }
+  else { L = tile_at(X, 2, c, r, j0 - 1); R = tile_at(X, 2, c, r, j0 + n); }
+  // an aligned quad (n == 4, W % 4 == 0) is entirely inside or outside the image
+  const bool row_in = gy >= 0 && gy < a.H;
+  const bool quad_in = row_in && x0 + j0 >= 0 && x0 + j0 < a.W;
+  T2O_UNROLL
+  for (int i = 0; i < 4; ++i) {
+    if (i < n) {
+      const bool in = n == 4 ? quad_in : (row_in && x0 + j0 + i >= 0 && x0 + j0 + i < a.W);
+      const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == n - 1 ? R : ce[i < 3 ? i + 1 : 3];
+      const float d = sharp_delta(ce[i], up[i], left, right, dn[i]);
+      const float m = a.mask_ch ? mq[i] : 1.0f;
+      float z = ce[i] + p * d;
+      if (a.mask_ch) z = blend(z, ce[i], m);
+      const float gz = a.target ? sign_of(clamp01(z) - gq[i]) * gs : gq[i];
+      dz[i] = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
+      if (interior) red0 += dz[i] * m * d;
+    }
+  }
+  float* dst = G + c * tile_floats(1) + (r + 1) * kRowStride + kIntOff + j0;
+  if (n == 4) store_vec<4>(dst, dz); else dst[0] = dz[0];
 }
 
+// Work items are (plane, row, quad): 3 x 18 x 16 = 864 aligned quads + 108 halo elements over 256
+// threads = 3.8 rounds at 95 % occupancy (whole pixels per item left the second round 87 % idle).
 template <int V>
 T2O_HD void sharp_bwd_phase_dz(const OpArgs& a, int b, int tile, int tid, float* lds, float& red0) {
   int y0, x0;
@@ -441,14 +467,21 @@ T2O_HD void sharp_bwd_phase_dz(const OpArgs& a, int b, int tile, int tid, float*
   const float gs = a.target ? a.gloss[0] * a.inv_n : 0.0f;
   const int rows = kTileH + 2;
   if (V == 4) {
-    for (int i = tid; i < rows * (kTileW / 4); i += kThreads)             // aligned quads of the 64 interior columns
-      sharp_dz_quad(a, p, gs, y0, x0, i / (kTileW / 4) - 1, 4 * (i % (kTileW / 4)), 4, lds, red0);
-    for (int i = tid; i < rows * 2; i += kThreads)                        // the two halo columns
-      sharp_dz_quad(a, p, gs, y0, x0, i / 2 - 1, (i % 2) ? kTileW : -1, 1, lds, red0);
+    const int per = rows * (kTileW / 4);
+    for (int i = tid; i < 3 * per; i += kThreads) {                       // aligned quads of the 64 interior columns
+      const int c = i / per, rem = i % per;
+      sharp_dz_quad(a, p, gs, y0, x0, c, rem / (kTileW / 4) - 1, 4 * (rem % (kTileW / 4)), 4, lds, red0);
+    }
+    for (int i = tid; i < 3 * rows * 2; i += kThreads) {                  // the two halo columns
+      const int c = i / (rows * 2), rem = i % (rows * 2);
+      sharp_dz_quad(a, p, gs, y0, x0, c, rem / 2 - 1, (rem % 2) ? kTileW : -1, 1, lds, red0);
+    }
   } else {
-    const int cols = kTileW + 2;
-    for (int i = tid; i < rows * cols; i += kThreads)
-      sharp_dz_quad(a, p, gs, y0, x0, i / cols - 1, i % cols - 1, 1, lds, red0);
+    const int cols = kTileW + 2, per = rows * cols;
+    for (int i = tid; i < 3 * per; i += kThreads) {
+      const int c = i / per, rem = i % per;
+      sharp_dz_quad(a, p, gs, y0, x0, c, rem / cols - 1, rem % cols - 1, 1, lds, red0);
+    }
   }
 }
 
@@ -459,7 +492,7 @@ T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const
   tile_origin(a, tile, y0, x0);
   const int ty = tid / (kTileW / 4), tx = tid % (kTileW / 4);
   const int gy = y0 + ty, gx0 = x0 + 4 * tx;
-  if (gy >= a.H || gx0 >= a.W || !a.gimg) return;
+  const bool live = gy < a.H && gx0 < a.W && a.gimg;
   const float p = a.param[(size_t)b * a.param_stride];
   const float* G = lds + sharp_bwd_g_off();
   const float* M = lds + sharp_bwd_m_off();
@@ -470,7 +503,8 @@ T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const
     tile_quad(G, 1, c, ty - 1, 4 * tx, up);
     tile_quad(G, 1, c, ty, 4 * tx, ce);
     tile_quad(G, 1, c, ty + 1, 4 * tx, dn);
-    float L = tile_at(G, 1, c, ty, 4 * tx - 1), R = tile_at(G, 1, c, ty, 4 * tx + 4);
+    const Sides sg = quad_sides(G, 1, c, ty, 4 * tx, ce);
+    float L = sg.L, R = sg.R;
     T2O_UNROLL
     for (int i = 0; i < 4; ++i) pass[i] = 0.0f;
     if (a.mask_ch) {
@@ -478,8 +512,9 @@ T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const
       tile_quad(M, 1, mc, ty - 1, 4 * tx, mu);
       tile_quad(M, 1, mc, ty, 4 * tx, mcq);
       tile_quad(M, 1, mc, ty + 1, 4 * tx, md);
-      L *= tile_at(M, 1, mc, ty, 4 * tx - 1);
-      R *= tile_at(M, 1, mc, ty, 4 * tx + 4);
+      const Sides sm = quad_sides(M, 1, mc, ty, 4 * tx, mcq);
+      L *= sm.L;
+      R *= sm.R;
       T2O_UNROLL
       for (int i = 0; i < 4; ++i) {
         pass[i] = ce[i] * (1.0f - mcq[i]);
@@ -491,6 +526,7 @@ T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const
       const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
       o[i] = pass[i] + (ce[i] + p * sharp_delta(ce[i], up[i], left, right, dn[i]));
     }
+    if (!live) continue;
     float* dst = a.gimg + plane_off(a, b, c) + (size_t)gy * a.W + gx0;
     if (V == 4) store_vec<4>(dst, o);
     else for (int i = 0; i < 4 && gx0 + i < a.W; ++i) dst[i] = o[i];

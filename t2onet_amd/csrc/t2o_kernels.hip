@@ -322,15 +322,16 @@ __global__ __launch_bounds__(kThreads) void k_finalize_params_multi(MultiFinaliz
   if ((int)threadIdx.x >= np && (int)threadIdx.x < kMaxParam) grow[threadIdx.x] = 0.0f;
 }
 
-// loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order)
+// loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order): lane = block row
+// index within a sample, wave = sample index (stride 4): no integer division in the loop
 __global__ __launch_bounds__(kThreads) void k_finalize_loss(OpArgs a, float* loss, int nblk_point, int nblk_sharp) {
   float acc = 0.0f;
-  const int total = a.B * a.nblk_max;
-  for (int i = threadIdx.x; i < total; i += kThreads) {
-    const int b = i / a.nblk_max, k = i - b * a.nblk_max;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < a.B; b += kThreads / 64) {
     const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
     const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
-    if (k < nb) acc += a.loss_partials[i];
+    const float* row = a.loss_partials + (size_t)b * a.nblk_max;
+    for (int k = lane; k < nb; k += 64) acc += row[k];
   }
   __shared__ float out1;
   block_reduce_store1(acc, &out1);
