@@ -26,10 +26,22 @@ int fail(int code, const char* msg) {
 }
 
 // ------------------------------------------------------------------ device helpers
+// Sum over the 64 lanes, returned in every lane.  Pure VALU: an inclusive scan inside each 16-lane
+// row by DPP row shifts (1, 2, 4, 8), row_bcast:15 / row_bcast:31 to fold the four rows, then a
+// broadcast of lane 63 -- 6 DPP adds instead of 6 LDS-crossbar shuffles (ds_bpermute).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(float, moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_shift_add<0x111, 0xF>(v);   // row_shr:1
+  v = dpp_shift_add<0x112, 0xF>(v);   // row_shr:2
+  v = dpp_shift_add<0x114, 0xF>(v);   // row_shr:4
+  v = dpp_shift_add<0x118, 0xF>(v);   // row_shr:8   -> lane 15 of every row holds the row sum
+  v = dpp_shift_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_shift_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -327,12 +339,20 @@ __global__ __launch_bounds__(kThreads) void k_finalize_params_multi(MultiFinaliz
 __global__ __launch_bounds__(kThreads) void k_finalize_loss(OpArgs a, float* loss, int nblk_point, int nblk_sharp) {
   float acc = 0.0f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = wave; b < a.B; b += kThreads / 64) {
-    const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
-    const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
-    const float* row = a.loss_partials + (size_t)b * a.nblk_max;
-    for (int k = lane; k < nb; k += 64) acc += row[k];
+  float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};     // four samples in flight per wave: the loads overlap
+  for (int b0 = wave * 4; b0 < a.B; b0 += kThreads / 64 * 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = b0 + j;
+      if (b < a.B) {
+        const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
+        const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
+        const float* row = a.loss_partials + (size_t)b * a.nblk_max;
+        for (int k = lane; k < nb; k += 64) acc4[j] += row[k];
+      }
+    }
   }
+  acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   __shared__ float out1;
   block_reduce_store1(acc, &out1);
   __syncthreads();
