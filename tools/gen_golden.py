@@ -270,6 +270,47 @@ def gen_ssim():
     print('ssim.npz')
 
 
+def synthetic_records():
+    """Planner records covering truncation, curve normalisation and the |p| > 5 outlier rule."""
+    recs = []
+    for seed in range(8):
+        n = 2 + seed % 5
+        names = ['brightness', 'tone', 'contrast', 'color', 'saturation', 'sharpness'][seed % 3:][:n]
+        d = 0.2
+        seq = []
+        for i, name in enumerate(names):
+            drop = [0.05, 0.03, 0.0015, 0.02, 0.0, 0.01][(i + seed) % 6]
+            d = d - drop
+            k = {'color': 24, 'tone': 8}.get(name, 1)
+            vals = (synth.uniform((k,), 500 + 10 * seed + i, -2.0, 2.0) * (4.0 if (seed + i) % 4 == 0 else 1.0)).tolist()
+            seq.append([name, vals, d])
+        recs.append({'init distance': 0.2, 'operation sequence': [seq]})
+    return recs
+
+
+def gen_data():
+    """FiveKAct.get_act's record logic (datasets/FiveKdataset.py:86-116) on synthetic records; the
+    reference method is called with its image loader stubbed out (no image files here)."""
+    import datasets.FiveKdataset as ds
+    import json
+    ds.load_train_img = lambda path, size: torch.zeros(3, size, size)
+    obj = ds.FiveKAct.__new__(ds.FiveKAct)
+    obj.op_max_len, obj.train_img_size, obj.phase = 5, 8, 'train'
+    obj.actions = ['brightness', 'contrast', 'saturation', 'color', 'inpaint', 'tone', 'sharpness', 'white']
+    obj.act2pn = {'brightness': 1, 'contrast': 1, 'saturation': 1, 'color': 24, 'inpaint': 0, 'tone': 8, 'sharpness': 1, 'white': 0}
+    d = tempfile.mkdtemp(prefix='t2o_act_')
+    obj.act_dir = d
+    g = {}
+    for i, rec in enumerate(synthetic_records()):
+        os.makedirs(os.path.join(d, 'train%d' % i))
+        json.dump(rec, open(os.path.join(d, 'train%d' % i, '%05d.json' % i), 'w'))
+        ops, params, imgs = obj.get_act(i)
+        g['ops%d' % i], g['params%d' % i] = np.asarray(ops), np.asarray(params)
+        g['trunc%d' % i] = np.array(ds.analyze_traj([rec['init distance']] + [v[2] for v in rec['operation sequence'][0]]))
+    np.savez_compressed(os.path.join(OUT, 'data.npz'), **g)
+    print('data.npz: %d arrays' % len(g))
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'run in the build container (needs /root/reference)'
     os.makedirs(OUT, exist_ok=True)
@@ -278,6 +319,10 @@ if __name__ == '__main__':
     enter_workdir()
     torch.set_num_threads(4)
     opt = reference_opt()
+    if len(sys.argv) > 1 and sys.argv[1] == 'data':
+        gen_data()
+        sys.exit(0)
     gen_operators(opt)
     gen_ssim()
     gen_actor(opt)
+    gen_data()
