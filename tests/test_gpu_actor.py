@@ -140,3 +140,17 @@ def test_evaluation_loop_full_resolution():
     init_d, d = evaluate(model, batches, opt, is_test=True, verbose=False)
     ref_init = float(np.mean([(a - b).abs().mean().item() for a, b, _, _ in batches]))
     assert abs(init_d - ref_init) < 1e-6 and 0.0 <= d <= 1.0
+
+
+def test_train_cli_runs_and_checkpoints(tmp_path):
+    """Four iterations of the reference-shaped loop on synthetic FiveK batches; the checkpoint has the
+    reference's 199-tensor layout and reloads."""
+    from t2onet_amd import train_cli, default_options
+    from t2onet_amd.actor import Actor
+    avg = train_cli.main(['--synthetic', '--batch_size', '4', '--img_size', '64', '--num_iters', '4', '--print_every', '2',
+                          '--checkpoint_every', '4', '--run_dir', str(tmp_path), '--num_workers', '0'])
+    assert avg['fs_t'] > 0 and avg['l1_t'] > 0
+    path = tmp_path / 'seq2seqL1_model' / 'checkpoint_iter00000004' / 'model.pth'
+    sd = torch.load(str(path))
+    assert len(sd) == 199
+    Actor(default_options()).load_state_dict(sd)
