@@ -1,6 +1,14 @@
-"""One-step attention LSTM decoder (models/action_decoder.py:9-78): same module names, so the
-reference's state_dict loads.  The LSTM / Linear GEMMs run on MIOpen / hipBLASLt through
-PyTorch-ROCm (MFMA); the attention core is the HIP kernel in attention.py."""
+"""Operator decoder of the actor: one decoding step at a time.
+
+Counterpart of models/action_decoder.py:9-78.  What has to stay for checkpoints and callers:
+the sub-module names (`embedding`, `rnn`, `out_linear`, `vis_linear`, `attention`,
+`input_dropout`) and the two entry points `forward_step` / `_init_state`.
+
+Per step:  [operator embedding (300) | relu(vis_linear(image feature)) (512)]  ->  2-layer LSTM
+(812 -> 512)  ->  dot-product attention over the request encoding (HIP kernel, attention.py)
+->  out_linear  ->  log-softmax over the 11 operator tokens.  The LSTM and the Linear layers are
+library GEMMs (MIOpen / hipBLASLt through PyTorch-ROCm).
+"""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -8,46 +16,50 @@ import torch.nn.functional as F
 from .attention import Attention
 
 
+def merge_directions(state):
+    """(layers*2, B, h) bidirectional encoder state -> (layers, B, 2h): forward and backward halves of
+    each layer side by side (action_decoder.py:75-78)."""
+    fwd, bwd = state[0::2], state[1::2]
+    return torch.cat((fwd, bwd), dim=2)
+
+
 class Decoder(nn.Module):
     def __init__(self, vocab_size, max_len, word_vec_dim, hidden_size, n_layers, rnn_type='lstm',
                  bidirectional=False, input_dropout_p=0, dropout_p=0, use_attention=False):
         super().__init__()
-        self.max_length = max_len
-        self.output_size = vocab_size
-        self.hidden_size = hidden_size * 2 if bidirectional else hidden_size
-        self.word_vec_dim = word_vec_dim
-        self.bidirectional_encoder = bidirectional
-        self.use_attention = use_attention
-        self.embedding = nn.Embedding(self.output_size, self.word_vec_dim)
-        self.rnn = getattr(nn, rnn_type.upper())(self.word_vec_dim + self.hidden_size, self.hidden_size, n_layers,
-                                                 batch_first=True, dropout=dropout_p)
-        self.out_linear = nn.Linear(self.hidden_size, self.output_size)
-        self.vis_linear = nn.Linear(self.hidden_size, self.hidden_size)
+        width = 2 * hidden_size if bidirectional else hidden_size      # the encoder's output width
+        self.max_length, self.output_size, self.word_vec_dim = max_len, vocab_size, word_vec_dim
+        self.hidden_size, self.bidirectional_encoder, self.use_attention = width, bidirectional, use_attention
+        rnn_cls = {'lstm': nn.LSTM, 'gru': nn.GRU}[rnn_type.lower()]
+        self.embedding = nn.Embedding(vocab_size, word_vec_dim)
+        self.rnn = rnn_cls(word_vec_dim + width, width, n_layers, batch_first=True, dropout=dropout_p)
+        self.out_linear = nn.Linear(width, vocab_size)
+        self.vis_linear = nn.Linear(width, width)
         if use_attention:
-            self.attention = Attention(self.hidden_size)
+            self.attention = Attention(width)
         self.input_dropout = nn.Dropout(p=input_dropout_p)
 
     def forward_step(self, input_var, hidden, encoder_outputs, img_feat):
-        """input_var (B,1) previous operator id -> (log-probs (B,1,n_cls), hidden, attn (B,1,L), context (B,d))."""
-        B = input_var.size(0)
-        vis_feat = F.relu(self.vis_linear(img_feat))
-        embedded = torch.cat((self.embedding(input_var), vis_feat.view(B, 1, -1)), 2)
-        embedded = self.input_dropout(embedded)
-        context, hidden = self.rnn(embedded, hidden)
+        """input_var (B,1) previous operator token, hidden LSTM state, encoder_outputs (B,L,d),
+        img_feat (B,d).  Returns (log-probabilities (B,1,n_tokens), new hidden, attention (B,1,L) or
+        None, context (B,d))."""
+        n = input_var.shape[0]
+        token = self.embedding(input_var)                                   # (B,1,300)
+        visual = F.relu(self.vis_linear(img_feat)).unsqueeze(1)            # (B,1,d)
+        step_in = self.input_dropout(torch.cat((token, visual), dim=2))
+        context, hidden = self.rnn(step_in, hidden)
         attn = None
         if self.use_attention:
             context, attn = self.attention(context, encoder_outputs)
-        logits = self.out_linear(context.contiguous().view(-1, self.hidden_size))
-        return F.log_softmax(logits.view(B, 1, -1), -1), hidden, attn, context.squeeze(1)
+        scores = self.out_linear(context.reshape(n, self.hidden_size))
+        return F.log_softmax(scores, dim=-1).view(n, 1, -1), hidden, attn, context.squeeze(1)
 
     def _init_state(self, encoder_hidden):
+        """Encoder final state -> decoder initial state."""
         if encoder_hidden is None:
             return None
+        if not self.bidirectional_encoder:
+            return encoder_hidden
         if isinstance(encoder_hidden, tuple):
-            return tuple(self._cat_directions(h) for h in encoder_hidden)
-        return self._cat_directions(encoder_hidden)
-
-    def _cat_directions(self, h):
-        if self.bidirectional_encoder:                       # (2L,B,h) -> (L,B,2h)
-            h = torch.cat([h[0:h.size(0):2], h[1:h.size(0):2]], 2)
-        return h
+            return tuple(merge_directions(s) for s in encoder_hidden)
+        return merge_directions(encoder_hidden)
