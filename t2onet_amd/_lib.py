@@ -53,6 +53,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:                                   # (re)build when the sources changed and hipcc is here; never required
+        from . import build as _build
+        if os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+            _build.build()
+    except Exception:                      # noqa: BLE001 -- fall through to the existence check below
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             'libt2onet_hip.so not found at %s: build it with `python -m t2onet_amd.build` '
