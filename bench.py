@@ -177,6 +177,40 @@ class FusedRunner(SequenceRunner):
             self._p(self.gimg), self._p(self.gparams), None, None, self._p(self.ws), wsn, B, H, W, st))
 
 
+def api_path_bench(B, H, W, device, steps, warmup):
+    """The same step through the drop-in Python surface: six Executor.execute calls + l1_loss +
+    torch autograd backward (ctypes calls into the C ABI from autograd Functions)."""
+    import t2onet_amd
+    import t2onet_amd.functional as T
+    ex = t2onet_amd.Executor(t2onet_amd.default_options()).to(device)
+    img, tgt, params = make_inputs(B, H, W, device)
+    x = img.clone().requires_grad_(True)
+    ps = [params[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
+
+    def step():
+        x.grad = None
+        for p in ps:
+            p.grad = None
+        cur = x
+        for op, p in zip(OPS, ps):
+            cur, _ = ex.execute(cur, op, None, specified_param=p)
+        loss = T.l1_loss(cur, tgt)
+        loss.backward()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'what': 'six Executor.execute calls + l1_loss + autograd backward (Python API path)',
+            'value': round(B * steps / dt, 1), 'unit': 'images/sec', 'ms_per_step': round(dt / steps * 1e3, 4),
+            'loss': float(loss.item())}
+
+
 def algorithmic_bytes(name, P):
     """operator forward 24 B/pixel, backward 36 B/pixel, +12 B/pixel (target)
     for the forward fused with the L1 loss (its backward reads the target instead of gout).
@@ -371,6 +405,13 @@ def main():
     total_bytes = (6 * 60 + 12) * P                      # K*60*P + 12*P
     sum_ms = sum(k['ms'] for k in kernels.values())
 
+    api = None
+    try:
+        api = api_path_bench(B, H, W, device, args.steps, args.warmup)
+    except Exception as e:                     # noqa: BLE001
+        api = {'error': '%s: %s' % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
+
     train = None
     if args.train_steps > 0:
         try:                                   # secondary measurement: never let it take the headline line down
@@ -418,6 +459,8 @@ def main():
                 'frac_of_peak': round(total_bytes / (mat_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                 'loss': mat_loss, 'kernels': mat_kernels},
         }
+        if api is not None:
+            line['executor_api_path'] = api
         if train is not None:
             line['train_step'] = train
         if not args.no_cpu_baseline and n_gpus == 1:

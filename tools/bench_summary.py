@@ -15,3 +15,5 @@ if 'cpu_baseline' in d:
     print(' cpu:', d['cpu_baseline'])
 if 'train_step' in d:
     print(' train:', d['train_step'])
+if 'executor_api_path' in d:
+    print(' api path:', d['executor_api_path'])

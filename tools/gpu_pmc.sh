@@ -11,4 +11,7 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
 timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/sq2 -- $CMD > $OUT/sq2.log 2>&1; echo "sq2 rc=$?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1; echo "fetch rc=$?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1; echo "write rc=$?"
-python tools/pmc_summary.py $OUT
+python tools/pmc_summary.py $OUT > $OUT/summary.txt
+# raw per-dispatch CSVs are tens of MB: keep only the per-kernel summary (gpurun merges <= 64 MiB)
+rm -rf $OUT/sq $OUT/sq2 $OUT/fetch $OUT/write
+tail -n 3 $OUT/summary.txt
