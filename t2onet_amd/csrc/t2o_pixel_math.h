@@ -444,7 +444,7 @@ T2O_HD float curve_bwd_1(const float k[kCurveSteps], float scale, float xin, flo
     const float d = x - (float)i / kCurveSteps;
     const float t = fminf(fmaxf(d, 0.0f), 1.0f / kCurveSteps);
     red[i] += g * t;
-    slope += (d >= 0.0f && d <= 1.0f / kCurveSteps) ? k[i] : 0.0f;
+    slope += (t == d) ? k[i] : 0.0f;        // clamp(d) == d  <=>  0 <= d <= 1/8 (inclusive, as PyTorch's clamp backward)
   }
   return g * scale * slope;
 }
