@@ -77,6 +77,23 @@ class Actor(nn.Module):
             img = img.contiguous(memory_format=torch.channels_last)
         return F.relu(self.bn1(self.vis_encoder(img)))                 # actor.py:142-143, :215-216
 
+    def get_gt_mask(self, img, mask_dict, op):
+        """Per-sample local-edit masks (actor.py:78-98): mask_dict[i] maps an operator id (as a
+        string) to a list whose first entry is that sample's mask array; samples without an entry
+        for the chosen operator get an all-ones mask (global edit).  op: (B,1) host array.
+        Returns (B,3,H,W) on the image's device."""
+        masks = []
+        for i in range(len(mask_dict)):
+            entry = mask_dict[i].get(str(op[i][0]))
+            mask = None
+            if entry is not None:
+                try:
+                    mask = torch.as_tensor(entry[0], dtype=img.dtype).to(img.device).expand_as(img[i])
+                except (RuntimeError, TypeError, IndexError):
+                    mask = None
+            masks.append(torch.ones_like(img[i]) if mask is None else mask)
+        return torch.stack(masks, dim=0)
+
     def divide_op_group(self, ops):
         """Kept for API compatibility (actor.py:100-114); the forward passes do not use it."""
         unqs = torch.unique(ops)
@@ -114,8 +131,6 @@ class Actor(nn.Module):
     # ------------------------------------------------------------------ free running
     def episode_forward(self, x, img_x, mask_dict, reinforce_sample=1, lengths=None):
         """actor.py:184-284.  Returns (state, pred_imgs (B,T,3,H,W), pred_ops (B,T), pred_params list of T (B,24))."""
-        if mask_dict is not None:
-            raise NotImplementedError('local-edit masks belong to the GIER path (SURVEY.md 8(f) rank 4)')
         B = x.shape[0]
         dev = img_x.device
         enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
@@ -123,7 +138,7 @@ class Actor(nn.Module):
         hiddens = [tuple(h.detach() for h in hidden)]
         op_mask = torch.tensor(OP_MASK, dtype=torch.float, device=dev).repeat(B, 1)
         pred_op = torch.full((B, 1), self.start_id, dtype=torch.long, device=dev)
-        pred_ops, pred_params, pred_imgs = [], [], []
+        pred_ops, pred_params, pred_imgs, pred_masks = [], [], [], []
         for _ in range(self.opt.decoder_max_len):
             feat = self.image_features(img_x)
             logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
@@ -137,7 +152,11 @@ class Actor(nn.Module):
             else:
                 pred_op = probs.topk(1)[1].view(B, -1)
             op_mask.scatter_(1, pred_op, 0.0)              # an operator is used at most once
-            img_x, par = self._execute(img_x, pred_op, context)
+            pred_mask = None
+            if mask_dict is not None:                      # local edits (GIER): one host sync per step, as the reference
+                pred_mask = self.get_gt_mask(img_x, mask_dict, pred_op.detach().cpu().numpy())
+                pred_masks.append(pred_mask)
+            img_x, par = self._execute(img_x, pred_op, context, pred_mask)
             pred_imgs.append(img_x)
             pred_params.append(par)
             pred_ops.append(pred_op.squeeze(-1))
@@ -146,14 +165,12 @@ class Actor(nn.Module):
         pred_ops = torch.stack(pred_ops, 1)
         pred_imgs = torch.stack(pred_imgs, 1)
         state = {'reqs': x, 'imgs': pred_imgs.detach(), 'ops': pred_ops, 'param': pred_params,
-                 'hidden': hiddens, 'masks': None}
+                 'hidden': hiddens, 'masks': torch.stack(pred_masks, 1) if pred_masks else None}
         return state, pred_imgs, pred_ops, pred_params
 
     # ------------------------------------------------------------------ single RL step (no caller in the reference)
     def forward(self, x, img_x, hidden, op, mask_dict=None, lengths=None):
         """actor.py:286-354."""
-        if mask_dict is not None:
-            raise NotImplementedError('local-edit masks belong to the GIER path')
         op = op.view(-1, 1)
         B = img_x.shape[0]
         with torch.no_grad():
@@ -165,7 +182,8 @@ class Actor(nn.Module):
         probs = probs * op_mask
         probs = probs / (probs.sum(1, keepdim=True) + 1e-30)
         pred_op = torch.distributions.Categorical(probs=probs).sample().view(B, -1)
-        pred_img, _ = self._execute(img_x, pred_op, context)
+        pred_mask = self.get_gt_mask(img_x, mask_dict, pred_op.detach().cpu().numpy()) if mask_dict is not None else None
+        pred_img, _ = self._execute(img_x, pred_op, context, pred_mask)
         _, _, _, next_context = self.decoder.forward_step(pred_op, dec_hidden, enc_out, self.image_features(pred_img))
         return pred_img, logp, entropy_penalty, context, next_context
 

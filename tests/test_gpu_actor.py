@@ -154,3 +154,29 @@ def test_train_cli_runs_and_checkpoints(tmp_path):
     sd = torch.load(str(path))
     assert len(sd) == 199
     Actor(default_options()).load_state_dict(sd)
+
+
+def test_episode_with_local_edit_masks():
+    """mask_dict path (actor.py:78-98, :238-239): samples with a mask for the chosen operator are
+    edited only inside it; others globally.  Checked against the unmasked run and the blend identity."""
+    dev = torch.device('cuda:0')
+    model, opt = make_model(dev)
+    model.eval()
+    x = synth.requests(B, L, 41).to(dev)
+    img = synth.images(B, H, W, 42).to(dev)
+    with torch.no_grad():
+        _, imgs0, ops0, _ = model.episode_forward(x, img, None, reinforce_sample=0)
+        first = ops0[:, 0].tolist()
+        box = np.zeros((1, H, W), np.float32)
+        box[:, 16:48, 16:48] = 1.0
+        # sample 0 and 2 carry a mask for their first chosen operator; 1 and 3 do not
+        mask_dict = [{str(first[0]): [box]}, {}, {str(first[2]): [box]}, {}]
+        state, imgs1, ops1, _ = model.episode_forward(x, img, mask_dict, reinforce_sample=0)
+    assert state['masks'].shape == (B, 5, 3, H, W)
+    assert torch.equal(ops1[:, 0], ops0[:, 0])
+    m = torch.from_numpy(box).to(dev)
+    for b in (0, 2):                      # masked: inside = the global edit, outside = the input (clamped blend)
+        want = (imgs0[b, 0] * m + img[b] * (1 - m)).clamp(0, 1)
+        assert torch.allclose(imgs1[b, 0], want, atol=1e-6)
+    for b in (1, 3):
+        assert torch.equal(imgs1[b, 0], imgs0[b, 0])
