@@ -274,9 +274,30 @@ def cpu_baseline(B_sample, H, W, reps=7):
         ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
-    return {'value': B_sample / med, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'oracle/cpu_ref.py eager fp32, same 6-op sequence fwd+L1+bwd, bs=%d %dx%d, median of %d reps '
-                      '(%.2f s each)' % (B_sample, H, W, reps, med)}
+    res = {'value': B_sample / med, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': 'oracle/cpu_ref.py eager fp32, same 6-op sequence fwd+L1+bwd, bs=%d %dx%d, median of %d reps '
+                     '(%.2f s each)' % (B_sample, H, W, reps, med)}
+    # parity gate reported with the number: the GPU paths against the oracle on the first 4 images
+    try:
+        import t2onet_amd
+        n = min(4, B_sample)
+        x = img[:n].clone().requires_grad_(True)
+        ps = [params[k, :n, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
+        ref, _ = cpu_ref.run_sequence(x, OPS, ps, opt)
+        ref_loss = cpu_ref.l1_loss(ref, tgt[:n])
+        ref_loss.backward()
+        ex = t2onet_amd.Executor(t2onet_amd.default_options()).cuda()
+        xg = img[:n].cuda().requires_grad_(True)
+        pg = params[:, :n].cuda().requires_grad_(True)
+        loss, out = ex.run_sequence_fused(xg, OPS, pg, tgt[:n].cuda())
+        loss.backward()
+        gerr = (xg.grad.cpu() - x.grad).abs().max().item() / max(x.grad.abs().max().item(), 1e-30)
+        res['parity'] = {'images': n, 'fwd_max_abs_err': (out.detach().cpu() - ref.detach()).abs().max().item(),
+                         'loss_abs_dev': abs(loss.item() - ref_loss.item()),
+                         'gimg_max_err_rel_to_max': gerr, 'tolerance': 1e-5}
+    except Exception as e:                     # noqa: BLE001
+        res['parity'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return res
 
 
 def train_step_bench(device, dist, world, B, H, W, steps, warmup):
