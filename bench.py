@@ -254,19 +254,29 @@ def cpu_baseline(B_sample, H, W, reps=7):
         cpu_ref.l1_loss(out, tgt).backward()
 
     # eager ATen ops on 50 MB tensors do not scale to every core of a big host (256 threads ran
-    # 50x slower than 32 on the first MI355X node): pick the fastest thread count on a short probe
+    # 50x slower than 32 on the first MI355X node): pick the thread count on a short bs=8 probe
     ncpu = os.cpu_count() or 1
+    pimg, ptgt, pparams = img[:8], tgt[:8], params[:, :8]
+
+    def probe():
+        x = pimg.clone().requires_grad_(True)
+        ps = [pparams[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
+        out, _ = cpu_ref.run_sequence(x, OPS, ps, opt)
+        cpu_ref.l1_loss(out, ptgt).backward()
+
     best = None
     for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
         torch.set_num_threads(nt)
+        probe()
         t0 = time.perf_counter()
-        once()
+        probe()
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, nt)
-        if dt > 20.0:
-            break
+        elif dt > 1.5 * best[0]:
+            break                                   # past the knee: more threads only get slower
     torch.set_num_threads(best[1])
+    once()                                          # warm-up at the chosen thread count
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
