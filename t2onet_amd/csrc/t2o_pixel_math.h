@@ -132,10 +132,10 @@ T2O_HD Hsv rgb_to_hsv(float r, float g, float b) {
   o.s = delta / (maxc + kHsvEps);
   const float ds = (delta == 0.0f) ? 1.0f : delta;
   const float rc = maxc - r, gc = maxc - g, bc = maxc - b;
-  float hn;
-  if (arg == 0) hn = bc - gc;
-  else if (arg == 1) hn = (rc - bc) + 2.0f * ds;
-  else hn = (gc - rc) + 4.0f * ds;
+  // all three candidates, then two selects: no divergent branches
+  // (T2O_OPAQUE pins each candidate where it is: otherwise hipcc sinks them back into a branch tree)
+  const float hn0 = T2O_OPAQUE(bc - gc), hn1 = T2O_OPAQUE((rc - bc) + 2.0f * ds), hn2 = T2O_OPAQUE((gc - rc) + 4.0f * ds);
+  const float hn = arg == 0 ? hn0 : (arg == 1 ? hn1 : hn2);
   float h = hn / ds;
   h = div_by(h, 6.0f, kSixth);
   h = h - truncf(h);            // fmod(h, 1)
@@ -149,15 +149,22 @@ T2O_HD Rgb hsv_to_rgb(float H, float s, float v) {
   const float h6 = h * 6.0f;
   const float hi = rem6(floorf(h6));
   const float f = rem6(h6) - hi;
-  const float p = v * (1.0f - s);
-  const float q = v * (1.0f - f * s);
-  const float t = v * (1.0f - (1.0f - f) * s);
+  // out_c = v (1 - w_c s) with w_c = 0 (the "v" role), 1 ("p"), f ("q") or 1 - f ("t"): the same products
+  // as the reference's p, q, t (1*s and 0*s are exact), chosen per channel by its phase
+  // j = (sector - 2c) mod 6 -> w = {0, f, 1, 1, 1 - f, 0}[j]; selects only, no branch tree
   const int k = (int)hi;
+  const float fq = T2O_OPAQUE(f), omf = T2O_OPAQUE(1.0f - f);
   Rgb o;
-  //                 sector 0        1        2        3        4        5
-  o.c[0] = k == 0 ? v : k == 1 ? q : k == 2 ? p : k == 3 ? p : k == 4 ? t : v;
-  o.c[1] = k == 0 ? t : k == 1 ? v : k == 2 ? v : k == 3 ? q : k == 4 ? p : p;
-  o.c[2] = k == 0 ? p : k == 1 ? p : k == 2 ? t : k == 3 ? v : k == 4 ? v : q;
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    int j = k - 2 * c;
+    j += (j < 0) ? 6 : 0;
+    // 0/1 masks and exact arithmetic (exactly one term is non-zero) instead of a ternary chain,
+    // which hipcc turns into a divergent branch tree
+    const float m1 = (j == 1) ? 1.0f : 0.0f, m4 = (j == 4) ? 1.0f : 0.0f, m23 = ((j & ~1) == 2) ? 1.0f : 0.0f;
+    const float w = m1 * fq + (m4 * omf + m23);
+    o.c[c] = v * (1.0f - w * s);
+  }
   return o;
 }
 
@@ -363,11 +370,13 @@ T2O_HD Rgb brightness_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   argmaxmin(x, amax, amin, v, mn);
   const float ve = v + kHsvEps;
   const float t = v * (1.0f + p);
-  float a, da_dv, da_dp;
-  const float rve = T2O_FDIV(1.0f, ve);
-  if (t < 0.0f)      { a = 0.0f; da_dv = 0.0f; da_dp = 0.0f; }
-  else if (t > 1.0f) { a = rve; da_dv = -a * rve; da_dp = 0.0f; }
-  else               { a = t * rve; da_dv = (1.0f + p) * kHsvEps * rve * rve; da_dp = v * rve; }
+  // three clamp regimes (t < 0: v' = 0;  t > 1: v' = 1;  else v' = t) blended with 0/1 masks: no branches
+  const float m_hi = t > 1.0f ? 1.0f : 0.0f;
+  const float m_in = (t >= 0.0f && t <= 1.0f) ? 1.0f : 0.0f;
+  const float rve = T2O_FDIV(1.0f, ve > 0.5f * kHsvEps ? ve : 1.0f);   // inputs below 0 only occur in the t < 0 regime
+  const float a = m_in * (t * rve) + m_hi * rve;
+  const float da_dv = m_in * ((1.0f + p) * kHsvEps * rve * rve) - m_hi * (rve * rve);
+  const float da_dp = m_in * (v * rve);
   const float S = g.c[0] * (x.c[0] + kHsvEps) + g.c[1] * (x.c[1] + kHsvEps) + g.c[2] * (x.c[2] + kHsvEps);
   Rgb gx;
   red[0] += S * da_dp;
@@ -383,31 +392,28 @@ T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   int amax, amin; float v, mn;
   argmaxmin(x, amax, amin, v, mn);
   const float ve = v + kHsvEps;
-  const float delta = v - mn;
-  const float rve = T2O_FDIV(1.0f, ve);
+  const float delta = v - mn;                  // > 0: no two channels are equal here
+  const float rve = T2O_FDIV(1.0f, ve > 0.5f * kHsvEps ? ve : 1.0f);
+  const float rd = T2O_FDIV(1.0f, delta);
   const float s = delta / ve;                 // the clamp decision uses the forward's exact s
   const float t = s * (1.0f + p);
   const float u0 = v - x.c[0], u1 = v - x.c[1], u2 = v - x.c[2];
   const float G = g.c[0] + g.c[1] + g.c[2];
   const float GU = g.c[0] * u0 + g.c[1] * u1 + g.c[2] * u2;
+  // regimes: t < 0 (s' = 0, every channel becomes v), t > 1 (s' = 1), else s' = s (1 + p); 0/1 masks, no branches
+  const float m_lo = t < 0.0f ? 1.0f : 0.0f;
+  const float m_hi = t > 1.0f ? 1.0f : 0.0f;
+  const float m_in = (t >= 0.0f && t <= 1.0f) ? 1.0f : 0.0f;
+  const float vd = v * rd;
+  const float b = v * (1.0f + p) * rve;
+  const float db = (1.0f + p) * kHsvEps * rve * rve;
+  const float coef = m_hi * vd + m_in * b;
   Rgb gx;
-  if (t < 0.0f) {                       // s' = 0: every channel becomes v
-    gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
-    add_at(gx, amax, G);
-  } else if (t > 1.0f) {                // s' = 1 (needs delta > 0)
-    const float vd = v / delta;
-    T2O_UNROLL
-  for (int c = 0; c < 3; ++c) gx.c[c] = vd * g.c[c];
-    add_at(gx, amax, G * (1.0f - vd) + GU * (vd - 1.0f) / delta);
-    add_at(gx, amin, -GU * vd / delta);
-  } else {                              // s' = s (1 + p)
-    const float b = v * (1.0f + p) / ve;
-    const float db = (1.0f + p) * kHsvEps / (ve * ve);
-    T2O_UNROLL
-  for (int c = 0; c < 3; ++c) gx.c[c] = b * g.c[c];
-    add_at(gx, amax, G * (1.0f - b) - GU * db);
-    red[0] += -GU * (v / ve);
-  }
+  T2O_UNROLL
+  for (int c = 0; c < 3; ++c) gx.c[c] = coef * g.c[c];
+  add_at(gx, amax, m_lo * G + m_hi * (G * (1.0f - vd) + GU * (vd - 1.0f) * rd) + m_in * (G * (1.0f - b) - GU * db));
+  add_at(gx, amin, m_hi * (-GU * vd * rd));
+  red[0] += m_in * (-GU * (v * rve));
   return gx;
 }
 
