@@ -470,3 +470,20 @@ def test_quantized_images_ties_everywhere(executor, dev, op):
     np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(x.grad.cpu().numpy(), gi_ref.numpy(), rtol=1e-4, atol=5e-5 if op in (0, 2) else 2e-6)
     np.testing.assert_allclose(pp.grad.cpu().numpy(), gp_ref.numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(gp_ref.abs().max())))
+
+
+def test_forward_bit_identical_to_reference_arithmetic(executor, dev):
+    """On the GPU too, the forward reproduces the reference's eager fp32 CPU path bit for bit for
+    every operator except contrast (cos differs by an ulp between the two libms): same operation
+    order, -ffp-contract=off, correctly rounded quotients."""
+    img = synth.images(4, 64, 64, 5)
+    for op in [0, 2, 3, 5, 6]:
+        p = synth.op_params(op, 4, 50 + op, 'mid')
+        ref = cpu_ref.operator_apply(op, img, p, None, OPT)
+        out, _ = executor.execute(img.to(dev), op, None, specified_param=p.to(dev))
+        assert torch.equal(out.cpu(), ref), 'operator %d: %d floats differ, max %.3g' % (
+            op, int((out.cpu() != ref).sum()), float((out.cpu() - ref).abs().max()))
+    p = synth.op_params(1, 4, 51, 'mid')
+    ref = cpu_ref.operator_apply(1, img, p, None, OPT)
+    out, _ = executor.execute(img.to(dev), 1, None, specified_param=p.to(dev))
+    assert (out.cpu() - ref).abs().max().item() <= 2.4e-7
