@@ -252,43 +252,45 @@ T2O_HD void pointwise_bwd_thread(const OpArgs& a, int op, int b, int blk, int ti
 T2O_HD int tile_rows(int halo) { return kTileH + 2 * halo; }
 T2O_HD int tile_floats(int halo) { return tile_rows(halo) * kRowStride; }
 
-// Cooperative load of a (kTileH+2*halo) x (kTileW+2*halo) window of `planes` planes
-// starting at plane pointer src (plane stride hw) into lds; zero outside the image.
+// Cooperative load of a (kTileH+2*HALO) x (kTileW+2*HALO) window of `planes` planes starting at
+// plane pointer src (plane stride hw) into lds; zero outside the image.  HALO is a template
+// parameter so every divisor below is a compile-time constant (multiply-shift, not a divide
+// sequence), and offsets inside a sample are 32-bit.
 // V == 4 (W % 4 == 0): interior as aligned float4 + scalar halo columns; V == 1: scalars.
-template <int V>
-T2O_HD void tile_load(const float* src, size_t hw, int planes, int H, int W, int y0, int x0, int halo,
-                      float* lds, int tid) {
-  const int rows = tile_rows(halo);
+template <int V, int HALO>
+T2O_HD void tile_load(const float* src, unsigned hw, int planes, int H, int W, int y0, int x0, float* lds, int tid) {
+  constexpr int rows = kTileH + 2 * HALO;
+  constexpr int plane_floats = rows * kRowStride;
   if (V == 4) {
-    const int per_plane = rows * (kTileW / 4);
+    constexpr int per_plane = rows * (kTileW / 4);
     for (int i = tid; i < planes * per_plane; i += kThreads) {
       const int c = i / per_plane, rem = i % per_plane;
       const int r = rem / (kTileW / 4), q = rem % (kTileW / 4);
-      const int gy = y0 - halo + r, gx = x0 + 4 * q;
+      const int gy = y0 - HALO + r, gx = x0 + 4 * q;
       float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (gy >= 0 && gy < H && gx < W) load_vec<4>(src + c * hw + (size_t)gy * W + gx, v);
-      store_vec<4>(lds + c * tile_floats(halo) + r * kRowStride + kIntOff + 4 * q, v);
+      if (gy >= 0 && gy < H && gx < W) load_vec<4>(src + ((unsigned)c * hw + (unsigned)gy * (unsigned)W + (unsigned)gx), v);
+      store_vec<4>(lds + c * plane_floats + r * kRowStride + kIntOff + 4 * q, v);
     }
-    const int hper = rows * 2 * halo;
+    constexpr int hper = rows * 2 * HALO;
     for (int i = tid; i < planes * hper; i += kThreads) {
       const int c = i / hper, rem = i % hper;
-      const int r = rem / (2 * halo), k = rem % (2 * halo);
-      const int j = k < halo ? k - halo : kTileW + (k - halo);     // column relative to the tile
-      const int gy = y0 - halo + r, gx = x0 + j;
+      const int r = rem / (2 * HALO), k = rem % (2 * HALO);
+      const int j = k < HALO ? k - HALO : kTileW + (k - HALO);     // column relative to the tile
+      const int gy = y0 - HALO + r, gx = x0 + j;
       float v = 0.0f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[c * hw + (size_t)gy * W + gx];
-      lds[c * tile_floats(halo) + r * kRowStride + kIntOff + j] = v;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[(unsigned)c * hw + (unsigned)gy * (unsigned)W + (unsigned)gx];
+      lds[c * plane_floats + r * kRowStride + kIntOff + j] = v;
     }
   } else {
-    const int cols = kTileW + 2 * halo;
-    const int per_plane = rows * cols;
+    constexpr int cols = kTileW + 2 * HALO;
+    constexpr int per_plane = rows * cols;
     for (int i = tid; i < planes * per_plane; i += kThreads) {
       const int c = i / per_plane, rem = i % per_plane;
-      const int r = rem / cols, j = rem % cols - halo;
-      const int gy = y0 - halo + r, gx = x0 + j;
+      const int r = rem / cols, j = rem % cols - HALO;
+      const int gy = y0 - HALO + r, gx = x0 + j;
       float v = 0.0f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[c * hw + (size_t)gy * W + gx];
-      lds[c * tile_floats(halo) + r * kRowStride + kIntOff + j] = v;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[(unsigned)c * hw + (unsigned)gy * (unsigned)W + (unsigned)gx];
+      lds[c * plane_floats + r * kRowStride + kIntOff + j] = v;
     }
   }
 }
@@ -314,7 +316,7 @@ template <int V>
 T2O_HD void sharp_fwd_phase_load(const OpArgs& a, int b, int tile, int tid, float* lds) {
   int y0, x0;
   tile_origin(a, tile, y0, x0);
-  tile_load<V>(a.img + plane_off(a, b, 0), (size_t)a.H * a.W, 3, a.H, a.W, y0, x0, 1, lds, tid);
+  tile_load<V, 1>(a.img + plane_off(a, b, 0), (unsigned)a.H * (unsigned)a.W, 3, a.H, a.W, y0, x0, lds, tid);
 }
 
 // 4 horizontally adjacent window elements of plane c starting at tile column j (j % 4 == 0):
@@ -401,13 +403,11 @@ template <int V>
 T2O_HD void sharp_bwd_phase_load(const OpArgs& a, int b, int tile, int tid, float* lds) {
   int y0, x0;
   tile_origin(a, tile, y0, x0);
-  const size_t hw = (size_t)a.H * a.W;
-  tile_load<V>(a.img + plane_off(a, b, 0), hw, 3, a.H, a.W, y0, x0, 2, lds + sharp_bwd_x_off(), tid);
-  tile_load<V>((a.target ? a.target : a.gout) + plane_off(a, b, 0), hw, 3, a.H, a.W, y0, x0, 1,
-               lds + sharp_bwd_g_off(), tid);
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  tile_load<V, 2>(a.img + plane_off(a, b, 0), hw, 3, a.H, a.W, y0, x0, lds + sharp_bwd_x_off(), tid);
+  tile_load<V, 1>((a.target ? a.target : a.gout) + plane_off(a, b, 0), hw, 3, a.H, a.W, y0, x0, lds + sharp_bwd_g_off(), tid);
   if (a.mask_ch)
-    tile_load<V>(a.mask + (size_t)b * a.mask_ch * hw, hw, a.mask_ch, a.H, a.W, y0, x0, 1,
-                 lds + sharp_bwd_m_off(), tid);
+    tile_load<V, 1>(a.mask + (size_t)b * a.mask_ch * hw, hw, a.mask_ch, a.H, a.W, y0, x0, lds + sharp_bwd_m_off(), tid);
 }
 
 // Phase 2: at every window position (interior + 1-px halo) replace G by
