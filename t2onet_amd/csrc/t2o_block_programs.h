@@ -646,9 +646,7 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* r
     float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
     if (d == 0.0f && i > 0) slope += kk[i - 1];                     // on a knot both neighbours pass (inclusive clamp)
     gx.c[c] = dz.c[c] * t[kTabScale + cc] * slope;
-    T2O_UNROLL
-    for (int j = 0; j < kCurveSteps; ++j)
-      red[cc * kCurveSteps + j] += dz.c[c] * fminf(fmaxf(x.c[c] - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+    curve_bins_accumulate(x.c[c], dz.c[c], red + cc * kCurveSteps);
   }
   return gx;
 }
