@@ -175,6 +175,10 @@ struct LdsAcc {
   float* acc;
   // N raw sums of this thread: 4-lane (quad) DPP reduction, then the quad's first lane adds into
   // the quad's private LDS cells with plain read-add-write (sole owner: no atomics, fixed order).
+  // Measured alternatives on MI355X (5-operator chain, 126 us with this scheme): one cell per THREAD
+  // with ds_add_f32 -- 845 us (LDS float atomics cost ~190 cycles per wave instruction even with
+  // conflict-free addresses); one cell per thread with read-add-write -- 221 us (4x the LDS cells to
+  // zero and reduce per workgroup, 3 workgroups per CU instead of 5).
   template <int N>
   __device__ __forceinline__ void add_n(int slot0, float (&v)[N]) {
 #pragma unroll
