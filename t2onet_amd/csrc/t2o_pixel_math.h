@@ -135,10 +135,7 @@ struct Hsv {
 };
 
 T2O_HD Hsv rgb_to_hsv(float r, float g, float b) {
-  float maxc = r;
-  int arg = 0;
-  if (g > maxc) { maxc = g; arg = 1; }
-  if (b > maxc) { maxc = b; arg = 2; }
+  const float maxc = fmaxf(r, fmaxf(g, b));
   const float minc = fminf(r, fminf(g, b));
   const float delta = maxc - minc;
   Hsv o;
@@ -146,10 +143,11 @@ T2O_HD Hsv rgb_to_hsv(float r, float g, float b) {
   o.s = div_fast(delta, maxc + kHsvEps);
   const float ds = (delta == 0.0f) ? 1.0f : delta;
   const float rc = maxc - r, gc = maxc - g, bc = maxc - b;
-  // all three candidates, then two selects: no divergent branches
+  // all three candidates, then two selects: no divergent branches.  The FIRST channel that attains
+  // the maximum decides (torch.max index convention): r == maxc, else g == maxc, else b.
   // (T2O_OPAQUE pins each candidate where it is: otherwise hipcc sinks them back into a branch tree)
   const float hn0 = T2O_OPAQUE(bc - gc), hn1 = T2O_OPAQUE((rc - bc) + 2.0f * ds), hn2 = T2O_OPAQUE((gc - rc) + 4.0f * ds);
-  const float hn = arg == 0 ? hn0 : (arg == 1 ? hn1 : hn2);
+  const float hn = (r == maxc) ? hn0 : ((g == maxc) ? hn1 : hn2);
   float h = div_fast(hn, ds);
   h = div_by(h, 6.0f, kSixth);
   h = h - truncf(h);            // fmod(h, 1)
@@ -165,18 +163,17 @@ T2O_HD Rgb hsv_to_rgb(float H, float s, float v) {
   const float f = rem6(h6) - hi;
   // out_c = v (1 - w_c s) with w_c = 0 (the "v" role), 1 ("p"), f ("q") or 1 - f ("t"): the same products
   // as the reference's p, q, t (1*s and 0*s are exact), chosen per channel by its phase
-  // j = (sector - 2c) mod 6 -> w = {0, f, 1, 1, 1 - f, 0}[j]; selects only, no branch tree
-  const int k = (int)hi;
+  // j = sector - 2c in -4..5 -> w = {1, 1, 1-f, 0 | 0, f, 1, 1, 1-f, 0}[j + 4].  That table is the sum of two
+  // clamped ramps, min((j-1) + f, (4-j) + (1-f)) and (-2-j) + (1-f), each clamped to [0,1]: where a ramp is
+  // strictly inside (0,1) its integer part is 0, so it returns f or 1-f exactly; elsewhere it saturates
+  // with a margin (f in [0,1)), and at most one of the two is non-zero.  No compares, no selects.
   const float fq = T2O_OPAQUE(f), omf = T2O_OPAQUE(1.0f - f);
   Rgb o;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
-    int j = k - 2 * c;
-    j += (j < 0) ? 6 : 0;
-    // 0/1 masks and exact arithmetic (exactly one term is non-zero) instead of a ternary chain,
-    // which hipcc turns into a divergent branch tree
-    const float m1 = (j == 1) ? 1.0f : 0.0f, m4 = (j == 4) ? 1.0f : 0.0f, m23 = ((j & ~1) == 2) ? 1.0f : 0.0f;
-    const float w = m1 * fq + (m4 * omf + m23);
+    const float j = hi - (float)(2 * c);
+    float w = clamp01(fminf((j - 1.0f) + fq, (4.0f - j) + omf));
+    if (c > 0) w = w + clamp01((-2.0f - j) + omf);
     o.c[c] = v * (1.0f - w * s);
   }
   return o;
