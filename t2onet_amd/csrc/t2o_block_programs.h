@@ -628,12 +628,13 @@ T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
 
 // backward of a curve operator on one pixel (COLOR: per-channel curves, else one shared curve):
 // dz = gradient w.r.t. the PRE-clamp output (already zeroed where the clamp was active);
-// returns the gradient w.r.t. the input, adds the raw sums red[8*row + j] += dz * t_j.
+// returns the gradient w.r.t. the input, adds the raw sums red[8*row + j] += dz * t_j (first = true:
+// this is the thread's first pixel, the sums are assigned instead and need no zeroing).
 // (A segment-histogram variant -- two LDS float atomics per channel instead of 8 multiply-adds --
 // measured 3x SLOWER on MI355X: ds_add_f32 with per-lane addresses runs at roughly one lane per
 // 3 cycles per CU.  Kept out.)
 template <bool COLOR>
-T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* red) {
+T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* red, bool first) {
   Rgb gx;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
@@ -646,7 +647,7 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* r
     float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
     if (d == 0.0f && i > 0) slope += kk[i - 1];                     // on a knot both neighbours pass (inclusive clamp)
     gx.c[c] = dz.c[c] * t[kTabScale + cc] * slope;
-    curve_bins_accumulate(x.c[c], dz.c[c], red + cc * kCurveSteps);
+    curve_bins_accumulate(x.c[c], dz.c[c], red + cc * kCurveSteps, first && (COLOR || c == 0));
   }
   return gx;
 }
@@ -780,8 +781,7 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
 #define T2O_CHAIN_BWD_BODY(NRED, CALL)                                                   \
       {                                                                                  \
         float red[NRED];                                                                 \
-        T2O_UNROLL                                                                       \
-        for (int j = 0; j < NRED; ++j) red[j] = 0.0f;                                    \
+        if (NRED == 1) red[0] = 0.0f;      /* curve bodies assign on their first pixel */ \
         T2O_UNROLL                                                                       \
         for (int i = 0; i < V; ++i) {                                                    \
           Rgb xi, gi;                                                                    \
@@ -796,8 +796,8 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
         }                                                                                \
         acc.template add_n<NRED>(bin0, red);                                             \
       }
-      if (op == OP_COLOR) T2O_CHAIN_BWD_BODY(24, chain_curve_bwd<true>(xi, t, gi, red))
-      else if (op == OP_TONE) T2O_CHAIN_BWD_BODY(8, chain_curve_bwd<false>(xi, t, gi, red))
+      if (op == OP_COLOR) T2O_CHAIN_BWD_BODY(24, chain_curve_bwd<true>(xi, t, gi, red, i == 0))
+      else if (op == OP_TONE) T2O_CHAIN_BWD_BODY(8, chain_curve_bwd<false>(xi, t, gi, red, i == 0))
       else if (op == OP_WHITE) {
         T2O_UNROLL
         for (int c = 0; c < 3; ++c) {

@@ -185,6 +185,7 @@ struct LdsAcc {
     for (int j = 0; j < N; ++j) {
       v[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j]), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
       v[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j]), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+      asm volatile("" : "+v"(v[j]));   // finish the sum HERE (one v_add_f32_dpp), not as a dpp move + an add inside the owner branch
     }
     if ((threadIdx.x & 3) == 0) {
       float* cell = acc + slot0 * kAccStride + (threadIdx.x >> 2);

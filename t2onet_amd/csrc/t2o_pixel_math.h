@@ -171,9 +171,9 @@ T2O_HD Rgb hsv_to_rgb(float H, float s, float v) {
   Rgb o;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
-    const float j = hi - (float)(2 * c);
-    float w = clamp01(fminf((j - 1.0f) + fq, (4.0f - j) + omf));
-    if (c > 0) w = w + clamp01((-2.0f - j) + omf);
+    // with j = hi - 2c folded into the constants (small integers: exact either way)
+    float w = clamp01(fminf((hi - (float)(2 * c + 1)) + fq, ((float)(2 * c + 4) - hi) + omf));
+    if (c > 0) w = w + clamp01(((float)(2 * c - 2) - hi) + omf);
     o.c[c] = v * (1.0f - w * s);
   }
   return o;
@@ -456,7 +456,8 @@ T2O_HD Rgb contrast_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
 // parameter gradient.  On gfx950 two segments per instruction: a packed fp32 add with the [0,1]
 // output clamp gives w_j = clamp(8x - j, 0, 1) (= 8 * the term above exactly: 8x is a power-of-two
 // scaling and 8x - j is exact wherever it is positive), then one packed multiply-add with g/8.
-T2O_HD void curve_bins_accumulate(float x, float g, float* red) {
+// first = true: red[j] = ... instead of += (the caller's first contribution: saves zeroing the sums).
+T2O_HD void curve_bins_accumulate(float x, float g, float* red, bool first = false) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const float t = x * (float)kCurveSteps, g8 = g * (1.0f / kCurveSteps);
@@ -466,14 +467,21 @@ T2O_HD void curve_bins_accumulate(float x, float g, float* red) {
     const f32x2 nj = {-(float)j, -(float)(j + 1)};     // wave-uniform constants: a scalar register pair
     f32x2 w;
     asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(w) : "v"(tt), "s"(nj));
-    f32x2 acc = {red[j], red[j + 1]};
-    acc = __builtin_elementwise_fma(gg, w, acc);
+    f32x2 acc;
+    if (first) {
+      acc = gg * w;
+    } else {
+      acc = f32x2{red[j], red[j + 1]};
+      acc = __builtin_elementwise_fma(gg, w, acc);
+    }
     red[j] = acc.x;
     red[j + 1] = acc.y;
   }
 #else
-  for (int j = 0; j < kCurveSteps; ++j)
-    red[j] += g * fminf(fmaxf(x - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+  for (int j = 0; j < kCurveSteps; ++j) {
+    const float t = g * fminf(fmaxf(x - (float)j / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+    red[j] = first ? t : red[j] + t;
+  }
 #endif
 }
 
