@@ -358,10 +358,11 @@ T2O_HD Rgb hsv_literal_bwd(bool sat, const Rgb& x, float P, const Rgb& g, float*
   float Gv, Gs;
   if (sat) { Gv = GV; Gs = in ? GS * (1.0f + P) : 0.0f; red[0] += in ? GS * s : 0.0f; }
   else     { Gv = in ? GV * (1.0f + P) : 0.0f; Gs = GS; red[0] += in ? GV * M : 0.0f; }
-  float Gd = Gs / ve;                         // d / d delta through s
-  Gv += -Gs * delta / (ve * ve);
-  const float Ghn = Gf / ds;
-  if (delta != 0.0f) Gd += -Gf * hn / (ds * ds) + (a == 1 ? 2.0f * Ghn : a == 2 ? 4.0f * Ghn : 0.0f);
+  const float rve = T2O_FDIV(1.0f, ve), rds = T2O_FDIV(1.0f, ds);   // derivative only: hardware reciprocals
+  float Gd = Gs * rve;                        // d / d delta through s
+  Gv += -Gs * delta * (rve * rve);
+  const float Ghn = Gf * rds;
+  if (delta != 0.0f) Gd += -Gf * hn * (rds * rds) + (a == 1 ? 2.0f * Ghn : a == 2 ? 4.0f * Ghn : 0.0f);
   Rgb gx;
   gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
   // hn = (g - b), (b - r) + 2 ds, (r - g) + 4 ds for argmax = r, g, b
@@ -429,13 +430,35 @@ T2O_HD Rgb saturation_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
 }
 
 // out_c = x_c ((1 - p) + p q(L)),  q = cl(L) / (L + 1e-6)
+// sin(pi L), cos(pi L) for L in [0,1] to 2e-7 absolute: with r = L - 1/2, sin(pi L) = cos(pi r) and
+// cos(pi L) = -sin(pi r), |pi r| <= pi/2, Taylor polynomials in r^2 (truncation < 6e-8).  13 multiply-adds
+// instead of libm's general sincosf (argument reduction for any magnitude, ~50 instructions).
+T2O_HD void sincospi_unit(float L, float& sn, float& cs) {
+  const float r = L - 0.5f, r2 = r * r;
+  float ps = -0.007370430945714348f;
+  ps = fmaf(ps, r2, 0.08214588661112819f);
+  ps = fmaf(ps, r2, -0.5992645293207919f);
+  ps = fmaf(ps, r2, 2.550164039877345f);
+  ps = fmaf(ps, r2, -5.167712780049969f);
+  ps = fmaf(ps, r2, 3.141592653589793f);
+  float pc = 0.001929574309403922f;
+  pc = fmaf(pc, r2, -0.02580689139001405f);
+  pc = fmaf(pc, r2, 0.23533063035889312f);
+  pc = fmaf(pc, r2, -1.3352627688545893f);
+  pc = fmaf(pc, r2, 4.058712126416768f);
+  pc = fmaf(pc, r2, -4.934802200544679f);
+  pc = fmaf(pc, r2, 1.0f);
+  sn = pc;
+  cs = -(ps * r);
+}
+
 T2O_HD Rgb contrast_bwd(const Rgb& x, float p, const Rgb& g, float* red) {
   const float lum = luminance(x);
   const float L = fminf(fmaxf(lum, 0.0f), 1.0f);
   // torch.min(torch.max(lum, 0), 1): elementwise max/min split the gradient 1/2 - 1/2 at a tie
   const float inside = (lum > 0.0f && lum < 1.0f) ? 1.0f : ((lum == 0.0f || lum == 1.0f) ? 0.5f : 0.0f);
   float sn, cs;
-  sincosf(kPi * L, &sn, &cs);                  // one shared argument reduction
+  sincospi_unit(L, sn, cs);                    // derivative only (1e-5 bar); the forward keeps libm's cosf
   const float cl = (-cs) * 0.5f + 0.5f;
   const float Le = L + 1e-6f;
   const float rLe = T2O_FDIV(1.0f, Le);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the fused chain kernels for arbitrary operator lists (cost of each operator inside a chain).
 
-    python tools/bench_chain_ops.py [B H W]
+    python tools/bench_chain_ops.py [B H W] [--quant]     (--quant: 8-bit images, so channels tie)
 
 Prints, per operator list, the HIP-event time of one t2o_fused_sequence_fwd and one
 t2o_fused_sequence_bwd call (gout path, no L1) -- differences between lists give the incremental
@@ -22,10 +22,14 @@ LISTS = [[0], [1], [2], [3], [5], [0, 0], [1, 1], [2, 2], [3, 3], [5, 5], [0, 1,
 
 
 def main():
-    B, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (64, 256, 256)
+    quant = '--quant' in sys.argv
+    argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+    B, H, W = (int(v) for v in argv[:3]) if len(argv) >= 3 else (64, 256, 256)
     dev = torch.device('cuda:0')
     lib = _lib.load()
     img, tgt, _ = bench.make_inputs(B, H, W, dev)
+    if quant:
+        img = torch.round(img * 255.0) / 255.0
     ws = torch.empty(lib.t2o_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
     out, gimg, gout = torch.empty_like(img), torch.empty_like(img), torch.randn_like(img)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
