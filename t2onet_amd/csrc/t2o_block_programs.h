@@ -23,6 +23,8 @@ constexpr int kRedSlots = 24;      // widest per-sample parameter-gradient reduc
 // Stencil tile: 16 rows x 64 columns per workgroup, thread (ty,tx) owns 4 pixels of one row.
 constexpr int kTileW = 64;
 constexpr int kTileH = 16;
+constexpr int kStripRows = 4;       // LDS-free stencil backward: rows per thread (x rows loaded / row = 2, dz rows computed / row = 1.5)
+constexpr int kFwdStripRows = 2;    // forward: 2 rows per thread measured best (1: 33.0, 2: 33.0, 4: 35.5 us; tile kernel 34.3)
 constexpr int kRowStride = 72;     // floats per LDS row: [..halo][64 interior at +4][halo..], 16-B aligned rows
 constexpr int kIntOff = 4;         // LDS column index of interior column 0
 
@@ -1048,7 +1050,8 @@ struct Geometry {
   int vec_tile;    // 4 when W % 4 == 0 (stencil kernels)
   int iters;       // pixel groups per thread (pointwise)
   int nblk_point;  // workgroups per sample (pointwise)
-  int nblk_sharp;  // tiles per sample (stencil)
+  int nblk_sharp;  // tiles per sample (stencil, LDS-tile kernels)
+  int nblk_strip_fwd, nblk_strip_bwd;   // workgroups per sample of the LDS-free stencil kernels
   int nblk_max;    // stride of the per-sample partial-sum rows
 };
 
@@ -1066,6 +1069,13 @@ inline Geometry geometry(int B, int H, int W, int forced_iters = 0) {
   g.nblk_point = (int)((groups + (size_t)kThreads * g.iters - 1) / ((size_t)kThreads * g.iters));
   g.nblk_sharp = sharp_num_tiles(H, W);
   g.nblk_max = g.nblk_point > g.nblk_sharp ? g.nblk_point : g.nblk_sharp;
+  // LDS-free stencil kernels (W % 4 == 0): workgroups of 4 waves x kFwdStripRows / kStripRows rows x 256 columns
+  g.nblk_strip_fwd = ((H + 4 * kFwdStripRows - 1) / (4 * kFwdStripRows)) * ((W + 255) / 256);
+  g.nblk_strip_bwd = ((H + 4 * kStripRows - 1) / (4 * kStripRows)) * ((W + 255) / 256);
+  if (g.vec_tile == 4) {
+    if (g.nblk_strip_fwd > g.nblk_max) g.nblk_max = g.nblk_strip_fwd;
+    if (g.nblk_strip_bwd > g.nblk_max) g.nblk_max = g.nblk_strip_bwd;
+  }
   return g;
 }
 

@@ -154,6 +154,179 @@ __global__ __launch_bounds__(kThreads) void k_sharp_fwd(OpArgs a, int tiles) {
   if (a.target) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk_max + tile);
 }
 
+// ---- stencil kernels without LDS (W % 4 == 0) ----
+// A thread owns a column strip of kStripRows rows x one aligned quad; a wave = 64 consecutive quads
+// (a 256-pixel segment) x kStripRows rows; the workgroup = 4 strips stacked (16 rows).  Every row a strip
+// needs is loaded up front with independent 16-byte loads, rows above / below are simply more registers,
+// left / right neighbours come from the adjacent lanes by wave-wide DPP shifts (wave_shr:1 / wave_shl:1);
+// only lane 0 / lane 63 of a segment that does not touch the image border read their outside column
+// from global memory.  No LDS staging pass, no barrier, no item arithmetic: these kernels stream.
+// (The LDS-tile kernels above remain for W % 4 != 0 and for the masked backward.  Measured at bs=64
+// 256x256 inside the benchmark step: backward 48.6 -> 31.0 us.  The tile kernels were issue-bound, ~170
+// vector + ~90 scalar instructions per pixel mostly for window addressing and predication, and their
+// load / compute / store phases added up exactly, with or without a register prefetch of the next tile.)
+// blocks per sample = ceil(H / 16) * ceil(W / 256).
+
+__device__ __forceinline__ float dpp_wave_shr1(float v) {   // lane i <- lane i-1 (lane 0 <- 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float v) {   // lane i <- lane i+1 (lane 63 <- 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+// WIDE = the image is wider than one 256-pixel segment (outside-column code compiled in).
+template <bool DYN, bool WIDE, int ROWS>
+__global__ __launch_bounds__(kThreads) void k_sharp_fwd_strip(OpArgs a, int nblk, int nseg) {
+  int b, blk;
+  wg_coords(nblk, b, blk);
+  if (DYN && a.op_id[b] != OP_SHARPNESS) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = (blk / nseg) * (4 * ROWS) + wave * ROWS, gx0 = (blk % nseg) * 256 + 4 * lane;
+  const bool col_live = gx0 < a.W;
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const float p = a.param[(size_t)b * a.param_stride];
+  const bool ext_l = WIDE && lane == 0 && gx0 > 0 && col_live, ext_r = WIDE && lane == 63 && gx0 + 4 < a.W;
+  float l1 = 0.0f;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    const float* xp = a.img + ((size_t)b * 3 + c) * hw;
+    float xr[ROWS + 2][4], tg[ROWS][4];
+#pragma unroll
+    for (int k = 0; k < ROWS + 2; ++k) {
+      const int y = y0 - 1 + k;
+      xr[k][0] = xr[k][1] = xr[k][2] = xr[k][3] = 0.0f;
+      if (col_live && y >= 0 && y < a.H) load_vec<4>(xp + (unsigned)y * (unsigned)a.W + (unsigned)gx0, xr[k]);
+    }
+    if (a.target) {
+#pragma unroll
+      for (int k = 0; k < ROWS; ++k) {
+        const int y = y0 + k;
+        tg[k][0] = tg[k][1] = tg[k][2] = tg[k][3] = 0.0f;
+        if (col_live && y < a.H) load_vec<4>(a.target + ((size_t)b * 3 + c) * hw + (unsigned)y * (unsigned)a.W + (unsigned)gx0, tg[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+      const int y = y0 + k;
+      const bool live = col_live && y < a.H;
+      const float* ce = xr[k + 1];
+      float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
+      if (ext_l && live) L = xp[(unsigned)y * (unsigned)a.W + (unsigned)gx0 - 1];
+      if (ext_r && live) R = xp[(unsigned)y * (unsigned)a.W + (unsigned)gx0 + 4];
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
+        o[i] = ce[i] + p * sharp_delta(ce[i], xr[k][i], left, right, xr[k + 2][i]);
+      }
+      if (!live) continue;
+      const unsigned off = (unsigned)y * (unsigned)a.W + (unsigned)gx0;
+      if (a.mask_ch) {
+        float m[4];
+        load_vec<4>(a.mask + ((size_t)b * a.mask_ch + (a.mask_ch == 3 ? c : 0)) * hw + off, m);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = blend(o[i], ce[i], m[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = clamp01(o[i]);
+      store_vec<4>(a.out + ((size_t)b * 3 + c) * hw + off, o);
+      if (a.target) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l1 += fabsf(o[i] - tg[k][i]);
+      }
+    }
+  }
+  if (a.target) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk_max + blk);
+}
+
+// Backward, strip layout as above (no mask): x rows y0-2..y0+5 and gradient (or L1 target) rows y0-1..y0+4
+// are loaded up front (14 independent 16-byte loads per plane), dz is computed once per window row in
+// registers (in place of the gradient rows), then the symmetric stencil is applied to it.  Lane 0 / 63 of
+// an interior segment get their outside dz column from sharp_dz_at (compiled in only for W > 256).
+
+// dz at one pixel straight from global memory (slow path for the outside column of interior segments)
+__device__ __forceinline__ float sharp_dz_at(const OpArgs& a, const float* xp, const float* gp, int y, int x, float p, float gs) {
+  if (y < 0 || y >= a.H || x < 0 || x >= a.W) return 0.0f;
+  const size_t o = (size_t)y * a.W + x;
+  const float ce = xp[o];
+  const float up = y > 0 ? xp[o - a.W] : 0.0f, dn = y + 1 < a.H ? xp[o + a.W] : 0.0f;
+  const float lf = x > 0 ? xp[o - 1] : 0.0f, rt = x + 1 < a.W ? xp[o + 1] : 0.0f;
+  const float z = ce + p * sharp_delta(ce, up, lf, rt, dn);
+  const float gz = a.target ? sign_of(clamp01(z) - gp[o]) * gs : gp[o];
+  return (z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
+}
+
+template <bool DYN, bool WIDE>
+__global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk, int nseg) {
+  int b, blk;
+  wg_coords(nblk, b, blk);
+  if (DYN && a.op_id[b] != OP_SHARPNESS) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = (blk / nseg) * (4 * kStripRows) + wave * kStripRows, gx0 = (blk % nseg) * 256 + 4 * lane;
+  const bool col_live = gx0 < a.W;
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const float p = a.param[(size_t)b * a.param_stride];
+  const float gs = a.target ? a.gloss[0] * a.inv_n : 0.0f;
+  const bool ext_l = WIDE && lane == 0 && gx0 > 0 && col_live, ext_r = WIDE && lane == 63 && gx0 + 4 < a.W;
+  float red0 = 0.0f;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+    const float* xp = a.img + ((size_t)b * 3 + c) * hw;
+    const float* gp = (a.target ? a.target : a.gout) + ((size_t)b * 3 + c) * hw;
+    float xr[kStripRows + 4][4], g[kStripRows + 2][4];
+#pragma unroll
+    for (int k = 0; k < kStripRows + 4; ++k) {
+      const int y = y0 - 2 + k;
+      xr[k][0] = xr[k][1] = xr[k][2] = xr[k][3] = 0.0f;
+      if (col_live && y >= 0 && y < a.H) load_vec<4>(xp + (unsigned)y * (unsigned)a.W + (unsigned)gx0, xr[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kStripRows + 2; ++k) {
+      const int y = y0 - 1 + k;
+      g[k][0] = g[k][1] = g[k][2] = g[k][3] = 0.0f;
+      if (col_live && y >= 0 && y < a.H) load_vec<4>(gp + (unsigned)y * (unsigned)a.W + (unsigned)gx0, g[k]);
+    }
+    // dz for window rows y0-1 .. y0+kStripRows (in place of g)
+#pragma unroll
+    for (int k = 0; k < kStripRows + 2; ++k) {
+      const int y = y0 - 1 + k;
+      const bool in = col_live && y >= 0 && y < a.H;
+      const float* ce = xr[k + 1];
+      float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
+      if (ext_l && in) L = xp[(unsigned)y * (unsigned)a.W + (unsigned)gx0 - 1];
+      if (ext_r && in) R = xp[(unsigned)y * (unsigned)a.W + (unsigned)gx0 + 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
+        const float d = sharp_delta(ce[i], xr[k][i], left, right, xr[k + 2][i]);
+        const float z = ce[i] + p * d;
+        const float gz = a.target ? sign_of(clamp01(z) - g[k][i]) * gs : g[k][i];
+        const float dz = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
+        g[k][i] = dz;
+        if (k >= 1 && k <= kStripRows) red0 += dz * d;
+      }
+    }
+    // gimg rows y0 .. y0+kStripRows-1
+#pragma unroll
+    for (int k = 1; k <= kStripRows; ++k) {
+      const int y = y0 - 1 + k;
+      const float* ce = g[k];
+      float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
+      if (ext_l) L = sharp_dz_at(a, xp, gp, y, gx0 - 1, p, gs);
+      if (ext_r) R = sharp_dz_at(a, xp, gp, y, gx0 + 4, p, gs);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
+        o[i] = ce[i] + p * sharp_delta(ce[i], g[k - 1][i], left, right, g[k + 1][i]);
+      }
+      if (a.gimg && col_live && y < a.H)
+        store_vec<4>(a.gimg + ((size_t)b * 3 + c) * hw + (unsigned)y * (unsigned)a.W + (unsigned)gx0, o);
+    }
+  }
+  block_reduce_store1(red0, a.partials + ((size_t)b * a.nblk_max + blk) * kRedSlots);
+}
+
 template <bool DYN, int V>
 __global__ __launch_bounds__(kThreads) void k_sharp_bwd(OpArgs a, int tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -589,7 +762,25 @@ void launch_point_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
   const unsigned grid = (unsigned)a.B * nblk;
   if (g.vec == 4) { T2O_POINT_CASES(k_point_bwd, 4) } else { T2O_POINT_CASES(k_point_bwd, 1) }
 }
+// which stencil kernels run, and how many per-sample partial rows they write
+bool sharp_uses_strips(const Geometry& g) {
+  static const int mode = env_int("T2O_SHARP_STRIPS", 1);      // 0: LDS-tile kernels everywhere (A/B runs)
+  return mode && g.vec_tile == 4;
+}
+bool sharp_bwd_uses_strips(const OpArgs& a, const Geometry& g) { return sharp_uses_strips(g) && a.mask_ch == 0; }
+int sharp_fwd_blocks(const OpArgs&, const Geometry& g) { return sharp_uses_strips(g) ? g.nblk_strip_fwd : g.nblk_sharp; }
+int sharp_bwd_blocks(const OpArgs& a, const Geometry& g) { return sharp_bwd_uses_strips(a, g) ? g.nblk_strip_bwd : g.nblk_sharp; }
+
 void launch_sharp_fwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
+  if (sharp_uses_strips(g)) {
+    const int nseg = (a.W + 255) / 256, nblk = sharp_fwd_blocks(a, g);
+    const unsigned grid = (unsigned)a.B * nblk;
+    const bool dyn = a.op == OP_DYNAMIC;
+    constexpr int R = kFwdStripRows;
+    if (nseg > 1) { if (dyn) k_sharp_fwd_strip<true, true, R><<<grid, kThreads, 0, st>>>(a, nblk, nseg); else k_sharp_fwd_strip<false, true, R><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
+    else          { if (dyn) k_sharp_fwd_strip<true, false, R><<<grid, kThreads, 0, st>>>(a, nblk, nseg); else k_sharp_fwd_strip<false, false, R><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
+    return;
+  }
   const unsigned grid = (unsigned)a.B * g.nblk_sharp;
   const size_t lds = sizeof(float) * sharp_fwd_lds_floats();
   const bool dyn = a.op == OP_DYNAMIC;
@@ -602,6 +793,14 @@ void launch_sharp_fwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
   }
 }
 void launch_sharp_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
+  if (sharp_bwd_uses_strips(a, g)) {
+    const int nseg = (a.W + 255) / 256, nblk = g.nblk_strip_bwd;
+    const unsigned grid = (unsigned)a.B * nblk;
+    const bool dyn = a.op == OP_DYNAMIC;
+    if (nseg > 1) { if (dyn) k_sharp_bwd_strip<true, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); else k_sharp_bwd_strip<false, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
+    else          { if (dyn) k_sharp_bwd_strip<true, false><<<grid, kThreads, 0, st>>>(a, nblk, nseg); else k_sharp_bwd_strip<false, false><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
+    return;
+  }
   const unsigned grid = (unsigned)a.B * g.nblk_sharp;
   const size_t lds = sizeof(float) * sharp_bwd_lds_floats(a.mask_ch);
   const bool dyn = a.op == OP_DYNAMIC;
@@ -654,7 +853,7 @@ int run_fwd(int op, const int* op_id, const float* img, const float* param, int 
   hipStream_t st = (hipStream_t)stream;
   if (op != OP_SHARPNESS) launch_point_fwd(a, g, st);
   if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_fwd(a, g, st);
-  if (target) k_finalize_loss<<<1, kThreads, 0, st>>>(a, loss, g.nblk_point, g.nblk_sharp);
+  if (target) k_finalize_loss<<<1, kThreads, 0, st>>>(a, loss, g.nblk_point, sharp_fwd_blocks(a, g));
   return check_launch("operator forward");
 }
 
@@ -695,7 +894,7 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   if (partials_region) {                        // the caller finalises every operator of the sequence at once
     if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
     else launch_sharp_bwd(a, g, st);
-    if (nblk_out) *nblk_out = (op == OP_SHARPNESS) ? g.nblk_sharp : g.nblk_point;
+    if (nblk_out) *nblk_out = (op == OP_SHARPNESS) ? sharp_bwd_blocks(a, g) : g.nblk_point;
     return check_launch("operator backward");
   }
   if ((op == OP_COLOR || op == OP_TONE) && !mask && gparam) {
@@ -709,7 +908,7 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
   if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_bwd(a, g, st);
   if (gparam && op != OP_IDENTITY)
-    k_finalize_params<<<B, kThreads, 0, st>>>(a, gparam, gparam_stride, g.nblk_point, g.nblk_sharp);
+    k_finalize_params<<<B, kThreads, 0, st>>>(a, gparam, gparam_stride, g.nblk_point, sharp_bwd_blocks(a, g));
   return check_launch("operator backward");
 }
 

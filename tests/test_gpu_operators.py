@@ -135,6 +135,44 @@ def test_vs_oracle_ragged_sizes(executor, dev, op, shape):
         np.testing.assert_allclose(pp.grad.cpu().numpy(), gp64.numpy(), rtol=2e-4, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 4), (1, 8, 260), (1, 21, 512), (2, 16, 256), (1, 9, 1028), (3, 50, 12)])
+@pytest.mark.parametrize('setting', ['mid', 'strong'])
+def test_sharpness_strip_kernels(executor, dev, shape, setting):
+    """W % 4 == 0: the LDS-free stencil kernels -- segment borders every 256 columns (lane 0 / 63 read
+    their outside column from memory), ragged last rows / last segment, fewer rows than one strip,
+    clamp active ('strong'); plain gradient and the fused-L1 form (target instead of gout)."""
+    import t2onet_amd.functional as T
+    B, H, W = shape
+    img = synth.images(B, H, W, 71)
+    gout = synth.uniform((B, 3, H, W), 72, -1.0, 1.0)
+    tgt = synth.images(B, H, W, 73)
+    p = synth.op_params(6, B, 470, setting)
+    o_ref = cpu_ref.operator_apply(6, img, p, None, OPT)
+    _, gi64, gp64 = _oracle64(6, img, p, None, gout)
+    x = img.to(dev).requires_grad_(True)
+    pp = p.to(dev).requires_grad_(True)
+    out, _ = executor.execute(x, 6, None, specified_param=pp)
+    out.backward(gout.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gi64.numpy(), rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(pp.grad.cpu().numpy(), gp64.numpy(), rtol=2e-4, atol=1e-4 * max(1.0, float(gp64.abs().max())))
+    # fused L1 on the stencil pair (t2o_op_fwd_l1 / t2o_op_bwd_l1 through the one-operator sequence)
+    x64 = img.double().requires_grad_(True)
+    p64 = p.double().requires_grad_(True)
+    loss_ref = (cpu_ref.operator_apply(6, x64, p64, None, OPT) - tgt.double()).abs().mean()
+    loss_ref.backward()
+    x2 = img.to(dev).requires_grad_(True)
+    p2 = torch.zeros(1, B, 24, device=dev)
+    p2[0, :, :1] = p.to(dev)
+    p2.requires_grad_(True)
+    loss, _ = T.sequence_l1(x2, [6], p2, tgt.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-6
+    n = B * 3 * H * W
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), x64.grad.float().numpy(), rtol=1e-5, atol=1e-6 / n * 10 + 1e-9)
+    np.testing.assert_allclose(p2.grad[0, :, :1].cpu().numpy(), p64.grad.float().numpy(), rtol=2e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('op', OPS)
 def test_edge_cases_ties_follow_pytorch(executor, dev, op):
     """Black / white / grey pixels, values on curve knots, flat saturated regions: PyTorch's tie
