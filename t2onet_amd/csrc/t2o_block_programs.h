@@ -24,6 +24,8 @@ constexpr int kRedSlots = 24;      // widest per-sample parameter-gradient reduc
 constexpr int kTileW = 64;
 constexpr int kTileH = 16;
 constexpr int kStripRows = 4;       // LDS-free stencil backward: rows per thread (x rows loaded / row = 2, dz rows computed / row = 1.5)
+constexpr int kStripWideCols = 248;  // backward, W > 256: columns a wave outputs (62 quads; lanes 0 / 63 overlap the neighbours)
+T2O_HD int strip_bwd_segments(int W) { return W <= 256 ? 1 : (W + kStripWideCols - 1) / kStripWideCols; }
 constexpr int kFwdStripRows = 2;    // forward: 2 rows per thread measured best (1: 33.0, 2: 33.0, 4: 35.5 us; tile kernel 34.3)
 constexpr int kRowStride = 72;     // floats per LDS row: [..halo][64 interior at +4][halo..], 16-B aligned rows
 constexpr int kIntOff = 4;         // LDS column index of interior column 0
@@ -1071,7 +1073,7 @@ inline Geometry geometry(int B, int H, int W, int forced_iters = 0) {
   g.nblk_max = g.nblk_point > g.nblk_sharp ? g.nblk_point : g.nblk_sharp;
   // LDS-free stencil kernels (W % 4 == 0): workgroups of 4 waves x kFwdStripRows / kStripRows rows x 256 columns
   g.nblk_strip_fwd = ((H + 4 * kFwdStripRows - 1) / (4 * kFwdStripRows)) * ((W + 255) / 256);
-  g.nblk_strip_bwd = ((H + 4 * kStripRows - 1) / (4 * kStripRows)) * ((W + 255) / 256);
+  g.nblk_strip_bwd = ((H + 4 * kStripRows - 1) / (4 * kStripRows)) * strip_bwd_segments(W);
   if (g.vec_tile == 4) {
     if (g.nblk_strip_fwd > g.nblk_max) g.nblk_max = g.nblk_strip_fwd;
     if (g.nblk_strip_bwd > g.nblk_max) g.nblk_max = g.nblk_strip_bwd;

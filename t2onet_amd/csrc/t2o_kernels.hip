@@ -241,20 +241,10 @@ __global__ __launch_bounds__(kThreads) void k_sharp_fwd_strip(OpArgs a, int nblk
 
 // Backward, strip layout as above (no mask): x rows y0-2..y0+5 and gradient (or L1 target) rows y0-1..y0+4
 // are loaded up front (14 independent 16-byte loads per plane), dz is computed once per window row in
-// registers (in place of the gradient rows), then the symmetric stencil is applied to it.  Lane 0 / 63 of
-// an interior segment get their outside dz column from sharp_dz_at (compiled in only for W > 256).
-
-// dz at one pixel straight from global memory (slow path for the outside column of interior segments)
-__device__ __forceinline__ float sharp_dz_at(const OpArgs& a, const float* xp, const float* gp, int y, int x, float p, float gs) {
-  if (y < 0 || y >= a.H || x < 0 || x >= a.W) return 0.0f;
-  const size_t o = (size_t)y * a.W + x;
-  const float ce = xp[o];
-  const float up = y > 0 ? xp[o - a.W] : 0.0f, dn = y + 1 < a.H ? xp[o + a.W] : 0.0f;
-  const float lf = x > 0 ? xp[o - 1] : 0.0f, rt = x + 1 < a.W ? xp[o + 1] : 0.0f;
-  const float z = ce + p * sharp_delta(ce, up, lf, rt, dn);
-  const float gz = a.target ? sign_of(clamp01(z) - gp[o]) * gs : gp[o];
-  return (z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
-}
+// registers (in place of the gradient rows), then the symmetric stencil is applied to it.
+// WIDE (W > 256): segments OVERLAP by one quad on each side -- lanes 0 and 63 only compute the dz column
+// their neighbours need (their own outer columns may be wrong and are never used) and store nothing, so a
+// wave outputs 62 quads = kStripWideCols pixels and no lane ever needs a dz from outside its wave.
 
 template <bool DYN, bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk, int nseg) {
@@ -262,12 +252,13 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
   wg_coords(nblk, b, blk);
   if (DYN && a.op_id[b] != OP_SHARPNESS) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int y0 = (blk / nseg) * (4 * kStripRows) + wave * kStripRows, gx0 = (blk % nseg) * 256 + 4 * lane;
-  const bool col_live = gx0 < a.W;
+  const int y0 = (blk / nseg) * (4 * kStripRows) + wave * kStripRows;
+  const int gx0 = WIDE ? (blk % nseg) * kStripWideCols - 4 + 4 * lane : 4 * lane;
+  const bool col_live = gx0 >= 0 && gx0 < a.W;
+  const bool own = !WIDE || (lane >= 1 && lane <= 62);      // this lane's quad is output (not an overlap lane)
   const unsigned hw = (unsigned)a.H * (unsigned)a.W;
   const float p = a.param[(size_t)b * a.param_stride];
   const float gs = a.target ? a.gloss[0] * a.inv_n : 0.0f;
-  const bool ext_l = WIDE && lane == 0 && gx0 > 0 && col_live, ext_r = WIDE && lane == 63 && gx0 + 4 < a.W;
   float red0 = 0.0f;
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
@@ -292,9 +283,7 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
       const int y = y0 - 1 + k;
       const bool in = col_live && y >= 0 && y < a.H;
       const float* ce = xr[k + 1];
-      float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
-      if (ext_l && in) L = xp[(unsigned)y * (unsigned)a.W + (unsigned)gx0 - 1];
-      if (ext_r && in) R = xp[(unsigned)y * (unsigned)a.W + (unsigned)gx0 + 4];
+      const float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
@@ -303,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
         const float gz = a.target ? sign_of(clamp01(z) - g[k][i]) * gs : g[k][i];
         const float dz = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
         g[k][i] = dz;
-        if (k >= 1 && k <= kStripRows) red0 += dz * d;
+        if (k >= 1 && k <= kStripRows && own) red0 += dz * d;
       }
     }
     // gimg rows y0 .. y0+kStripRows-1
@@ -311,16 +300,14 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
     for (int k = 1; k <= kStripRows; ++k) {
       const int y = y0 - 1 + k;
       const float* ce = g[k];
-      float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
-      if (ext_l) L = sharp_dz_at(a, xp, gp, y, gx0 - 1, p, gs);
-      if (ext_r) R = sharp_dz_at(a, xp, gp, y, gx0 + 4, p, gs);
+      const float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
         o[i] = ce[i] + p * sharp_delta(ce[i], g[k - 1][i], left, right, g[k + 1][i]);
       }
-      if (a.gimg && col_live && y < a.H)
+      if (a.gimg && own && col_live && y < a.H)
         store_vec<4>(a.gimg + ((size_t)b * 3 + c) * hw + (unsigned)y * (unsigned)a.W + (unsigned)gx0, o);
     }
   }
@@ -794,7 +781,7 @@ void launch_sharp_fwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
 }
 void launch_sharp_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
   if (sharp_bwd_uses_strips(a, g)) {
-    const int nseg = (a.W + 255) / 256, nblk = g.nblk_strip_bwd;
+    const int nseg = strip_bwd_segments(a.W), nblk = g.nblk_strip_bwd;
     const unsigned grid = (unsigned)a.B * nblk;
     const bool dyn = a.op == OP_DYNAMIC;
     if (nseg > 1) { if (dyn) k_sharp_bwd_strip<true, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); else k_sharp_bwd_strip<false, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
