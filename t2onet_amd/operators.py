@@ -76,8 +76,9 @@ class Operator(nn.Module):
         param = self.extract_parameters(features) if features is not None else specified_param
         if has_noise:                                                    # operators.py:118-121
             param = torch.clamp(param + self.get_param_noise(img.shape[0]).to(img.device), self.lb, self.ub)
-        self.param = param
-        self.mask = mask
+        # the reference's side effects (operators.py:122,125); plain attributes, so skip nn.Module.__setattr__
+        self.__dict__['param'] = param
+        self.__dict__['mask'] = mask
         return T.operator_apply(self.op_index, img, param, mask)
 
 
