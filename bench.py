@@ -326,7 +326,7 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
     if dist is not None:                                   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    tr = Trainer(model, opt)
+    tr = Trainer(model, opt, graph_encoder=os.environ.get('T2O_GRAPH_ENCODER', '1') != '0')
     g = torch.Generator().manual_seed(10)
     img = torch.rand(B, 3, H, W, generator=g).to(device)
     tgt = torch.rand(B, 3, H, W, generator=g).to(device)
@@ -347,6 +347,7 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.episode_step(x, img, tgt, lengths=lengths)
+    t_enq = time.perf_counter() - t0                       # host time to enqueue (includes the step's own host syncs)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -357,6 +358,7 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return {'images_per_sec': round(world * B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 2),
+            'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 2),
             'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()),
             'workload': 'episode/L1 train step (train_seq2seqL1.py:74-88), bs=%d/GPU %dx%d fp32, sampled ops, '
                         'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world)}

@@ -9,6 +9,7 @@
  *                                 :571-585 :607-616
  *     L1 step                     experiments/t2onet/train_seq2seqL1.py:78-85
  *     Attention.forward           models/attention.py:37-40 (score / softmax / mix)
+ *     BatchNorm2d + add + ReLU    models/actor_resnet.py:38-44, :99-100 (training mode)
  * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
  *
  * Conventions
@@ -145,6 +146,26 @@ int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix,
 /* gmix (B,D), gattn (B,L) nullable -> gq (B,D), gctx (B,L,D) */
 int t2o_attn_bwd(const float* q, const float* ctx, const float* attn, const float* gmix,
                  const float* gattn, float* gq, float* gctx, int B, int L, int D, void* stream);
+
+/* ---- training-mode BatchNorm2d fused with the residual add and ReLU that follow it in the image
+ * encoder: models/actor_resnet.py:38-44 (BasicBlock.forward: relu(bn1(conv1(x))), relu(bn2(conv2(.)) +
+ * shortcut(x))) and :99-100 (stem).  x, res, out: (N,C,H*W) contiguous NCHW; HW = H*W.
+ *   out = max((x - mean_c) * invstd_c * weight_c + bias_c (+ res), 0), batch statistics per channel
+ *   (biased variance), running_mean / running_var (nullable, both or neither) updated in place with
+ *   `momentum` and the unbiased variance, as torch.nn.BatchNorm2d in training mode.
+ * save_mean / save_invstd (C) are written for the backward.  workspace: t2o_bn_workspace_bytes(N, C). */
+size_t t2o_bn_workspace_bytes(int N, int C);
+int t2o_bn_relu_fwd(const float* x, const float* res, const float* weight, const float* bias,
+                    float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* out,
+                    float momentum, float eps, void* workspace, size_t workspace_bytes,
+                    int N, int C, int HW, void* stream);
+/* dy = gradient w.r.t. out.  has_res = 1: a residual was added (y = the forward's out is needed for the ReLU
+ * mask; dres (nullable) receives the residual's gradient); has_res = 0: the mask is recomputed from x, y may
+ * be NULL.  dx (N,C,HW), dweight / dbias (C, nullable). */
+int t2o_bn_relu_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
+                    const float* save_mean, const float* save_invstd, float* dx, float* dres,
+                    float* dweight, float* dbias, int has_res, void* workspace, size_t workspace_bytes,
+                    int N, int C, int HW, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ c_i = ctypes.POINTER(ctypes.c_int)
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _Z = ctypes.c_size_t
+_F = ctypes.c_float
 
 # name -> (restype, argtypes); must list every function declared in include/t2onet_hip.h
 SIGNATURES = {
@@ -43,6 +44,9 @@ SIGNATURES = {
     't2o_ssim_fwd': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     't2o_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     't2o_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    't2o_bn_workspace_bytes': (_Z, [_I, _I]),
+    't2o_bn_relu_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _Z, _I, _I, _I, _P]),
+    't2o_bn_relu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
 }
 
 _lib = None

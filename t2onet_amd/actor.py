@@ -45,6 +45,16 @@ def _vocab_sizes(opt):
         return opt.input_vocab_size, opt.output_vocab_size
 
 
+def sample_categorical(probs):
+    """One draw per row from unnormalised non-negative weights (B,K) -> (B,1) int64: what
+    Categorical(probs).sample() returns (actor.py:229), by inverse CDF.  torch.multinomial (and
+    Categorical's argument validation) check their input with a host synchronisation per call; this does not."""
+    cdf = probs.cumsum(1)
+    u = torch.rand(probs.shape[0], 1, device=probs.device, dtype=probs.dtype) * cdf[:, -1:]
+    idx = (cdf <= u).sum(1, keepdim=True)                    # first index whose cumulative weight exceeds u
+    return torch.where(idx >= probs.shape[1], probs.argmax(1, keepdim=True), idx)
+
+
 class Actor(nn.Module):
     def __init__(self, opt, word2vec=None):
         super().__init__()
@@ -62,6 +72,8 @@ class Actor(nn.Module):
         self.null_id, self.start_id, self.end_id = opt.null_id, opt.start_id, opt.end_id
         self.executor = Executor(opt)
         self.bn1 = nn.BatchNorm1d(512)
+        # OP_MASK on the device (not in the state_dict): building it per call is a blocking host-to-device copy
+        self.register_buffer('_op_mask_row', torch.tensor(OP_MASK, dtype=torch.float).view(1, -1), persistent=False)
 
     # ------------------------------------------------------------------ helpers
     def use_channels_last(self, on=True):
@@ -71,11 +83,40 @@ class Actor(nn.Module):
         self.vis_encoder.to(memory_format=torch.channels_last if on else torch.contiguous_format)
         return self
 
-    def image_features(self, img):
+    def image_features(self, img, call=None):
+        """relu(bn1(vis_encoder(img))) (actor.py:142-143, :215-216).  `call` = index of this encoder call
+        inside the step (0, 1, ...): selects the captured hipGraph of that call when graph_image_encoder()
+        has been run for this image shape."""
         if getattr(self, '_nhwc', False):
             # the operators work on NCHW planes; give MIOpen a packed NHWC copy (12 B/pixel, once per step)
             img = img.contiguous(memory_format=torch.channels_last)
-        return F.relu(self.bn1(self.vis_encoder(img)))                 # actor.py:142-143, :215-216
+        graphed = self.__dict__.get('_graphed_encoders')
+        if (graphed is not None and call is not None and call < len(graphed) and self.training
+                and tuple(img.shape) == self.__dict__['_graphed_shape'] and torch.is_grad_enabled()):
+            return F.relu(self.bn1(graphed[call](img)))
+        return F.relu(self.bn1(self.vis_encoder(img)))
+
+    def graph_image_encoder(self, sample_img, calls):
+        """Capture the image encoder's forward and backward as hipGraphs, one pair per encoder call of a
+        step (the activations of all `calls` forwards are alive until the backward, so every call needs its
+        own graph memory).  ~350 kernel launches per encoder forward+backward become 2 graph launches: the
+        train step is host-bound otherwise.  Training mode, fixed (B,3,H,W); anything else runs eagerly.
+        The wrappers share vis_encoder's parameters and are not registered as submodules (state_dict and
+        parameters() are unchanged)."""
+        class _Call(nn.Module):
+            def __init__(self, enc):
+                super().__init__()
+                self.enc = enc
+
+            def forward(self, img):
+                return self.enc(img)
+
+        wrappers = tuple(_Call(self.vis_encoder).train() for _ in range(calls))
+        samples = tuple((sample_img.detach().clone().requires_grad_(k > 0),) for k in range(calls))
+        graphed = torch.cuda.make_graphed_callables(wrappers, samples)
+        self.__dict__['_graphed_encoders'] = graphed
+        self.__dict__['_graphed_shape'] = tuple(sample_img.shape)
+        return self
 
     def get_gt_mask(self, img, mask_dict, op):
         """Per-sample local-edit masks (actor.py:78-98): mask_dict[i] maps an operator id (as a
@@ -116,7 +157,7 @@ class Actor(nn.Module):
         pred_params, pred_imgs, logprobs = [], [], []
         ops = y[:, 0].unsqueeze(-1)
         for i in range(1, step):
-            feat = self.image_features(img_x)
+            feat = self.image_features(img_x, i - 1)
             logp, hidden, _, context = self.decoder.forward_step(ops, hidden, enc_out, feat)
             logprobs.append(logp)
             ops = y[:, i].unsqueeze(-1)
@@ -136,11 +177,11 @@ class Actor(nn.Module):
         enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
         hidden = self.decoder._init_state(enc_hidden)
         hiddens = [tuple(h.detach() for h in hidden)]
-        op_mask = torch.tensor(OP_MASK, dtype=torch.float, device=dev).repeat(B, 1)
+        op_mask = self._op_mask_row.repeat(B, 1)                # device-resident: no host-to-device copy (a sync)
         pred_op = torch.full((B, 1), self.start_id, dtype=torch.long, device=dev)
         pred_ops, pred_params, pred_imgs, pred_masks = [], [], [], []
-        for _ in range(self.opt.decoder_max_len):
-            feat = self.image_features(img_x)
+        for call in range(self.opt.decoder_max_len):
+            feat = self.image_features(img_x, call)
             logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
             hiddens.append(tuple(h.detach() for h in hidden))
             probs = torch.exp(logp).squeeze(1)
@@ -148,7 +189,7 @@ class Actor(nn.Module):
             probs = probs * op_mask
             probs = probs / (probs.sum(1, keepdim=True) + 1e-30)
             if reinforce_sample:
-                pred_op = torch.distributions.Categorical(probs=probs).sample().view(B, -1)
+                pred_op = sample_categorical(probs)
             else:
                 pred_op = probs.topk(1)[1].view(B, -1)
             op_mask.scatter_(1, pred_op, 0.0)              # an operator is used at most once
@@ -175,13 +216,13 @@ class Actor(nn.Module):
         B = img_x.shape[0]
         with torch.no_grad():
             enc_out, _, _ = self.lang_encoder(x, lengths)
-        op_mask = torch.tensor(OP_MASK, dtype=torch.float, device=img_x.device).repeat(B, 1)
+        op_mask = self._op_mask_row.repeat(B, 1)
         logp, dec_hidden, _, context = self.decoder.forward_step(op, hidden, enc_out, self.image_features(img_x))
         entropy_penalty = self.get_entropy_penalty(logp)
         probs = torch.exp(logp).squeeze(1) * (1 - self.opt.explore_prob) + self.opt.explore_prob
         probs = probs * op_mask
         probs = probs / (probs.sum(1, keepdim=True) + 1e-30)
-        pred_op = torch.distributions.Categorical(probs=probs).sample().view(B, -1)
+        pred_op = sample_categorical(probs)
         pred_mask = self.get_gt_mask(img_x, mask_dict, pred_op.detach().cpu().numpy()) if mask_dict is not None else None
         pred_img, _ = self._execute(img_x, pred_op, context, pred_mask)
         _, _, _, next_context = self.decoder.forward_step(pred_op, dec_hidden, enc_out, self.image_features(pred_img))

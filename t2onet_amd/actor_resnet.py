@@ -1,9 +1,26 @@
 """Image encoder of the actor (models/actor_resnet.py): ResNet-18 layout with a 3x3 stride-2
 stem, no max-pool, every stage stride 2 (/32), global mean, fc.  The only dense contraction of
-the hot path: convolutions go to MIOpen (MFMA) through PyTorch-ROCm; nothing here is
-hand-written.  Module names follow the reference so its checkpoints load."""
+the hot path: convolutions go to MIOpen (MFMA) through PyTorch-ROCm.  The HBM-bound passes between
+them -- training-mode batch norm, residual add, ReLU -- are one fused HIP statistics pass + one fused
+apply pass (t2o_bn_relu_fwd / _bwd); evaluation mode and CPU tensors take PyTorch's own batch norm.
+Module names follow the reference so its checkpoints load."""
+import os
+
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import functional as T
+
+
+_FUSED = os.environ.get('T2O_FUSED_BN', '1') != '0'      # 0: PyTorch's batch norm everywhere (A/B timing)
+
+
+def _bn_relu(bn, x, residual=None):
+    """relu(bn(x) (+ residual)): fused kernels in training mode on the GPU."""
+    if _FUSED and bn.training and x.is_cuda:
+        return T.batch_norm_relu(x, bn, residual)
+    out = bn(x)
+    return F.relu(out if residual is None else out + residual)
 
 
 class BasicBlock(nn.Module):
@@ -20,9 +37,8 @@ class BasicBlock(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
     def forward(self, x):
-        out = F.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return F.relu(out + self.shortcut(x))
+        out = _bn_relu(self.bn1, self.conv1(x))
+        return _bn_relu(self.bn2, self.conv2(out), self.shortcut(x))
 
 
 class ResNet(nn.Module):
@@ -47,7 +63,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x):
-        x = F.relu(self.bn1(self.conv1(x)))
+        x = _bn_relu(self.bn1, self.conv1(x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = x.mean((2, 3))
         return self.fc(x.view(x.size(0), -1))

@@ -25,6 +25,10 @@ int fail(int code, const char* msg) {
   return code;
 }
 
+}  // namespace
+namespace t2o { int set_error(int code, const char* msg) { return fail(code, msg); } }   // for t2o_norm.hip
+namespace {
+
 // ------------------------------------------------------------------ device helpers
 // Sum over the 64 lanes, returned in every lane.  Pure VALU: an inclusive scan inside each 16-lane
 // row by DPP row shifts (1, 2, 4, 8), row_bcast:15 / row_bcast:31 to fold the four rows, then a

@@ -214,6 +214,69 @@ def attention_core(q, context):
     return _AttnFn.apply(q, context)
 
 
+class _BnReluFn(torch.autograd.Function):
+    """relu(batch_norm(x) (+ res)) with batch statistics (training mode), running stats updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, momentum, eps):
+        _need_gpu(x, res, weight, bias)
+        x = x.contiguous()
+        res = None if res is None else res.contiguous()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        lib = _lib.load()
+        out = torch.empty_like(x)
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bn_workspace(lib, N, C, x.device)
+        rc = lib.t2o_bn_relu_fwd(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                 _ptr(save_mean), _ptr(save_invstd), _ptr(out), float(momentum), float(eps),
+                                 _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
+        _lib.check(rc, 't2o_bn_relu_fwd')
+        ctx.save_for_backward(x, out if res is not None else None, weight, bias, save_mean, save_invstd)
+        ctx.has_res = res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res and ctx.needs_input_grad[1] else None
+        dweight = torch.empty_like(weight)
+        dbias = torch.empty_like(bias)
+        ws = _bn_workspace(lib, N, C, x.device)
+        rc = lib.t2o_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean), _ptr(save_invstd),
+                                 _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), 1 if ctx.has_res else 0,
+                                 _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
+        _lib.check(rc, 't2o_bn_relu_bwd')
+        return dx, dres, dweight, dbias, None, None, None, None
+
+
+_bn_ws = {}
+
+
+def _bn_workspace(lib, N, C, device):
+    key = (device.index, _stream(device), N, C)
+    ws = _bn_ws.get(key)
+    if ws is None:
+        ws = _bn_ws[key] = torch.empty(lib.t2o_bn_workspace_bytes(N, C), dtype=torch.uint8, device=device)
+    return ws
+
+
+def batch_norm_relu(x, bn, residual=None):
+    """relu(bn(x) (+ residual)) for a torch.nn.BatchNorm2d `bn` in TRAINING mode on the GPU: batch
+    statistics, running statistics and num_batches_tracked updated as nn.BatchNorm2d does
+    (models/actor_resnet.py:38-44, :99-100).  One statistics pass + one fused normalise/add/ReLU pass."""
+    if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+        raise NotImplementedError('batch_norm_relu: affine BatchNorm2d with running statistics and a fixed momentum only')
+    bn.num_batches_tracked.add_(1)
+    return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+
+
 class _SequenceFn(torch.autograd.Function):
     """A known operator list with every intermediate materialised + L1 on the last output."""
 

@@ -61,10 +61,15 @@ class RNNEncoder(nn.Module):
         dev = input_labels.device
         if lengths is None:
             lengths = (input_labels != self.pad_id).sum(dim=1).cpu()
-        by_length = torch.argsort(lengths, descending=True, stable=False)
-        undo = torch.argsort(by_length).to(dev)
+        # the same STABLE descending order computed twice -- on the host for pack_padded_sequence's lengths,
+        # on the device for the gathers -- instead of copying the permutation to the device (a blocking copy
+        # that drains the GPU queue at the top of every step)
+        by_length = torch.argsort(lengths, descending=True, stable=True)
+        dev_lengths = (input_labels != self.pad_id).sum(dim=1) if lengths.device != dev else lengths
+        by_length_dev = torch.argsort(dev_lengths, descending=True, stable=True)
+        undo = torch.argsort(by_length_dev)
         longest = int(lengths[by_length[0]])
-        ordered = input_labels[by_length.to(dev), :longest]
+        ordered = input_labels[by_length_dev, :longest]
         embedded = self.input_dropout(self.embedding(ordered))
         packed = pack_padded_sequence(embedded, lengths[by_length], batch_first=True)
         packed_out, state = self.rnn(packed)

@@ -49,11 +49,22 @@ class FlatGradients:
 class Trainer:
     """Drives the reference's alternation: odd iterations supervised, even iterations episode/L1."""
 
-    def __init__(self, model, opt, lr=None):
+    def __init__(self, model, opt, lr=None, graph_encoder=False):
+        """graph_encoder: capture the image encoder's forward/backward as hipGraphs on the first step (fixed
+        batch and image size from then on; other shapes run eagerly) -- see Actor.graph_image_encoder."""
         self.model, self.opt = model, opt
         self.grads = FlatGradients(model.parameters())
         self.optimizer = torch.optim.Adam(self.grads.params, lr=lr if lr is not None else opt.learning_rate)
         self.itr = 0
+        self.graph_encoder = graph_encoder
+
+    def _maybe_graph(self, img):
+        if self.graph_encoder and img.is_cuda and '_graphed_encoders' not in self.model.__dict__:
+            self.model.train()
+            self.model.graph_image_encoder(img, self.opt.decoder_max_len)
+            # capture ran warm-up forwards/backwards: drop what they left in the gradient buffer and undo
+            # nothing else -- batch-norm running statistics saw a few extra batches of this same image
+            self.grads.zero()
 
     def _finish(self, loss):
         self.grads.zero()
@@ -64,6 +75,7 @@ class Trainer:
     def supervised_step(self, x, y, img_x, img_y, gt_params, lengths=None):
         """train_seq2seqL1.py:51-65: NLL (mean, no ignore_index) + MSE(sum)/count_nonzero."""
         step = int((y != self.opt.null_id).sum(1).max())
+        self._maybe_graph(img_x)
         _, pred_params, logp = self.model.supervised_forward(x, y, img_x, img_y, gt_params, None, lengths)
         target = y[:, 1:step].contiguous().view(-1)
         op_loss = F.nll_loss(logp.reshape(-1, logp.shape[-1]), target)
@@ -74,6 +86,7 @@ class Trainer:
 
     def episode_step(self, x, img_x, target, reinforce_sample=1, lengths=None):
         """train_seq2seqL1.py:74-88: free-running episode, L1 between the END image and the target."""
+        self._maybe_graph(img_x)
         _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths)
         pred = select_end_images(pred_imgs, pred_ops, self.opt.end_id)
         loss = T.l1_loss(pred, target)

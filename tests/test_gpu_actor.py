@@ -180,3 +180,55 @@ def test_episode_with_local_edit_masks():
         assert torch.allclose(imgs1[b, 0], want, atol=1e-6)
     for b in (1, 3):
         assert torch.equal(imgs1[b, 0], imgs0[b, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 8, 6, 6), (2, 64, 16, 16), (3, 5, 5, 5), (64, 64, 32, 32)])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_fused_batchnorm_relu_matches_torch(shape, with_res):
+    """t2o_bn_relu_fwd / _bwd (training-mode BatchNorm2d + residual add + ReLU of the image encoder,
+    models/actor_resnet.py:38-44) against PyTorch's own batch norm in fp64 on the CPU: output,
+    running statistics, num_batches_tracked and every gradient."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import t2onet_amd.functional as T
+    from oracle import synth
+    dev = torch.device('cuda:0')
+    N, C, H, W = shape
+    x = synth.uniform(shape, 301, -2.0, 3.0)
+    res = synth.uniform(shape, 302, -1.0, 1.0) if with_res else None
+    gout = synth.uniform(shape, 303, -1.0, 1.0)
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(synth.uniform((C,), 304, 0.5, 1.5))
+        bn.bias.copy_(synth.uniform((C,), 305, -0.5, 0.5))
+        bn.running_mean.copy_(synth.uniform((C,), 306, -0.1, 0.1))
+        bn.running_var.copy_(synth.uniform((C,), 307, 0.5, 1.5))
+    import copy
+    ref = copy.deepcopy(bn).double().train()
+    x64 = x.double().requires_grad_(True)
+    r64 = None if res is None else res.double().requires_grad_(True)
+    pre = ref(x64)
+    y_ref = F.relu(pre if r64 is None else pre + r64)
+    y_ref.backward(gout.double())
+
+    g = copy.deepcopy(bn).to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    rg = None if res is None else res.to(dev).requires_grad_(True)
+    y = T.batch_norm_relu(xg, g, rg)
+    y.backward(gout.to(dev))
+    # elements whose pre-activation is within rounding of 0 may take the other ReLU branch
+    safe = (pre if r64 is None else pre + r64).detach().abs() > 1e-5
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().float().numpy(), rtol=1e-5, atol=2e-6)
+    assert bool(safe.float().mean() > 0.999)
+    np.testing.assert_allclose(g.running_mean.cpu().numpy(), ref.running_mean.float().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g.running_var.cpu().numpy(), ref.running_var.float().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(g.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    scale = float(x64.grad.abs().max())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), x64.grad.float().numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(g.weight.grad.cpu().numpy(), ref.weight.grad.float().numpy(), rtol=1e-4,
+                               atol=1e-5 * float(ref.weight.grad.abs().max()))
+    np.testing.assert_allclose(g.bias.grad.cpu().numpy(), ref.bias.grad.float().numpy(), rtol=1e-4,
+                               atol=1e-5 * float(ref.bias.grad.abs().max()))
+    if with_res:
+        np.testing.assert_allclose(rg.grad.cpu().numpy(), r64.grad.float().numpy(), rtol=0, atol=1e-6)
