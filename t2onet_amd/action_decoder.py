@@ -6,8 +6,8 @@ the sub-module names (`embedding`, `rnn`, `out_linear`, `vis_linear`, `attention
 
 Per step:  [operator embedding (300) | relu(vis_linear(image feature)) (512)]  ->  2-layer LSTM
 (812 -> 512)  ->  dot-product attention over the request encoding (HIP kernel, attention.py)
-->  out_linear  ->  log-softmax over the 11 operator tokens.  The LSTM and the Linear layers are
-library GEMMs (MIOpen / hipBLASLt through PyTorch-ROCm).
+->  out_linear  ->  log-softmax over the 11 operator tokens.  The LSTM cell and the Linear layers are
+library GEMMs (hipBLASLt through PyTorch-ROCm) plus PyTorch's fused gate kernel.
 """
 import torch
 import torch.nn as nn
@@ -47,12 +47,32 @@ class Decoder(nn.Module):
         token = self.embedding(input_var)                                   # (B,1,300)
         visual = F.relu(self.vis_linear(img_feat)).unsqueeze(1)            # (B,1,d)
         step_in = self.input_dropout(torch.cat((token, visual), dim=2))
-        context, hidden = self.rnn(step_in, hidden)
+        context, hidden = self._rnn_step(step_in, hidden)
         attn = None
         if self.use_attention:
             context, attn = self.attention(context, encoder_outputs)
         scores = self.out_linear(context.reshape(n, self.hidden_size))
         return F.log_softmax(scores, dim=-1).view(n, 1, -1), hidden, attn, context.squeeze(1)
+
+    def _rnn_step(self, step_in, hidden):
+        """One decoding step of self.rnn.  For the LSTM this is num_layers fused cell calls (two GEMMs + one
+        gate kernel each, the arithmetic of nn.LSTM on a length-1 sequence) instead of the library's sequence
+        entry point, whose per-call host cost (~1.8 ms forward, more backward: descriptors, workspaces) made
+        the five decoder steps the largest host-side item of the train step."""
+        rnn = self.rnn
+        if not (isinstance(rnn, nn.LSTM) and step_in.shape[1] == 1 and isinstance(hidden, tuple)
+                and not rnn.bidirectional and rnn.proj_size == 0 and (rnn.dropout == 0 or not self.training)):
+            return rnn(step_in, hidden)
+        h0, c0 = hidden
+        x = step_in[:, 0]
+        hs, cs = [], []
+        for layer in range(rnn.num_layers):
+            w = [getattr(rnn, '%s_l%d' % (name, layer)) for name in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')] \
+                if rnn.bias else [getattr(rnn, 'weight_ih_l%d' % layer), getattr(rnn, 'weight_hh_l%d' % layer), None, None]
+            x, c = torch._VF.lstm_cell(x, (h0[layer], c0[layer]), w[0], w[1], w[2], w[3])
+            hs.append(x)
+            cs.append(c)
+        return x.unsqueeze(1), (torch.stack(hs, 0), torch.stack(cs, 0))
 
     def _init_state(self, encoder_hidden):
         """Encoder final state -> decoder initial state."""
