@@ -40,6 +40,14 @@ def test_argument_validation_without_a_device(lib):
     assert lib.t2o_op_fwd(0, p, p, 1, p, 2, p, 1, 4, 4, None) == 1             # mask_ch must be 1 or 3
     assert lib.t2o_op_bwd(0, p, p, 1, None, 0, p, p, p, 1, None, 0, 1, 4, 4, None) == 3   # no workspace
     assert lib.t2o_attn_fwd(p, p, p, p, 1, 65, 64, None) == 1
+    # fused batch norm: null tensors, one running statistic without the other, missing workspace / ReLU mask source
+    assert lib.t2o_bn_workspace_bytes(64, 64) > 0
+    assert lib.t2o_bn_relu_fwd(None, None, p, p, p, p, p, p, p, 0.1, 1e-5, p, 1 << 20, 2, 4, 16, None) == 1
+    assert b'bn_relu_fwd' in lib.t2o_last_error()
+    assert lib.t2o_bn_relu_fwd(p, None, p, p, p, None, p, p, p, 0.1, 1e-5, p, 1 << 20, 2, 4, 16, None) == 1
+    assert lib.t2o_bn_relu_fwd(p, None, p, p, p, p, p, p, p, 0.1, 1e-5, None, 0, 2, 4, 16, None) == 3
+    assert lib.t2o_bn_relu_bwd(p, None, p, p, p, p, p, p, None, p, p, 1, p, 1 << 20, 2, 4, 16, None) == 1   # has_res needs y
+    assert lib.t2o_bn_relu_bwd(p, p, p, p, p, p, p, p, None, p, p, 0, None, 0, 2, 4, 16, None) == 3
 
 
 def test_python_surface_mirrors_reference():
