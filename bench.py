@@ -326,7 +326,12 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
     if dist is not None:                                   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    tr = Trainer(model, opt, graph_encoder=os.environ.get('T2O_GRAPH_ENCODER', '1') != '0')
+    # hipGraph capture of the image encoder: on for the single-process run.  With a process group alive the
+    # RCCL watchdog thread can touch the device during a (global-mode) capture and invalidate it on one rank
+    # only, which would leave the other ranks waiting in the gradient all-reduce -- not worth risking in a
+    # benchmark that cannot be rehearsed on this pool; T2O_GRAPH_ENCODER=1 forces it.
+    want_graph = os.environ.get('T2O_GRAPH_ENCODER', '1' if dist is None else '0') != '0'
+    tr = Trainer(model, opt, graph_encoder=want_graph)
     g = torch.Generator().manual_seed(10)
     img = torch.rand(B, 3, H, W, generator=g).to(device)
     tgt = torch.rand(B, 3, H, W, generator=g).to(device)

@@ -18,7 +18,8 @@ import bench  # noqa: E402
 from t2onet_amd import _lib  # noqa: E402
 
 LISTS = [[0], [1], [2], [3], [5], [0, 0], [1, 1], [2, 2], [3, 3], [5, 5], [0, 1, 2, 3, 5], [5, 3, 2, 1, 0],
-         [0, 1, 2], [3, 5], [0, 0, 0, 0, 0, 0, 0, 0], [5, 5, 5, 5, 5, 5, 5, 5]]
+         [0, 1, 2], [3, 5], [0, 0, 0, 0, 0, 0, 0, 0], [5, 5, 5, 5, 5, 5, 5, 5],
+         [5, 3, 5, 3, 0, 1, 2]]          # the per-pixel run of BASELINE configs[4]
 
 
 def main():
