@@ -382,6 +382,7 @@ def main():
                     help='also time this many full episode/L1 train steps (BASELINE configs[2]/[3], with the flat '
                          'gradient all-reduce when N > 1) -> "train_step"; 0 to skip')
     ap.add_argument('--train-warmup', type=int, default=2)
+    ap.add_argument('--train-timeout', type=int, default=420, help='seconds before the train-step leg is abandoned')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -450,14 +451,9 @@ def main():
         api = {'error': '%s: %s' % (type(e).__name__, e)}
     torch.cuda.empty_cache()
 
-    train = None
-    if args.train_steps > 0:
-        try:                                   # secondary measurement: never let it take the headline line down
-            train = train_step_bench(device, dist, world, B, H, W, args.train_steps, args.train_warmup)
-        except Exception as e:                 # noqa: BLE001
-            train = {'error': '%s: %s' % (type(e).__name__, e)}
-
-    if rank == 0:
+    def emit(train):
+        if rank != 0:
+            return
         ms_per_step = elapsed / args.steps * 1e3
         n_gpus = world
         line = {
@@ -504,6 +500,27 @@ def main():
         if not args.no_cpu_baseline and n_gpus == 1:
             line['cpu_baseline'] = cpu_baseline(args.cpu_sample, H, W)
         print(json.dumps(line))
+
+    train = None
+    if args.train_steps > 0:
+        # secondary measurement: it must never take the headline line down.  Exceptions are reported in the
+        # line; a hang (e.g. one rank failing inside a collective) is cut by an alarm that still prints the line.
+        # (a timer THREAD: a signal handler would not run while the main thread sits in a blocking device call)
+        import threading
+
+        def on_timeout():
+            emit({'error': 'train step did not finish within %d s' % args.train_timeout})
+            sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.train_timeout, on_timeout)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            train = train_step_bench(device, dist, world, B, H, W, args.train_steps, args.train_warmup)
+        except Exception as e:                 # noqa: BLE001
+            train = {'error': '%s: %s' % (type(e).__name__, e)}
+        watchdog.cancel()
+    emit(train)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
