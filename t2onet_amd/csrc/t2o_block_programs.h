@@ -88,6 +88,66 @@ T2O_HD void store_vec(float* p, const float (&r)[V]) {
 
 T2O_HD float sign_of(float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); }
 
+// ===================================================================== curve lookup table
+// Curves use a per-sample table (in LDS on the device): knots k[c][8], running sums
+// P[c][j] = sum_{i<j} k_i/8 accumulated in the reference's order, sum[c], scale[c] and 1/sum[c].  For a
+// pixel value x in segment i* = floor(8x):  total = P[i*] + clamp(x - i*/8, 0, 1/8) * k[i*]  -- bit-identical
+// to the reference's 8-term loop (the terms before i* are exactly k_i/8, the ones after are exactly 0), at
+// a quarter of the arithmetic.  Used by the fused chain kernels and by the single-operator backward.
+constexpr int kTabStride = 64;           // floats per operator table
+constexpr int kTabK = 0, kTabP = 24, kTabSum = 51, kTabScale = 54, kTabRsum = 57;
+
+// p = the operator's parameter row (8 knots, or 3 x 8 for the color curve); one thread builds the table
+T2O_HD void curve_table_build(const float* p, bool color, float* t) {
+  for (int c = 0; c < 3; ++c) {
+    const float* row = color ? p + c * kCurveSteps : p;
+    float s = 0.0f, run = 0.0f;
+    for (int i = 0; i < kCurveSteps; ++i) {
+      t[kTabK + c * kCurveSteps + i] = row[i];
+      t[kTabP + c * (kCurveSteps + 1) + i] = run;
+      run = run + (1.0f / kCurveSteps) * row[i];
+      s = s + row[i];
+    }
+    t[kTabP + c * (kCurveSteps + 1) + kCurveSteps] = run;
+    s = s + 1e-10f;
+    t[kTabSum + c] = s;
+    t[kTabRsum + c] = 1.0f / s;
+    t[kTabScale + c] = t[kTabRsum + c] * (float)kCurveSteps;
+  }
+}
+
+// segment index and clamped offset inside it
+T2O_HD void curve_locate(float x, int& i, float& frac) {
+  const float x8 = fminf(fmaxf(x * (float)kCurveSteps, 0.0f), (float)kCurveSteps - 0.5f);
+  i = (int)x8;
+  frac = fminf(fmaxf(x - (float)i / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+}
+
+// pre-clamp output of a curve operator for channel c
+T2O_HD float curve_lut_fwd(const float* t, bool color, int c, float x) {
+  const int cc = color ? c : 0;
+  int i; float frac;
+  curve_locate(x, i, frac);
+  const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * t[kTabK + cc * kCurveSteps + i];
+  return color ? total * t[kTabScale + cc]
+               : div_by(total * (float)kCurveSteps, t[kTabSum + cc], t[kTabRsum + cc]);
+}
+
+// backward of one channel of a curve operator through the table: g = gradient w.r.t. the pre-clamp output
+// (already zero where the clamp was active); adds the raw sums red_row[j] += g * t_j (red_row = this
+// channel's 8 slots), returns the gradient w.r.t. x
+T2O_HD float curve_lut_bwd_1(const float* t, bool color, int c, float x, float g, float* red_row, bool first = false) {
+  const int cc = color ? c : 0;
+  const float* kk = t + kTabK + cc * kCurveSteps;
+  int i; float frac;
+  curve_locate(x, i, frac);
+  const float d = x - (float)i / kCurveSteps;
+  float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
+  if (d == 0.0f && i > 0) slope += kk[i - 1];                       // on a knot both neighbours pass (inclusive clamp)
+  curve_bins_accumulate(x, g, red_row, first);
+  return g * t[kTabScale + cc] * slope;
+}
+
 // ===================================================================== pointwise operators
 // Per-sample base pointers + 32-bit offsets inside the sample: keeps the address arithmetic in
 // a handful of scalar registers (a sample is < 2^31 floats).
@@ -161,8 +221,9 @@ T2O_HD float pointwise_fwd_thread(const OpArgs& a, int op, int b, int blk, int t
 
 // Backward: recompute the forward (for the clamp test), apply the closed-form
 // derivative, write gimg, accumulate raw parameter-gradient sums into red[].
+// `tab`: this sample's curve lookup table (curve_table_build), used when op is a curve operator.
 template <int V, bool MASKED, bool L1>
-T2O_HD void pointwise_bwd_thread(const OpArgs& a, int op, int b, int blk, int tid, float (&red)[kRedSlots]) {
+T2O_HD void pointwise_bwd_thread(const OpArgs& a, int op, int b, int blk, int tid, float (&red)[kRedSlots], const float* tab) {
   const unsigned hw = (unsigned)a.H * (unsigned)a.W;
   const unsigned groups = hw / V;
   const size_t sb = (size_t)b * 3 * hw;
@@ -173,8 +234,7 @@ T2O_HD void pointwise_bwd_thread(const OpArgs& a, int op, int b, int blk, int ti
   s.m = MASKED ? a.mask + (size_t)b * a.mask_ch * hw : nullptr;
   s.mstride = (MASKED && a.mask_ch == 3) ? hw : 0u;
   const float* prow = a.param ? a.param + (size_t)b * a.param_stride : nullptr;
-  Curve cv;
-  if (op == OP_COLOR || op == OP_TONE) curve_load(cv, prow, op == OP_COLOR);
+  Curve cv;                                    // (curve operators go through `tab`: cv stays unused there)
   float p0[1] = {(op >= 0 && prow) ? prow[0] : 0.0f};
   const float gs = L1 ? a.gloss[0] * a.inv_n : 0.0f;
   for (int it = 0; it < a.iters; ++it) {
@@ -198,13 +258,13 @@ T2O_HD void pointwise_bwd_thread(const OpArgs& a, int op, int b, int blk, int ti
         T2O_UNROLL
         for (int c = 0; c < 3; ++c) {
           const float xv = T2O_CHAIN(x[c][i], dep);
-          const float r = curve_fwd_1(cv, color, c, xv);
+          const float r = curve_lut_fwd(tab, color, c, xv);
           const float m = MASKED ? (s.mstride ? mk[c][i] : mk[0][i]) : 1.0f;
           const float z = MASKED ? blend(r, xv, m) : r;
           const float gz = L1 ? sign_of(clamp01(z) - gg[c][i]) * gs : gg[c][i];
           const float dz = (z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
           const int kc = color ? c : 0;
-          const float gi = curve_bwd_1(cv.k[kc], cv.scale[kc], xv, MASKED ? dz * m : dz, red + kc * kCurveSteps);
+          const float gi = curve_lut_bwd_1(tab, color, c, xv, MASKED ? dz * m : dz, red + kc * kCurveSteps);
           gx[c][i] = MASKED ? gi + dz * (1.0f - m) : gi;
           dep = gx[c][i];
           T2O_UNROLL
@@ -542,14 +602,8 @@ T2O_HD void sharp_bwd_phase_out(const OpArgs& a, int b, int tile, int tid, const
 // once, the K pointwise operators run in registers, the result is written once.  Sharpness
 // (a stencil) ends a chain segment; the host splits sequences at it (t2o_kernels.hip).
 //
-// Curves use a per-sample table in LDS: knots k[c][8], running sums P[c][j] = sum_{i<j} k_i/8
-// accumulated in the reference's order, sum[c] and scale[c].  For a pixel value x in segment
-// i* = floor(8x):  total = P[i*] + clamp(x - i*/8, 0, 1/8) * k[i*]  -- bit-identical to the
-// reference's 8-term loop (the terms before i* are exactly k_i/8, the ones after are exactly 0),
-// at a quarter of the arithmetic.
+// Curves go through the per-sample lookup table above (one table row per chain operator, in LDS).
 constexpr int kMaxChain = 8;
-constexpr int kTabStride = 64;           // floats per operator in the LDS table
-constexpr int kTabK = 0, kTabP = 24, kTabSum = 51, kTabScale = 54, kTabRsum = 57;
 constexpr int kAccStride = 65;           // floats per slot row of the LDS accumulators (64 quads + pad)
 
 struct ChainArgs {
@@ -579,38 +633,7 @@ T2O_HD void chain_build_table(const ChainArgs& a, int b, int k, float* tab) {
   const float* p = a.params + ((size_t)a.src[k] * a.B + b) * a.param_stride;
   const int op = a.ops[k];
   if (!is_curve(op)) { t[0] = p[0]; return; }
-  for (int c = 0; c < 3; ++c) {
-    const float* row = op == OP_COLOR ? p + c * kCurveSteps : p;
-    float s = 0.0f, run = 0.0f;
-    for (int i = 0; i < kCurveSteps; ++i) {
-      t[kTabK + c * kCurveSteps + i] = row[i];
-      t[kTabP + c * (kCurveSteps + 1) + i] = run;
-      run = run + (1.0f / kCurveSteps) * row[i];
-      s = s + row[i];
-    }
-    t[kTabP + c * (kCurveSteps + 1) + kCurveSteps] = run;
-    s = s + 1e-10f;
-    t[kTabSum + c] = s;
-    t[kTabRsum + c] = 1.0f / s;
-    t[kTabScale + c] = t[kTabRsum + c] * (float)kCurveSteps;
-  }
-}
-
-// segment index and clamped offset inside it
-T2O_HD void curve_locate(float x, int& i, float& frac) {
-  const float x8 = fminf(fmaxf(x * (float)kCurveSteps, 0.0f), (float)kCurveSteps - 0.5f);
-  i = (int)x8;
-  frac = fminf(fmaxf(x - (float)i / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
-}
-
-// pre-clamp output of a curve operator for channel c
-T2O_HD float curve_lut_fwd(const float* t, bool color, int c, float x) {
-  const int cc = color ? c : 0;
-  int i; float frac;
-  curve_locate(x, i, frac);
-  const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * t[kTabK + cc * kCurveSteps + i];
-  return color ? total * t[kTabScale + cc]
-               : div_by(total * (float)kCurveSteps, t[kTabSum + cc], t[kTabRsum + cc]);
+  curve_table_build(p, op == OP_COLOR, t);
 }
 
 // forward of chain operator `op` on one pixel (pre-clamp); t = this operator's table row
@@ -644,14 +667,7 @@ T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* r
   for (int c = 0; c < 3; ++c) {
     constexpr int kOne = COLOR ? 1 : 0;
     const int cc = c * kOne;                                         // static after unrolling
-    const float* kk = t + kTabK + cc * kCurveSteps;
-    int i; float frac;
-    curve_locate(x.c[c], i, frac);
-    const float d = x.c[c] - (float)i / kCurveSteps;
-    float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
-    if (d == 0.0f && i > 0) slope += kk[i - 1];                     // on a knot both neighbours pass (inclusive clamp)
-    gx.c[c] = dz.c[c] * t[kTabScale + cc] * slope;
-    curve_bins_accumulate(x.c[c], dz.c[c], red + cc * kCurveSteps, first && (COLOR || c == 0));
+    gx.c[c] = curve_lut_bwd_1(t, COLOR, c, x.c[c], dz.c[c], red + cc * kCurveSteps, first && (COLOR || c == 0));
   }
   return gx;
 }

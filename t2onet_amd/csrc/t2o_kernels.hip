@@ -129,16 +129,22 @@ __global__ __launch_bounds__(kThreads) void k_point_bwd(OpArgs a, int nblk) {
   float red[kRedSlots];
 #pragma unroll
   for (int i = 0; i < kRedSlots; ++i) red[i] = 0.0f;
+  __shared__ float tab[kTabStride];             // curve lookup table of this sample (curve operators only)
+  if (OP == OP_COLOR || OP == OP_TONE || OP == OP_DYNAMIC) {
+    if ((op == OP_COLOR || op == OP_TONE) && threadIdx.x == 0)
+      curve_table_build(a.param + (size_t)b * a.param_stride, op == OP_COLOR, tab);
+    __syncthreads();
+  }
   if (OP == OP_DYNAMIC) {
     switch (op) {
-#define T2O_CASE(K) case K: pointwise_bwd_thread<V, MASKED, L1>(a, K, b, blk, threadIdx.x, red); break;
+#define T2O_CASE(K) case K: pointwise_bwd_thread<V, MASKED, L1>(a, K, b, blk, threadIdx.x, red, tab); break;
       T2O_CASE(OP_BRIGHTNESS) T2O_CASE(OP_CONTRAST) T2O_CASE(OP_SATURATION) T2O_CASE(OP_COLOR)
       T2O_CASE(OP_TONE) T2O_CASE(OP_WHITE)
 #undef T2O_CASE
-      default: pointwise_bwd_thread<V, MASKED, L1>(a, OP_IDENTITY, b, blk, threadIdx.x, red); break;
+      default: pointwise_bwd_thread<V, MASKED, L1>(a, OP_IDENTITY, b, blk, threadIdx.x, red, tab); break;
     }
   } else {
-    pointwise_bwd_thread<V, MASKED, L1>(a, OP, b, blk, threadIdx.x, red);
+    pointwise_bwd_thread<V, MASKED, L1>(a, OP, b, blk, threadIdx.x, red, tab);
   }
   if (op == OP_IDENTITY || op == OP_WHITE) return;        // no parameter gradient (uniform per block)
   block_reduce_store(red, nred_of(op), a.partials + ((size_t)b * a.nblk_max + blk) * kRedSlots);

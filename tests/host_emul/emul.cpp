@@ -35,10 +35,12 @@ float point_fwd_block(const OpArgs& a, int op, int b, int blk) {
 }
 template <int V, bool M, bool L>
 void point_bwd_block(const OpArgs& a, int op, int b, int blk, float* sums) {
+  float tab[kTabStride] = {0.0f};               // the kernel builds this in LDS once per workgroup
+  if (op == OP_COLOR || op == OP_TONE) curve_table_build(a.param + (size_t)b * a.param_stride, op == OP_COLOR, tab);
   for (int tid = 0; tid < kThreads; ++tid) {
     float red[kRedSlots];
     for (int i = 0; i < kRedSlots; ++i) red[i] = 0.0f;
-    pointwise_bwd_thread<V, M, L>(a, op, b, blk, tid, red);
+    pointwise_bwd_thread<V, M, L>(a, op, b, blk, tid, red, tab);
     for (int i = 0; i < kRedSlots; ++i) sums[i] += red[i];
   }
 }
