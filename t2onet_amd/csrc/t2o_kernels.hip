@@ -854,10 +854,6 @@ int run_fwd(int op, const int* op_id, const float* img, const float* param, int 
   return check_launch("operator forward");
 }
 
-int run_curve_bwd_as_chain(int op, const float* img, const float* param, int param_stride, const float* gout,
-                           const float* target, const float* gloss, float* gimg, float* gparam, int gparam_stride,
-                           void* ws, int B, int H, int W, hipStream_t st);
-
 int run_bwd(int op, const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
             int mask_ch, const float* gout, const float* target, const float* gloss, float* gimg, float* gparam,
             int gparam_stride, void* ws, size_t ws_bytes, int B, int H, int W, void* stream,
@@ -893,14 +889,6 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
     else launch_sharp_bwd(a, g, st);
     if (nblk_out) *nblk_out = (op == OP_SHARPNESS) ? sharp_bwd_blocks(a, g) : g.nblk_point;
     return check_launch("operator backward");
-  }
-  if ((op == OP_COLOR || op == OP_TONE) && !mask && gparam) {
-    // curve operators can run as a one-operator chain (LDS curve lookup, clamp bits from the forward
-    // sweep).  T2O_CURVE_CHAIN: 0 = never (default: no faster than k_point_bwd at 4x pixels per thread), 1 = color only, 2 = both
-    static const int mode = env_int("T2O_CURVE_CHAIN", 0);
-    if (mode >= 2 || (mode == 1 && op == OP_COLOR))
-      return run_curve_bwd_as_chain(op, img, param, param_stride, gout, target, gloss, gimg, gparam, gparam_stride,
-                                    ws, B, H, W, st);
   }
   if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
   if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_bwd(a, g, st);
@@ -1080,28 +1068,6 @@ static int fused_chain_launch_bwd(ChainArgs& a, int vec, bool l1, hipStream_t st
   return 0;
 }
 
-}  // extern "C"  (helpers below live in the anonymous namespace)
-namespace {
-int run_curve_bwd_as_chain(int op, const float* img, const float* param, int param_stride, const float* gout,
-                           const float* target, const float* gloss, float* gimg, float* gparam, int gparam_stride,
-                           void* ws, int B, int H, int W, hipStream_t st) {
-  static const int forced = env_int("T2O_CHAIN_ITERS", 0);
-  int vec, iters, nblk;
-  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CURVE_CHAIN_VEC", 2));   // one operator: pixel pairs
-  Segment sg;
-  sg.first = 0; sg.count = 1; sg.sharp = false; sg.n = 1; sg.ops[0] = op; sg.src[0] = 0;
-  ChainArgs a;
-  memset(&a, 0, sizeof(a));
-  chain_fill(a, sg, B, H, W, iters, nblk);
-  a.param_stride = param_stride; a.gparam_stride = gparam_stride;
-  a.img = img; a.params = param; a.gimg = gimg; a.partials = (float*)ws;
-  if (target) { a.target = target; a.gloss = gloss; } else { a.gout = gout; }
-  fused_chain_launch_bwd(a, vec, target != nullptr, st);
-  k_chain_finalize<<<B, kThreads, 0, st>>>(a, gparam);
-  return check_launch("curve operator backward");
-}
-}  // namespace
-extern "C" {
 
 int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float* params, const float* target,
                            float* out, float* loss, float* seg_bufs, void* workspace, size_t workspace_bytes, int B,

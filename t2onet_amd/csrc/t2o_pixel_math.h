@@ -508,54 +508,6 @@ T2O_HD void curve_bins_accumulate(float x, float g, float* red, bool first = fal
 #endif
 }
 
-// d out / d x = scale * sum_i k_i [0 <= x - i/8 <= 1/8]   (clamp is inclusive at both ends)
-T2O_HD float curve_bwd_1(const float k[kCurveSteps], float scale, float xin, float g, float* red) {
-  const float x = T2O_OPAQUE(xin);
-  float slope = 0.0f;
-#if defined(__HIP_DEVICE_COMPILE__)
-  // as curve_bins_accumulate, and segment j passes the gradient iff the clamp left 8x - j unchanged
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const float t = x * (float)kCurveSteps, g8 = g * (1.0f / kCurveSteps);
-  const f32x2 tt = {t, t}, gg = {g8, g8};
-  T2O_UNROLL
-  for (int j = 0; j < kCurveSteps; j += 2) {
-    const f32x2 nj = {-(float)j, -(float)(j + 1)};
-    const f32x2 u = tt + nj;
-    f32x2 w;
-    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(w) : "v"(tt), "s"(nj));
-    f32x2 acc = {red[j], red[j + 1]};
-    acc = __builtin_elementwise_fma(gg, w, acc);
-    red[j] = acc.x;
-    red[j + 1] = acc.y;
-    slope += (w.x == u.x) ? k[j] : 0.0f;
-    slope += (w.y == u.y) ? k[j + 1] : 0.0f;
-  }
-#else
-  for (int i = 0; i < kCurveSteps; ++i) {
-    const float d = x - (float)i / kCurveSteps;
-    const float t = fminf(fmaxf(d, 0.0f), 1.0f / kCurveSteps);
-    red[i] += g * t;
-    slope += (t == d) ? k[i] : 0.0f;        // clamp(d) == d  <=>  0 <= d <= 1/8 (inclusive, as PyTorch's clamp backward)
-  }
-#endif
-  return g * scale * slope;
-}
-
-T2O_HD Rgb tone_bwd(const Rgb& x, const Curve& cv, const Rgb& g, float* red) {
-  Rgb gx;
-  T2O_UNROLL
-  for (int c = 0; c < 3; ++c) gx.c[c] = curve_bwd_1(cv.k[0], cv.scale[0], x.c[c], g.c[c], red);
-  return gx;
-}
-
-T2O_HD Rgb color_bwd(const Rgb& x, const Curve& cv, const Rgb& g, float* red) {
-  Rgb gx;
-  T2O_UNROLL
-  for (int c = 0; c < 3; ++c)
-    gx.c[c] = curve_bwd_1(cv.k[c], cv.scale[c], x.c[c], g.c[c], red + c * kCurveSteps);
-  return gx;
-}
-
 // Can the final clamp(0,1) of operator `op` be active for input pixel x?  For brightness and
 // saturation the HSV round trip returns v' * [0,1] factors (resp. v * [0,1] factors): with the
 // input inside [0,1] the output provably is too, in fp32 as well (every factor is a rounded
@@ -568,13 +520,13 @@ T2O_HD bool clamp_can_act(int op, const Rgb& x) {
   return true;
 }
 
+// (the curve operators' backward goes through the lookup table: curve_lut_bwd_1 in t2o_block_programs.h)
 T2O_HD Rgb pointwise_bwd(int op, const Rgb& x, const float* p, const Curve& cv, const Rgb& g, float* red) {
+  (void)cv;
   switch (op) {
     case OP_BRIGHTNESS: return brightness_bwd(x, p[0], g, red);
     case OP_CONTRAST:   return contrast_bwd(x, p[0], g, red);
     case OP_SATURATION: return saturation_bwd(x, p[0], g, red);
-    case OP_COLOR:      return color_bwd(x, cv, g, red);
-    case OP_TONE:       return tone_bwd(x, cv, g, red);
     case OP_WHITE: { Rgb z; z.c[0] = z.c[1] = z.c[2] = 0.0f; return z; }
     default:            return g;
   }
