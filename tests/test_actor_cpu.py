@@ -111,3 +111,38 @@ def test_data_parallel_flat_allreduce_gloo(tmp_path):
         opt.step()
     for u, v in zip(a, net.parameters()):
         assert torch.allclose(u, v.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_sample_categorical_is_a_categorical_draw():
+    """Inverse-CDF sampling (no host sync) draws from the same distribution as Categorical(probs):
+    zero-weight entries are never chosen, frequencies follow the (unnormalised) weights."""
+    from t2onet_amd.actor import sample_categorical
+    torch.manual_seed(3)
+    w = torch.tensor([[0.0, 0.0, 2.0, 1.0, 0.0, 1.0, 0.0]]).repeat(40000, 1)
+    idx = sample_categorical(w)
+    assert idx.shape == (40000, 1) and idx.dtype == torch.long
+    counts = torch.bincount(idx.view(-1), minlength=7).float() / 40000
+    assert float(counts[[0, 1, 4, 6]].sum()) == 0.0
+    np.testing.assert_allclose(counts[[2, 3, 5]].numpy(), [0.5, 0.25, 0.25], atol=0.01)
+    # a row whose last entries are zero never falls off the end
+    w2 = torch.zeros(1000, 11)
+    w2[:, 3] = 1e-3
+    assert bool((sample_categorical(w2) == 3).all())
+
+
+def test_decoder_single_step_equals_nn_lstm():
+    """Decoder._rnn_step (fused cell calls on the module's own weights) == nn.LSTM on a length-1 sequence,
+    values and gradients."""
+    from t2onet_amd.action_decoder import Decoder
+    torch.manual_seed(5)
+    dec = Decoder(11, 6, 300, 256, 2, 'lstm', bidirectional=True, use_attention=False)
+    x = torch.randn(4, 1, 300 + 512, requires_grad=True)
+    h0, c0 = torch.randn(2, 4, 512), torch.randn(2, 4, 512)
+    out, (h, c) = dec._rnn_step(x, (h0, c0))
+    ref_out, (rh, rc) = dec.rnn(x, (h0, c0))
+    np.testing.assert_allclose(out.detach().numpy(), ref_out.detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(h.detach().numpy(), rh.detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(c.detach().numpy(), rc.detach().numpy(), rtol=0, atol=2e-6)
+    g1, = torch.autograd.grad(out.sum() + c.sum(), x, retain_graph=True)
+    g2, = torch.autograd.grad(ref_out.sum() + rc.sum(), x)
+    np.testing.assert_allclose(g1.numpy(), g2.numpy(), rtol=0, atol=5e-6)
