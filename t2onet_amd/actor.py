@@ -113,7 +113,15 @@ class Actor(nn.Module):
 
         wrappers = tuple(_Call(self.vis_encoder).train() for _ in range(calls))
         samples = tuple((sample_img.detach().clone().requires_grad_(k > 0),) for k in range(calls))
+        # capture runs warm-up iterations: keep them out of the batch-norm running statistics (restored in
+        # place, the graphs keep pointing at the same buffers); parameter .grad does receive the warm-up
+        # gradients -- zero it before the next real step (Trainer does)
+        buffers = list(self.vis_encoder.buffers())
+        saved = [t.clone() for t in buffers]
         graphed = torch.cuda.make_graphed_callables(wrappers, samples)
+        with torch.no_grad():
+            for t, keep in zip(buffers, saved):
+                t.copy_(keep)
         self.__dict__['_graphed_encoders'] = graphed
         self.__dict__['_graphed_shape'] = tuple(sample_img.shape)
         return self

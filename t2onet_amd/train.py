@@ -62,8 +62,8 @@ class Trainer:
         if self.graph_encoder and img.is_cuda and '_graphed_encoders' not in self.model.__dict__:
             self.model.train()
             self.model.graph_image_encoder(img, self.opt.decoder_max_len)
-            # capture ran warm-up forwards/backwards: drop what they left in the gradient buffer and undo
-            # nothing else -- batch-norm running statistics saw a few extra batches of this same image
+            # capture ran warm-up forwards/backwards: drop what they left in the gradient buffer (the
+            # batch-norm running statistics are restored by graph_image_encoder itself)
             self.grads.zero()
 
     def _finish(self, loss):

@@ -232,3 +232,49 @@ def test_fused_batchnorm_relu_matches_torch(shape, with_res):
                                atol=1e-5 * float(ref.bias.grad.abs().max()))
     if with_res:
         np.testing.assert_allclose(rg.grad.cpu().numpy(), r64.grad.float().numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_trainer_with_graphed_encoder_matches_eager():
+    """Trainer(graph_encoder=True): the image encoder replayed from hipGraphs gives the same losses and the
+    same flat gradient as eager execution, for the teacher-forced and the episode step, and capture leaves the
+    batch-norm running statistics untouched."""
+    import copy
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    opt = t2onet_amd.default_options()
+    torch.manual_seed(11)
+    base = Actor(opt).to(dev).train()
+    B, H, W = 4, 64, 64
+    img_x = synth.images(B, H, W, 81).to(dev)
+    img_y = torch.stack([synth.images(B, H, W, 82 + k) for k in range(6)], 1).to(dev)
+    x = synth.requests(B, 17, 83).to(dev)
+    y = synth.op_targets(B, 84).to(dev)
+    gt = synth.uniform((B, 5, 24), 85, -1.0, 1.0).to(dev)
+    lengths = (x != 0).sum(1).cpu()
+    results = []
+    for graph in (False, True):
+        model = copy.deepcopy(base)
+        tr = Trainer(model, opt, graph_encoder=graph)
+        stats0 = [b.clone() for b in model.vis_encoder.buffers()]
+        if graph:
+            tr._maybe_graph(img_x)
+            for b0, b1 in zip(stats0, model.vis_encoder.buffers()):
+                assert torch.equal(b0, b1)
+            assert '_graphed_encoders' in model.__dict__
+        torch.manual_seed(12)
+        sup = tr.supervised_step(x, y, img_x, img_y, gt, lengths=lengths)
+        g_sup = tr.grads.flat.clone()
+        torch.manual_seed(13)
+        epi = tr.episode_step(x, img_x, img_y[:, -1], lengths=lengths)
+        g_epi = tr.grads.flat.clone()
+        results.append((float(sup[0]), float(sup[1]), g_sup, float(epi), g_epi))
+    (o0, p0, gs0, e0, ge0), (o1, p1, gs1, e1, ge1) = results
+    assert abs(o0 - o1) < 1e-5 and abs(p0 - p1) < 1e-4 * max(1.0, abs(p0))
+    np.testing.assert_allclose(gs1.cpu().numpy(), gs0.cpu().numpy(), rtol=0, atol=2e-5 * float(gs0.abs().max()))
+    # the episode samples operators: same seed, same draws (encoder graphs consume no random numbers); the
+    # second step starts from parameters that already differ by one Adam step of rounding-level gradients
+    assert abs(e0 - e1) < 1e-3
+    np.testing.assert_allclose(ge1.cpu().numpy(), ge0.cpu().numpy(), rtol=0, atol=5e-3 * float(ge0.abs().max()))
