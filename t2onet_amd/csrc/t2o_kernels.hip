@@ -509,25 +509,20 @@ __global__ __launch_bounds__(kThreads) void k_finalize_params_multi(MultiFinaliz
   if ((int)threadIdx.x >= np && (int)threadIdx.x < kMaxParam) grow[threadIdx.x] = 0.0f;
 }
 
-// loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order): lane = block row
-// index within a sample, wave = sample index (stride 4): no integer division in the loop
+// loss[0] = inv_n * sum of all loss partials (single workgroup, fixed order).  Flat over (sample, block
+// row): every thread's loads are independent and issued back to back (the kernel is one memory round trip
+// plus the launch, not one round trip per group of samples).
 __global__ __launch_bounds__(kThreads) void k_finalize_loss(OpArgs a, float* loss, int nblk_point, int nblk_sharp) {
+  const int nbmax = nblk_point > nblk_sharp ? nblk_point : nblk_sharp;
+  const int total = a.B * nbmax;
   float acc = 0.0f;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};     // four samples in flight per wave: the loads overlap
-  for (int b0 = wave * 4; b0 < a.B; b0 += kThreads / 64 * 4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int b = b0 + j;
-      if (b < a.B) {
-        const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
-        const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
-        const float* row = a.loss_partials + (size_t)b * a.nblk_max;
-        for (int k = lane; k < nb; k += 64) acc4[j] += row[k];
-      }
-    }
+#pragma unroll 8
+  for (int idx = threadIdx.x; idx < total; idx += kThreads) {
+    const int b = idx / nbmax, k = idx - b * nbmax;
+    const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
+    const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
+    if (k < nb) acc += a.loss_partials[(size_t)b * a.nblk_max + k];
   }
-  acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   __shared__ float out1;
   block_reduce_store1(acc, &out1);
   __syncthreads();
