@@ -61,7 +61,12 @@ class Trainer:
     def _maybe_graph(self, img):
         if self.graph_encoder and img.is_cuda and '_graphed_encoders' not in self.model.__dict__:
             self.model.train()
-            self.model.graph_image_encoder(img, self.opt.decoder_max_len)
+            try:
+                self.model.graph_image_encoder(img, self.opt.decoder_max_len)
+            except Exception as e:                     # noqa: BLE001 -- an optimisation only: run eagerly instead
+                import warnings
+                warnings.warn('image-encoder graph capture failed (%s: %s); continuing without it' % (type(e).__name__, e))
+                self.graph_encoder = False
             # capture ran warm-up forwards/backwards: drop what they left in the gradient buffer (the
             # batch-norm running statistics are restored by graph_image_encoder itself)
             self.grads.zero()
