@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void k_sharp_fwd(OpArgs a, int tiles) {
 // left / right neighbours come from the adjacent lanes by wave-wide DPP shifts (wave_shr:1 / wave_shl:1);
 // only lane 0 / lane 63 of a segment that does not touch the image border read their outside column
 // from global memory.  No LDS staging pass, no barrier, no item arithmetic: these kernels stream.
-// (The LDS-tile kernels above remain for W % 4 != 0 and for the masked backward.  Measured at bs=64
+// (The LDS-tile kernels above remain for W % 4 != 0.  Measured at bs=64
 // 256x256 inside the benchmark step: backward 48.6 -> 31.0 us.  The tile kernels were issue-bound, ~170
 // vector + ~90 scalar instructions per pixel mostly for window addressing and predication, and their
 // load / compute / store phases added up exactly, with or without a register prefetch of the next tile.)
@@ -249,14 +249,16 @@ __global__ __launch_bounds__(kThreads) void k_sharp_fwd_strip(OpArgs a, int nblk
   if (a.target) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk_max + blk);
 }
 
-// Backward, strip layout as above (no mask): x rows y0-2..y0+5 and gradient (or L1 target) rows y0-1..y0+4
+// Backward, strip layout as above: x rows y0-2..y0+5 and gradient (or L1 target) rows y0-1..y0+4
 // are loaded up front (14 independent 16-byte loads per plane), dz is computed once per window row in
 // registers (in place of the gradient rows), then the symmetric stencil is applied to it.
 // WIDE (W > 256): segments OVERLAP by one quad on each side -- lanes 0 and 63 only compute the dz column
 // their neighbours need (their own outer columns may be wrong and are never used) and store nothing, so a
 // wave outputs 62 quads = kStripWideCols pixels and no lane ever needs a dz from outside its wave.
 
-template <bool DYN, bool WIDE>
+// MASKED: out = clamp(blend(x + p * Lap(x), x, m)): with do = dz * m the input gradient is
+// dz * (1 - m) + do + p * Lap(do) and d loss / d p sums do * Lap(x); the mask rows ride along in registers.
+template <bool DYN, bool WIDE, bool MASKED>
 __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk, int nseg) {
   int b, blk;
   wg_coords(nblk, b, blk);
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
   for (int c = 0; c < 3; ++c) {
     const float* xp = a.img + ((size_t)b * 3 + c) * hw;
     const float* gp = (a.target ? a.target : a.gout) + ((size_t)b * 3 + c) * hw;
-    float xr[kStripRows + 4][4], g[kStripRows + 2][4];
+    const float* mp = MASKED ? a.mask + ((size_t)b * a.mask_ch + (a.mask_ch == 3 ? c : 0)) * hw : nullptr;
+    float xr[kStripRows + 4][4], g[kStripRows + 2][4], mk[MASKED ? kStripRows + 2 : 1][4], pass[MASKED ? kStripRows : 1][4];
 #pragma unroll
     for (int k = 0; k < kStripRows + 4; ++k) {
       const int y = y0 - 2 + k;
@@ -285,7 +288,11 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
     for (int k = 0; k < kStripRows + 2; ++k) {
       const int y = y0 - 1 + k;
       g[k][0] = g[k][1] = g[k][2] = g[k][3] = 0.0f;
-      if (col_live && y >= 0 && y < a.H) load_vec<4>(gp + (unsigned)y * (unsigned)a.W + (unsigned)gx0, g[k]);
+      if (MASKED) mk[k][0] = mk[k][1] = mk[k][2] = mk[k][3] = 0.0f;
+      if (col_live && y >= 0 && y < a.H) {
+        load_vec<4>(gp + (unsigned)y * (unsigned)a.W + (unsigned)gx0, g[k]);
+        if (MASKED) load_vec<4>(mp + (unsigned)y * (unsigned)a.W + (unsigned)gx0, mk[k]);
+      }
     }
     // dz for window rows y0-1 .. y0+kStripRows (in place of g)
 #pragma unroll
@@ -298,11 +305,14 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
       for (int i = 0; i < 4; ++i) {
         const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
         const float d = sharp_delta(ce[i], xr[k][i], left, right, xr[k + 2][i]);
-        const float z = ce[i] + p * d;
+        const float m = MASKED ? mk[k][i] : 1.0f;
+        float z = ce[i] + p * d;
+        if (MASKED) z = blend(z, ce[i], m);
         const float gz = a.target ? sign_of(clamp01(z) - g[k][i]) * gs : g[k][i];
         const float dz = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
-        g[k][i] = dz;
-        if (k >= 1 && k <= kStripRows && own) red0 += dz * d;
+        g[k][i] = MASKED ? dz * m : dz;                                   // do
+        if (MASKED && k >= 1 && k <= kStripRows) pass[k - 1][i] = dz * (1.0f - m);
+        if (k >= 1 && k <= kStripRows && own) red0 += dz * m * d;
       }
     }
     // gimg rows y0 .. y0+kStripRows-1
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
       for (int i = 0; i < 4; ++i) {
         const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
         o[i] = ce[i] + p * sharp_delta(ce[i], g[k - 1][i], left, right, g[k + 1][i]);
+        if (MASKED) o[i] = pass[k - 1][i] + o[i];
       }
       if (a.gimg && own && col_live && y < a.H)
         store_vec<4>(a.gimg + ((size_t)b * 3 + c) * hw + (unsigned)y * (unsigned)a.W + (unsigned)gx0, o);
@@ -759,7 +770,7 @@ bool sharp_uses_strips(const Geometry& g) {
   static const int mode = env_int("T2O_SHARP_STRIPS", 1);      // 0: LDS-tile kernels everywhere (A/B runs)
   return mode && g.vec_tile == 4;
 }
-bool sharp_bwd_uses_strips(const OpArgs& a, const Geometry& g) { return sharp_uses_strips(g) && a.mask_ch == 0; }
+bool sharp_bwd_uses_strips(const OpArgs&, const Geometry& g) { return sharp_uses_strips(g); }
 int sharp_fwd_blocks(const OpArgs&, const Geometry& g) { return sharp_uses_strips(g) ? g.nblk_strip_fwd : g.nblk_sharp; }
 int sharp_bwd_blocks(const OpArgs& a, const Geometry& g) { return sharp_bwd_uses_strips(a, g) ? g.nblk_strip_bwd : g.nblk_sharp; }
 
@@ -789,8 +800,12 @@ void launch_sharp_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
     const int nseg = strip_bwd_segments(a.W), nblk = g.nblk_strip_bwd;
     const unsigned grid = (unsigned)a.B * nblk;
     const bool dyn = a.op == OP_DYNAMIC;
-    if (nseg > 1) { if (dyn) k_sharp_bwd_strip<true, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); else k_sharp_bwd_strip<false, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
-    else          { if (dyn) k_sharp_bwd_strip<true, false><<<grid, kThreads, 0, st>>>(a, nblk, nseg); else k_sharp_bwd_strip<false, false><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
+#define T2O_BWD_STRIP(D, Wd) \
+    { if (a.mask_ch) k_sharp_bwd_strip<D, Wd, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); \
+      else k_sharp_bwd_strip<D, Wd, false><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
+    if (nseg > 1) { if (dyn) T2O_BWD_STRIP(true, true) else T2O_BWD_STRIP(false, true) }
+    else          { if (dyn) T2O_BWD_STRIP(true, false) else T2O_BWD_STRIP(false, false) }
+#undef T2O_BWD_STRIP
     return;
   }
   const unsigned grid = (unsigned)a.B * g.nblk_sharp;
