@@ -63,6 +63,10 @@ class Trainer:
             self.model.train()
             try:
                 self.model.graph_image_encoder(img, self.opt.decoder_max_len)
+                # the captured backward hands its parameter gradients over from the capture stream: expected here
+                quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+                if quiet is not None:
+                    quiet(False)
             except Exception as e:                     # noqa: BLE001 -- an optimisation only: run eagerly instead
                 import warnings
                 warnings.warn('image-encoder graph capture failed (%s: %s); continuing without it' % (type(e).__name__, e))
