@@ -45,6 +45,9 @@ extern "C" {
 
 int t2o_abi_version(void);
 const char* t2o_last_error(void);
+/* sha256 (hex) of the sources + compiler flags this binary was built from (compiled in by
+ * t2onet_amd/build.py); the loader refuses a library whose digest differs from the tree's. */
+const char* t2o_source_digest(void);
 
 /* number of parameters of operator `op` (Executor.get_param_num, executor.py:61-63); -1 if unknown */
 int t2o_op_num_params(int op);

@@ -23,6 +23,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     't2o_abi_version': (_I, []),
     't2o_last_error': (ctypes.c_char_p, []),
+    't2o_source_digest': (ctypes.c_char_p, []),
     't2o_op_num_params': (_I, [_I]),
     't2o_workspace_bytes': (_Z, [_I, _I, _I]),
     't2o_op_fwd': (_I, [_I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
@@ -52,28 +53,35 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 2
+
+
 def load():
-    """Load (once) and return the ctypes library.  Raises if it is not there."""
+    """Load (once) and return the ctypes library.  The library must have been built from exactly the sources
+    in this tree (digest compiled into it): a stale one is rebuilt when hipcc is here -- compiler errors
+    propagate -- and refused otherwise.  Nothing is swallowed and nothing falls back."""
     global _lib
     if _lib is not None:
         return _lib
-    try:                                   # (re)build when the sources changed and hipcc is here; never required
-        from . import build as _build
-        if os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
-            _build.build()
-    except Exception:                      # noqa: BLE001 -- fall through to the existence check below
-        pass
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            'libt2onet_hip.so not found at %s: build it with `python -m t2onet_amd.build` '
-            '(needs hipcc; there is no CPU fallback)' % LIB_PATH)
+    from . import build as _build
+    want = _build.source_digest()
+    have = _build.library_digest(LIB_PATH)
+    if have != want:
+        if os.path.exists(_build.hipcc_path()):
+            _build.build()                      # raises on failure; atomic rename under a file lock
+            have = _build.library_digest(LIB_PATH)
+        if have != want:
+            raise RuntimeError(
+                'libt2onet_hip.so at %s %s; build it with `python -m t2onet_amd.build` (needs hipcc; there is no '
+                'CPU fallback)' % (LIB_PATH, 'is missing' if have is None and not os.path.exists(LIB_PATH)
+                                   else 'was built from other sources (digest %s, tree %s)' % (have, want)))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.t2o_abi_version() != 1:
-        raise RuntimeError('libt2onet_hip.so ABI version mismatch')
+    if lib.t2o_abi_version() != ABI_VERSION or lib.t2o_source_digest().decode() != want:
+        raise RuntimeError('libt2onet_hip.so ABI version / source digest mismatch after load')
     _lib = lib
     return lib
 

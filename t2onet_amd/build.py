@@ -2,7 +2,13 @@
 with the repo snapshot to the GPU box.  hipcc cross-compiles without a GPU.
 
     python -m t2onet_amd.build [--force] [--report]
+
+The sha256 of the sources + flags is compiled INTO the library (t2o_source_digest()); nothing
+beside the binary records what it was built from, so a checkout that changes the sources can
+never be mistaken for up to date.  The link goes to a temporary file that is renamed over the
+target under a file lock: concurrent ranks never see a half-written library.
 """
+import fcntl
 import hashlib
 import os
 import subprocess
@@ -20,31 +26,58 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fP
          '-I' + os.path.join(ROOT, 'include')]
 
 
-def _digest():
-    h = hashlib.sha256(' '.join(FLAGS).encode())
+def hipcc_path():
+    return os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+def source_digest():
+    """sha256 over the flags (paths made repo-relative: the tree moves between machines) and every source."""
+    h = hashlib.sha256(' '.join(f.replace(ROOT, '.') for f in FLAGS).encode())
     for f in SOURCES + HEADERS:
         with open(f if os.path.isabs(f) else os.path.join(CSRC, f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()
 
 
+def library_digest(path=LIB):
+    """The digest compiled into an existing library file, or None (missing / predates the digest).  Read from
+    the file's bytes, not through dlopen: a library loaded here would shadow the rebuilt one in this process."""
+    tag = b't2o-src-digest:'
+    try:
+        with open(path, 'rb') as f:
+            data = f.read()
+    except OSError:
+        return None
+    i = data.find(tag)
+    if i < 0:
+        return None
+    dig = data[i + len(tag):i + len(tag) + 64]
+    return dig.decode() if len(dig) == 64 and all(c in b'0123456789abcdef' for c in dig) else None
+
+
 def build(force=False, report=False):
+    """Compile if the library is missing or was built from other sources.  Raises on any compiler error."""
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = LIB + '.sha256'
-    dig = _digest()
-    if not force and not report and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+    dig = source_digest()
+    if not force and not report and library_digest() == dig:
         return LIB
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if report:
-        cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError('hipcc failed building libt2onet_hip.so')
+    with open(LIB + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not report and library_digest() == dig:         # another process built it meanwhile
+            return LIB
+        tmp = '%s.tmp.%d' % (LIB, os.getpid())
+        cmd = [hipcc_path()] + FLAGS + ['-DT2O_SRC_DIGEST="%s"' % dig, '-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+        if report:
+            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+            raise RuntimeError('hipcc failed building libt2onet_hip.so')
+        os.replace(tmp, LIB)
     if report:
         _print_report(r.stderr)
-    open(stamp, 'w').write(dig)
     return LIB
 
 

@@ -912,7 +912,13 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
 // ==================================================================== C ABI
 extern "C" {
 
-int t2o_abi_version(void) { return 1; }
+int t2o_abi_version(void) { return 2; }
+#ifndef T2O_SRC_DIGEST
+#define T2O_SRC_DIGEST "unstamped"
+#endif
+// the tag lets build.py read the digest out of the file without loading it
+static const char k_src_digest[] = "t2o-src-digest:" T2O_SRC_DIGEST;
+const char* t2o_source_digest(void) { return k_src_digest + 15; }
 const char* t2o_last_error(void) { return g_err; }
 
 int t2o_op_num_params(int op) { return (op >= 0 && op <= 7) ? op_num_params(op) : -1; }

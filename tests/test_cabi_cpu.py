@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_argument_validation_without_a_device(lib):
-    assert lib.t2o_abi_version() == 1
+    assert lib.t2o_abi_version() == 2
     assert [lib.t2o_op_num_params(i) for i in range(-1, 9)] == [-1, 1, 1, 1, 24, 1, 8, 1, 1, -1]
     assert lib.t2o_workspace_bytes(0, 4, 4) == 0 and lib.t2o_workspace_bytes(64, 256, 256) > 0
     # null image / unsupported operator / bad mask are rejected before any launch
@@ -75,3 +75,30 @@ def test_python_surface_mirrors_reference():
     assert out is img and par.shape == (2, 24)
     with pytest.raises(RuntimeError, match='no CPU'):
         ex.execute(img, 0, None, specified_param=torch.zeros(2, 1))
+
+
+def test_stale_library_is_refused_not_loaded(lib, tmp_path):
+    """A library built from other sources (digest compiled in) must not load silently: with no compiler
+    reachable the loader raises; it never binds the new signatures onto the old binary."""
+    import subprocess
+    import sys
+    from t2onet_amd import build
+    assert build.library_digest() == build.source_digest() == lib.t2o_source_digest().decode()
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['HIPCC'] = '/nonexistent/hipcc'\n"
+        "from t2onet_amd import build, _lib\n"
+        "build.source_digest = lambda: 'f' * 64\n"          # as if a checkout had changed the sources
+        "try:\n"
+        "    _lib.load()\n"
+        "except RuntimeError as e:\n"
+        "    assert 'other sources' in str(e), e\n"
+        "    print('refused')\n" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert r.stdout.strip() == 'refused', r.stdout + r.stderr
+    # a failing compiler is an error, not a fallback to whatever binary is lying around
+    code2 = code.replace("'/nonexistent/hipcc'", "'/bin/false'").replace("except RuntimeError as e:\n    assert 'other sources' in str(e), e",
+                                                                        "except RuntimeError as e:\n    assert 'hipcc failed' in str(e), e")
+    r = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True)
+    assert r.stdout.strip() == 'refused', r.stdout + r.stderr
