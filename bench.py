@@ -1,65 +1,136 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on MI355X.
+"""bench.py -- BASELINE.json's metric on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): bs=64 per GPU, 256x256 fp32, the six-operator executor
-sequence [brightness, contrast, saturation, color-curve, tone-curve, sharpness] forward + L1
-loss + backward to every operator parameter and to the input image.  Inputs are synthetic
-(U[0,1) images, torch.Generator seed 10; parameters as in SURVEY.md 8(d)) and already resident
-in HBM when the timed region starts.  A "step" = one such forward+L1+backward over the batch.
+Headline (`value`): images/sec of the episode/L1 TRAIN STEP (BASELINE.json metric; configs[2] at
+N=1, configs[3] at N=8): request encoder + 5 x (ResNet image features + attention decoder step +
+sampled per-sample operator) + END-image select + L1 + backward + ONE flat fp32 gradient
+all-reduce (RCCL) + Adam, bs=64 per GPU, 256x256 fp32, FiveK-shaped synthetic batch, random-init
+weights (experiments/t2onet/train_seq2seqL1.py:74-88).  W untimed warm-up steps, then exactly K
+timed steps between barrier + synchronize on both sides, MAX over ranks.
 
-The step runs through the C ABI (t2o_sequence_fwd / t2o_sequence_bwd): every intermediate
-image is materialised, as Executor.execute returns it, so the HBM traffic is the algorithmic
-K*60*P + 12*P bytes of SURVEY.md 8(d).  N > 1: the batch dimension shards (64 images per GPU,
-weak scaling), the executor path has no data-path collective; one process per
-GPU under torch.distributed/RCCL, timed between barriers, MAX over ranks.
+N > 1: when RANK is not in the environment this process is only a LAUNCHER -- before touching a
+GPU it checks that N devices exist (exit 2 otherwise, never a silent 1-GPU run), starts N child
+ranks of this script (one per GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it is a rank directly.
 
-One JSON line on rank 0, with
-  roofline      dominant kernel (largest share of step time): algorithmic bytes per launch /
-                its mean duration, measured with HIP events on the launch stream in a second,
-                per-kernel instrumented pass over the same steps
-  cpu_baseline  the oracle (oracle/cpu_ref.py, eager PyTorch restatement of the reference)
-                timed on this node's host cores on a bounded sample of the same workload
+The same line carries the op-pipeline half of the metric ("GB/s vs HBM roofline"):
+  executor.cfg2_bs64     BASELINE configs[1]: 6-op executor sequence fwd + L1 + bwd, bs=64 256x256
+  executor.bs256         the same at bs=256 (the north-star >= 60 % target size)
+  executor.cfg5_16x512   configs[4] per-GPU shape: 16 x 512x512, ops [5,3,5,3,0,1,2,6]
+each through the fused C-ABI path and the fully materialised one, with per-kernel HIP-event
+timings.  `roofline` = the dominant hand-written kernel of the cfg2 fused step (HBM);
+`train_roofline` = the train step against the fp32 matrix peak (4.34 TFLOP per bs=64 step).
+`cpu_baseline` = the oracle (oracle/cpu_ref.py) on this node's host cores for configs[0], [1]
+and (bounded sample) [2], N=1 only.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-OPS = [0, 1, 2, 3, 5, 6]
+CFG2_OPS = [0, 1, 2, 3, 5, 6]
+CFG5_OPS = [5, 3, 5, 3, 0, 1, 2, 6]
 OP_NAMES = {0: 'brightness', 1: 'contrast', 2: 'saturation', 3: 'color', 5: 'tone', 6: 'sharpness'}
 PARAM_RANGES = {0: (1, -0.3, 0.3), 1: (1, -0.3, 0.3), 2: (1, -0.3, 0.3), 3: (24, 0.5, 1.5), 5: (8, 0.5, 1.5), 6: (1, 0.0, 1.0)}
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MATRIX_PEAK_TF = 157.3     # same guide: v_mfma_f32_* = the fp32 vector rate
+TRAIN_FLOP_PER_IMAGE = 67.8e9   # 5 x ResNet fwd+bwd at 256x256 (scales with H*W)
 
 
-def make_inputs(B, H, W, device, seed=10):
+# ---------------------------------------------------------------------------------------------
+# launcher (no GPU call in this process)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args, argv):
+    """Start args.gpus ranks of this script and relay rank 0's stdout.  Exit code: 2 if the node has
+    fewer devices than asked for, else the worst child's."""
+    import torch
+    n = args.gpus
+    if not args.selftest:
+        have = torch.cuda.device_count()            # does not initialise the GPU runtime on this image
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to run on fewer\n' % (n, have))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out,
+                                      start_new_session=True))
+    deadline = time.time() + args.launch_timeout
+    line, rc = None, 0
+    try:
+        out0, _ = procs[0].communicate(timeout=args.launch_timeout)
+        for ln in out0.decode('utf-8', 'replace').splitlines():
+            if ln.startswith('{'):
+                line = ln
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+            rc = max(rc, abs(p.returncode))
+    except subprocess.TimeoutExpired:
+        rc = 124
+        sys.stderr.write('bench.py: ranks did not finish within %d s; stopping them\n' % args.launch_timeout)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 15)             # the exact process groups started above
+                except OSError:
+                    pass
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# executor legs (C ABI, preallocated buffers, no autograd)
+# ---------------------------------------------------------------------------------------------
+def make_inputs(ops, B, H, W, device, seed=10):
+    import torch
     g = torch.Generator().manual_seed(seed)
     img = torch.rand(B, 3, H, W, generator=g)
     tgt = torch.rand(B, 3, H, W, generator=g)
-    params = torch.zeros(len(OPS), B, 24)
-    for k, op in enumerate(OPS):
+    params = torch.zeros(len(ops), B, 24)
+    for k, op in enumerate(ops):
         n, lo, hi = PARAM_RANGES[op]
         params[k, :, :n] = torch.rand(B, n, generator=g) * (hi - lo) + lo
     return img.to(device), tgt.to(device), params.to(device)
 
 
 class SequenceRunner:
-    """Preallocated buffers + direct C-ABI calls (no autograd, no allocation in the step)."""
+    """t2o_sequence_fwd/bwd: one kernel pair per operator, every intermediate in HBM (what K
+    Executor.execute calls + autograd do); HBM traffic = the algorithmic K*60*P + 12*P bytes."""
 
-    def __init__(self, B, H, W, device):
+    def __init__(self, ops, B, H, W, device):
+        import torch
         from t2onet_amd import _lib
+        self.torch = torch
         self.lib = _lib.load()
         self.check = _lib.check
-        self.B, self.H, self.W, self.K = B, H, W, len(OPS)
-        self.img, self.tgt, self.params = make_inputs(B, H, W, device)
+        self.ops = list(ops)
+        self.B, self.H, self.W, self.K = B, H, W, len(ops)
+        self.img, self.tgt, self.params = make_inputs(ops, B, H, W, device)
         self.acts = torch.empty(self.K, B, 3, H, W, device=device)
         self.gbuf = torch.empty(2, B, 3, H, W, device=device)
         self.gimg = torch.empty(B, 3, H, W, device=device)
@@ -67,14 +138,23 @@ class SequenceRunner:
         self.loss = torch.zeros((), device=device)
         self.gloss = torch.ones((), device=device)
         self.ws = torch.empty(self.lib.t2o_workspace_bytes(B, H, W), dtype=torch.uint8, device=device)
-        self.c_ops = (ctypes.c_int * self.K)(*OPS)
+        self.c_ops = (ctypes.c_int * self.K)(*ops)
 
     def _p(self, t):
         return ctypes.c_void_p(t.data_ptr())
 
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def _timed(self, rec, name, fn):
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.check(fn(), name)
+        e1.record()
+        rec.setdefault(name, []).append((e0, e1))
+
     def step(self):
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        B, H, W = self.B, self.H, self.W
+        st, B, H, W = self._stream(), self.B, self.H, self.W
         rc = self.lib.t2o_sequence_fwd(self.c_ops, self.K, self._p(self.img), self._p(self.params), self._p(self.tgt),
                                        self._p(self.acts), self._p(self.loss), self._p(self.ws), self.ws.numel(), B, H, W, st)
         self.check(rc, 't2o_sequence_fwd')
@@ -84,63 +164,60 @@ class SequenceRunner:
         self.check(rc, 't2o_sequence_bwd')
 
     def profiled_step(self, rec):
-        """The same launches, one C call per operator, each bracketed by HIP events recorded on
-        the launch stream (torch's current stream)."""
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        B, H, W, K = self.B, self.H, self.W, self.K
+        """The same launches, one C call per operator, each bracketed by HIP events recorded on the launch
+        stream (torch's current stream).  Repeated operators are numbered (tone, tone#2)."""
+        st, B, H, W, K = self._stream(), self.B, self.H, self.W, self.K
         wsn = self.ws.numel()
-
-        def timed(name, fn):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.check(fn(), name)
-            e1.record()
-            rec.setdefault(name, []).append((e0, e1))
-
+        seen, names = {}, []
+        for op in self.ops:
+            seen[op] = seen.get(op, 0) + 1
+            names.append(OP_NAMES[op] + ('' if seen[op] == 1 else '#%d' % seen[op]))
         cur = self.img
-        for k, op in enumerate(OPS):
+        for k, op in enumerate(self.ops):
             out, p = self.acts[k], self.params[k]
             if k == K - 1:
-                timed('fwd_%s+l1' % OP_NAMES[op], lambda: self.lib.t2o_op_fwd_l1(
+                self._timed(rec, 'fwd_%s+l1' % names[k], lambda: self.lib.t2o_op_fwd_l1(
                     op, self._p(cur), self._p(p), 24, None, 0, self._p(self.tgt), self._p(out), self._p(self.loss),
                     self._p(self.ws), wsn, B, H, W, st))
             else:
-                timed('fwd_%s' % OP_NAMES[op], lambda: self.lib.t2o_op_fwd(
+                self._timed(rec, 'fwd_%s' % names[k], lambda: self.lib.t2o_op_fwd(
                     op, self._p(cur), self._p(p), 24, None, 0, self._p(out), B, H, W, st))
             cur = out
         gcur = None
         for k in range(K - 1, -1, -1):
-            op = OPS[k]
+            op = self.ops[k]
             inp = self.img if k == 0 else self.acts[k - 1]
             gnext = self.gimg if k == 0 else self.gbuf[k & 1]
             p, gp = self.params[k], self.gparams[k]
             if k == K - 1:
-                timed('bwd_%s+l1' % OP_NAMES[op], lambda: self.lib.t2o_op_bwd_l1(
+                self._timed(rec, 'bwd_%s+l1' % names[k], lambda: self.lib.t2o_op_bwd_l1(
                     op, self._p(inp), self._p(p), 24, None, 0, self._p(self.tgt), self._p(self.gloss), self._p(gnext),
                     self._p(gp), 24, self._p(self.ws), wsn, B, H, W, st))
             else:
-                timed('bwd_%s' % OP_NAMES[op], lambda: self.lib.t2o_op_bwd(
+                self._timed(rec, 'bwd_%s' % names[k], lambda: self.lib.t2o_op_bwd(
                     op, self._p(inp), self._p(p), 24, None, 0, self._p(gcur), self._p(gnext), self._p(gp), 24,
                     self._p(self.ws), wsn, B, H, W, st))
             gcur = gnext
 
 
 class FusedRunner(SequenceRunner):
-    """Same workload through t2o_fused_sequence_fwd/bwd: the five per-pixel operators run in
-    registers in one kernel pair, sharpness (+L1) in its stencil pair; only the image before the
-    sharpness is materialised.  Same loss and gradients (tests/test_gpu_operators.py)."""
+    """Same workload through t2o_fused_sequence_fwd/bwd: the leading per-pixel operators run in registers in
+    one kernel pair, the final sharpness (+L1) in its stencil pair; only the image before the sharpness is
+    materialised.  Same loss and gradients (tests/test_gpu_operators.py)."""
 
-    def __init__(self, B, H, W, device):
-        super().__init__(B, H, W, device)
+    def __init__(self, ops, B, H, W, device):
+        import torch
+        super().__init__(ops, B, H, W, device)
+        assert ops[-1] == 6 and 6 not in ops[:-1] and len(ops) - 1 <= 8, 'bench sequences end with one sharpness'
         self.nbuf = self.lib.t2o_fused_sequence_buffers(self.c_ops, self.K)
         self.seg = torch.empty(max(self.nbuf, 1), B, 3, H, W, device=device)
         self.out = torch.empty(B, 3, H, W, device=device)
         self.acts = None                               # not needed: free the K materialised images
-        self.c_chain = (ctypes.c_int * 5)(*OPS[:5])
+        self.nc = self.K - 1
+        self.c_chain = (ctypes.c_int * self.nc)(*ops[:-1])
 
     def step(self):
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        B, H, W = self.B, self.H, self.W
+        st, B, H, W = self._stream(), self.B, self.H, self.W
         rc = self.lib.t2o_fused_sequence_fwd(self.c_ops, self.K, self._p(self.img), self._p(self.params), self._p(self.tgt),
                                              self._p(self.out), self._p(self.loss), self._p(self.seg), self._p(self.ws),
                                              self.ws.numel(), B, H, W, st)
@@ -151,71 +228,33 @@ class FusedRunner(SequenceRunner):
         self.check(rc, 't2o_fused_sequence_bwd')
 
     def profiled_step(self, rec):
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        B, H, W = self.B, self.H, self.W
+        st, B, H, W, nc = self._stream(), self.B, self.H, self.W, self.nc
         wsn = self.ws.numel()
-
-        def timed(name, fn):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.check(fn(), name)
-            e1.record()
-            rec.setdefault(name, []).append((e0, e1))
-
-        mid, p6, gp6 = self.seg[0], self.params[5], self.gparams[5]
-        timed('fwd_chain5', lambda: self.lib.t2o_fused_sequence_fwd(
-            self.c_chain, 5, self._p(self.img), self._p(self.params), None, self._p(mid), None, None,
+        mid, p6, gp6 = self.seg[0], self.params[nc], self.gparams[nc]
+        self._timed(rec, 'fwd_chain%d' % nc, lambda: self.lib.t2o_fused_sequence_fwd(
+            self.c_chain, nc, self._p(self.img), self._p(self.params), None, self._p(mid), None, None,
             self._p(self.ws), wsn, B, H, W, st))
-        timed('fwd_sharpness+l1', lambda: self.lib.t2o_op_fwd_l1(
+        self._timed(rec, 'fwd_sharpness+l1', lambda: self.lib.t2o_op_fwd_l1(
             6, self._p(mid), self._p(p6), 24, None, 0, self._p(self.tgt), self._p(self.out), self._p(self.loss),
             self._p(self.ws), wsn, B, H, W, st))
-        timed('bwd_sharpness+l1', lambda: self.lib.t2o_op_bwd_l1(
+        self._timed(rec, 'bwd_sharpness+l1', lambda: self.lib.t2o_op_bwd_l1(
             6, self._p(mid), self._p(p6), 24, None, 0, self._p(self.tgt), self._p(self.gloss), self._p(self.gbuf[0]),
             self._p(gp6), 24, self._p(self.ws), wsn, B, H, W, st))
-        timed('bwd_chain5', lambda: self.lib.t2o_fused_sequence_bwd(
-            self.c_chain, 5, self._p(self.img), self._p(self.params), None, None, self._p(self.gbuf[0]),
+        self._timed(rec, 'bwd_chain%d' % nc, lambda: self.lib.t2o_fused_sequence_bwd(
+            self.c_chain, nc, self._p(self.img), self._p(self.params), None, None, self._p(self.gbuf[0]),
             self._p(self.gimg), self._p(self.gparams), None, None, self._p(self.ws), wsn, B, H, W, st))
 
 
-def api_path_bench(B, H, W, device, steps, warmup):
-    """The same step through the drop-in Python surface: six Executor.execute calls + l1_loss +
-    torch autograd backward (ctypes calls into the C ABI from autograd Functions)."""
-    import t2onet_amd
-    import t2onet_amd.functional as T
-    ex = t2onet_amd.Executor(t2onet_amd.default_options()).to(device)
-    img, tgt, params = make_inputs(B, H, W, device)
-    x = img.clone().requires_grad_(True)
-    ps = [params[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
-
-    def step():
-        x.grad = None
-        for p in ps:
-            p.grad = None
-        cur = x
-        for op, p in zip(OPS, ps):
-            cur, _ = ex.execute(cur, op, None, specified_param=p)
-        loss = T.l1_loss(cur, tgt)
-        loss.backward()
-        return loss
-
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {'what': 'six Executor.execute calls + l1_loss + autograd backward (Python API path)',
-            'value': round(B * steps / dt, 1), 'unit': 'images/sec', 'ms_per_step': round(dt / steps * 1e3, 4),
-            'loss': float(loss.item())}
+def _chain_len(name):
+    i = name.find('chain')
+    return int(name[i + 5:]) if i >= 0 else 1
 
 
 def algorithmic_bytes(name, P):
-    """operator forward 24 B/pixel, backward 36 B/pixel, +12 B/pixel (target)
-    for the forward fused with the L1 loss (its backward reads the target instead of gout).
-    A fused launch is credited with the operator applications it performs (5 for chain5)."""
-    n = 5 if 'chain5' in name else 1
+    """operator forward 24 B/pixel, backward 36 B/pixel, +12 B/pixel (target) for the forward
+    fused with the L1 loss (its backward reads the target instead of gout).  A fused launch is credited with
+    the operator applications it performs (n for chain<n>)."""
+    n = _chain_len(name)
     if name.startswith('fwd'):
         return (24 * n + (12 if name.endswith('+l1') else 0)) * P
     return 36 * n * P
@@ -229,41 +268,141 @@ def hbm_min_bytes(name, P):
 
 
 def pmc_traffic(kernel, P):
-    """HBM bytes per launch from the rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-    separate passes: tools/gpu_pmc.sh), stored per pixel in profiles/pmc_traffic.json.  bench.py
-    cannot run the profiler on itself, so this is the last committed measurement, not a live one."""
+    """HBM bytes per launch from the rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    passes: tools/gpu_pmc.sh), stored per pixel in profiles/pmc_traffic.json together with the digest of the
+    library they were measured on.  bench.py cannot run the profiler on itself; the figure is reported only
+    when that digest is the digest of the library being benchmarked, else null."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
+        from t2onet_amd import build
         with open(path) as f:
-            per_px = json.load(f)['bytes_per_pixel'].get(kernel)
+            d = json.load(f)
+        if d.get('lib_digest') != build.source_digest():
+            return None
+        per_px = d['bytes_per_pixel'].get(kernel)
         return None if per_px is None else int(per_px * P)
     except (OSError, ValueError, KeyError):
         return None
 
 
-def cpu_baseline(B_sample, H, W, reps=7):
-    """Oracle timed on the host cores: same sequence, fwd + L1 + bwd, on a bounded sample."""
-    from oracle import cpu_ref
-    img, tgt, params = make_inputs(B_sample, H, W, 'cpu')
-    opt = cpu_ref.default_opt()
+def executor_leg(ctx, ops, B, H, W, steps, warmup, with_api=False):
+    """Fused + materialised timing of one executor configuration on this rank's GPU; throughput aggregated
+    over ranks (batch shards, no collective: SURVEY 8(e))."""
+    import torch
+    dist, world, device = ctx['dist'], ctx['world'], ctx['device']
+    P, K = B * H * W, len(ops)
+    total_bytes = (K * 60 + 12) * P                     # BASELINE.md section 4: K*60*P + 12*P
 
-    def once():
-        x = img.clone().requires_grad_(True)
-        ps = [params[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
-        out, _ = cpu_ref.run_sequence(x, OPS, ps, opt)
-        cpu_ref.l1_loss(out, tgt).backward()
+    def measure(run):
+        for _ in range(warmup):
+            run.step()
+        ctx['barrier']()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el = ctx['max_over_ranks'](time.perf_counter() - t0)
+        rec = {}
+        for _ in range(min(steps, 50)):
+            run.profiled_step(rec)
+        torch.cuda.synchronize()
+        kernels = {}
+        for name, evs in rec.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            by = algorithmic_bytes(name, P)
+            kernels[name] = {'ms': round(ms, 5), 'algorithmic_MB': round(by / 1e6, 2), 'GBps': round(by / ms / 1e6, 1),
+                             'hbm_min_MB': round(hbm_min_bytes(name, P) / 1e6, 2),
+                             'hbm_min_GBps': round(hbm_min_bytes(name, P) / ms / 1e6, 1)}
+        return el, kernels, float(run.loss.item())
 
-    # eager ATen ops on 50 MB tensors do not scale to every core of a big host (256 threads ran
-    # 50x slower than 32 on the first MI355X node): pick the thread count on a short bs=8 probe
+    def summary(el, kernels, loss):
+        ms = el / steps * 1e3
+        return {'value': round(world * B * steps / el, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4),
+                'achieved_GBps_whole_step': round(total_bytes / (ms * 1e-3) / 1e9, 1),
+                'frac_of_peak': round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'sum_kernel_ms': round(sum(k['ms'] for k in kernels.values()), 4), 'loss': loss, 'kernels': kernels}
+
+    mat = summary(*measure(SequenceRunner(ops, B, H, W, device)))
+    torch.cuda.empty_cache()
+    fus = summary(*measure(FusedRunner(ops, B, H, W, device)))
+    torch.cuda.empty_cache()
+    res = {'workload': 'bs=%d/GPU %dx%d fp32, executor ops %s forward + L1 + backward to all parameters and the image'
+                       % (B, H, W, list(ops)),
+           'steps': steps, 'warmup': warmup, 'algorithmic_GB_per_step': round(total_bytes / 1e9, 4),
+           'fused': fus, 'materialised': mat}
+    res['fused']['what'] = ('t2o_fused_sequence_fwd/bwd: per-pixel operators fused in registers, sharpness+L1 stencil '
+                            'kernels; frac_of_peak uses the materialised algorithmic bytes (SURVEY 8(d)), i.e. it '
+                            'includes fusion credit')
+    res['materialised']['what'] = 't2o_sequence_fwd/bwd: one kernel pair per operator, every intermediate in HBM'
+    if with_api:
+        try:
+            res['api_path'] = api_path_bench(ops, B, H, W, device, steps, warmup)
+        except Exception as e:                     # noqa: BLE001
+            res['api_path'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return res
+
+
+def api_path_bench(ops, B, H, W, device, steps, warmup):
+    """The same step through the drop-in Python surface: K Executor.execute calls + l1_loss + torch autograd
+    backward (ctypes calls into the C ABI from autograd Functions)."""
+    import torch
+    import t2onet_amd
+    import t2onet_amd.functional as T
+    ex = t2onet_amd.Executor(t2onet_amd.default_options()).to(device)
+    img, tgt, params = make_inputs(ops, B, H, W, device)
+    x = img.clone().requires_grad_(True)
+    ps = [params[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(ops)]
+
+    def step():
+        x.grad = None
+        for p in ps:
+            p.grad = None
+        cur = x
+        for op, p in zip(ops, ps):
+            cur, _ = ex.execute(cur, op, None, specified_param=p)
+        loss = T.l1_loss(cur, tgt)
+        loss.backward()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'what': '%d Executor.execute calls + l1_loss + autograd backward (Python API path)' % len(ops),
+            'value': round(B * steps / dt, 1), 'unit': 'images/sec', 'ms_per_step': round(dt / steps * 1e3, 4),
+            'loss': float(loss.item())}
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baselines: the oracle on this node's host cores (rank 0, N = 1 only)
+# ---------------------------------------------------------------------------------------------
+def _median_time(fn, reps, budget_s):
+    fn()                                                # warm-up
+    ts = []
+    t_all = time.perf_counter()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s and len(ts) >= 1:
+            break
+    ts.sort()
+    return ts[len(ts) // 2], len(ts)
+
+
+def _pick_threads(probe):
+    """Eager ATen ops on 50 MB tensors do not scale to every core of a big host (256 threads ran 50x slower
+    than 32 on the first MI355X node): pick the thread count on a short probe."""
+    import torch
     ncpu = os.cpu_count() or 1
-    pimg, ptgt, pparams = img[:8], tgt[:8], params[:, :8]
-
-    def probe():
-        x = pimg.clone().requires_grad_(True)
-        ps = [pparams[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
-        out, _ = cpu_ref.run_sequence(x, OPS, ps, opt)
-        cpu_ref.l1_loss(out, ptgt).backward()
-
     best = None
     for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
         torch.set_num_threads(nt)
@@ -276,65 +415,113 @@ def cpu_baseline(B_sample, H, W, reps=7):
         elif dt > 1.5 * best[0]:
             break                                   # past the knee: more threads only get slower
     torch.set_num_threads(best[1])
-    once()                                          # warm-up at the chosen thread count
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        once()
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    res = {'value': B_sample / med, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-           'sample': 'oracle/cpu_ref.py eager fp32, same 6-op sequence fwd+L1+bwd, bs=%d %dx%d, median of %d reps '
-                     '(%.2f s each)' % (B_sample, H, W, reps, med)}
-    # parity gate reported with the number: the GPU paths against the oracle on the first 4 images
+    return best[1]
+
+
+def _host_info():
+    model = ''
     try:
-        import t2onet_amd
-        n = min(4, B_sample)
-        x = img[:n].clone().requires_grad_(True)
-        ps = [params[k, :n, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(OPS)]
-        ref, _ = cpu_ref.run_sequence(x, OPS, ps, opt)
-        ref_loss = cpu_ref.l1_loss(ref, tgt[:n])
-        ref_loss.backward()
-        ex = t2onet_amd.Executor(t2onet_amd.default_options()).cuda()
-        xg = img[:n].cuda().requires_grad_(True)
-        pg = params[:, :n].cuda().requires_grad_(True)
-        loss, out = ex.run_sequence_fused(xg, OPS, pg, tgt[:n].cuda())
-        loss.backward()
-        gerr = (xg.grad.cpu() - x.grad).abs().max().item() / max(x.grad.abs().max().item(), 1e-30)
-        res['parity'] = {'images': n, 'fwd_max_abs_err': (out.detach().cpu() - ref.detach()).abs().max().item(),
-                         'loss_abs_dev': abs(loss.item() - ref_loss.item()),
-                         'gimg_max_err_rel_to_max': gerr, 'tolerance': 1e-5}
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('model name'):
+                    model = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    phys = None
+    try:
+        out = subprocess.run(['lscpu', '-p=CORE,SOCKET'], capture_output=True, text=True).stdout
+        phys = len({ln for ln in out.splitlines() if ln and not ln.startswith('#')})
+    except OSError:
+        pass
+    return {'cpu_model': model, 'logical_cpus': os.cpu_count(), 'physical_cores': phys}
+
+
+def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=8, with_gpu_parity=True):
+    """configs[0] (one image, brightness->contrast->saturation), configs[1] (6-op
+    sequence fwd + L1 + bwd) and a bounded sample of configs[2] (the episode/L1 train step), each through
+    oracle/cpu_ref.py -- the eager-PyTorch restatement of the reference, validated against it by the
+    committed goldens -- on this node's host cores."""
+    import torch
+    from oracle import cpu_ref, synth
+    opt = cpu_ref.default_opt()
+    host = _host_info()
+
+    def seq_once(ops, img, tgt, params):
+        x = img.clone().requires_grad_(True)
+        ps = [params[k, :, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(ops)]
+        out, _ = cpu_ref.run_sequence(x, ops, ps, opt)
+        cpu_ref.l1_loss(out, tgt).backward()
+
+    img, tgt, params = make_inputs(CFG2_OPS, sample_cfg2, H, W, 'cpu')
+    threads = _pick_threads(lambda: seq_once(CFG2_OPS, img[:8], tgt[:8], params[:, :8]))
+    med2, n2 = _median_time(lambda: seq_once(CFG2_OPS, img, tgt, params), 7, 25.0)
+    res = {'value': round(sample_cfg2 / med2, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+           'config': 'configs[1]',
+           'sample': 'oracle/cpu_ref.py eager fp32, ops %s fwd+L1+bwd, bs=%d %dx%d, median of %d reps (%.2f s each), '
+                     '%d torch threads (chosen by a probe)' % (CFG2_OPS, sample_cfg2, H, W, n2, med2, threads),
+           'host': host}
+    # configs[0]: single 256x256 image, 3-op sequence, forward + L1 + backward
+    ops1 = [0, 1, 2]
+    i1, t1, p1 = make_inputs(ops1, 1, H, W, 'cpu')
+    torch.set_num_threads(min(threads, 8))
+    med1, n1 = _median_time(lambda: seq_once(ops1, i1, t1, p1), 15, 5.0)
+    res['cfg1'] = {'value': round(1.0 / med1, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+                   'config': 'configs[0]', 'sample': 'one %dx%d image, ops %s fwd+L1+bwd, median of %d reps (%.4f s each)'
+                                                     % (H, W, ops1, n1, med1)}
+    torch.set_num_threads(threads)
+    # configs[2]: episode/L1 train step on a bounded sample (fwd + END select + L1 + bwd + Adam), 1 warm-up + 1..2 reps
+    try:
+        B3 = sample_cfg3
+        sd = cpu_ref.make_leaf_params(synth.fill_state_dict(cpu_ref.actor_state_skeleton(opt)))
+        leaves = [v for v in sd.values() if v.requires_grad]
+        adam = torch.optim.Adam(leaves, lr=1e-3)
+        ximg, xtgt = synth.images(B3, H, W, 21), synth.images(B3, H, W, 22)
+        req = synth.requests(B3, 17, 23)
+        gen = torch.Generator().manual_seed(10)
+
+        def train_once():
+            adam.zero_grad(set_to_none=True)
+            r = cpu_ref.episode_forward(sd, req, ximg, opt, reinforce_sample=1, training=True, generator=gen)
+            pred = cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], opt.end_id)
+            cpu_ref.l1_loss(pred, xtgt).backward()
+            adam.step()
+        med3, n3 = _median_time(train_once, 2, 20.0)
+        res['cfg3'] = {'value': round(B3 / med3, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+                       'config': 'configs[2]',
+                       'sample': 'oracle episode_forward (training mode, sampled ops) + END select + L1 + backward + Adam, '
+                                 'bs=%d %dx%d, median of %d reps after 1 warm-up (%.2f s each)' % (B3, H, W, n3, med3)}
     except Exception as e:                     # noqa: BLE001
-        res['parity'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        res['cfg3'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if with_gpu_parity:
+        # parity gate reported with the numbers (SURVEY 8(d)): the GPU path against the oracle on 4 images
+        try:
+            import t2onet_amd
+            n = min(4, sample_cfg2)
+            x = img[:n].clone().requires_grad_(True)
+            ps = [params[k, :n, :PARAM_RANGES[op][0]].clone().requires_grad_(True) for k, op in enumerate(CFG2_OPS)]
+            ref, _ = cpu_ref.run_sequence(x, CFG2_OPS, ps, opt)
+            ref_loss = cpu_ref.l1_loss(ref, tgt[:n])
+            ref_loss.backward()
+            ex = t2onet_amd.Executor(t2onet_amd.default_options()).cuda()
+            xg = img[:n].cuda().requires_grad_(True)
+            pg = params[:, :n].cuda().requires_grad_(True)
+            loss, out = ex.run_sequence_fused(xg, CFG2_OPS, pg, tgt[:n].cuda())
+            loss.backward()
+            gerr = (xg.grad.cpu() - x.grad).abs().max().item() / max(x.grad.abs().max().item(), 1e-30)
+            res['parity'] = {'images': n, 'fwd_max_abs_err': (out.detach().cpu() - ref.detach()).abs().max().item(),
+                             'loss_abs_dev': abs(loss.item() - ref_loss.item()),
+                             'gimg_max_err_rel_to_max': gerr, 'tolerance': 1e-5}
+        except Exception as e:                     # noqa: BLE001
+            res['parity'] = {'error': '%s: %s' % (type(e).__name__, e)}
     return res
 
 
-def train_step_bench(device, dist, world, B, H, W, steps, warmup):
-    """BASELINE.json configs[2]/[3]: the episode/L1 train step of train_seq2seqL1.py:74-88 (request
-    encoder + 5 x (ResNet features + attention decoder step + sampled per-sample operator) +
-    END-image select + L1 + backward + one flat gradient all-reduce + Adam), FiveK-shaped synthetic
-    batch, random-init weights, fp32."""
-    import t2onet_amd
-    from t2onet_amd.actor import Actor
-    from t2onet_amd.train import Trainer
-    opt = t2onet_amd.default_options()
-    torch.manual_seed(10 + (dist.get_rank() if dist is not None else 0))
-    model = Actor(opt).to(device).train()
-    # (NHWC: the ResNet alone is 20 % faster, tools/bench_resnet.py, but the whole step measured
-    # slower -- 122 vs 94 ms -- so the default stays NCHW; Actor.use_channels_last() switches)
-    if dist is not None:                                   # identical replicas
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
-    # hipGraph capture of the image encoder: on for the single-process run.  With a process group alive the
-    # RCCL watchdog thread can touch the device during a (global-mode) capture and invalidate it on one rank
-    # only, which would leave the other ranks waiting in the gradient all-reduce -- not worth risking in a
-    # benchmark that cannot be rehearsed on this pool; T2O_GRAPH_ENCODER=1 forces it.
-    want_graph = os.environ.get('T2O_GRAPH_ENCODER', '1' if dist is None else '0') != '0'
-    tr = Trainer(model, opt, graph_encoder=want_graph)
-    g = torch.Generator().manual_seed(10)
-    img = torch.rand(B, 3, H, W, generator=g).to(device)
-    tgt = torch.rand(B, 3, H, W, generator=g).to(device)
+# ---------------------------------------------------------------------------------------------
+# train step (the headline)
+# ---------------------------------------------------------------------------------------------
+def synthetic_requests(B, g):
+    import torch
     n = torch.randint(1, 16, (B,), generator=g)
     x = torch.zeros(B, 17, dtype=torch.long)
     for b in range(B):
@@ -342,13 +529,36 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
         x[b, 0] = 1
         x[b, 1:1 + k] = torch.randint(4, 918, (k,), generator=g)
         x[b, 1 + k] = 2
+    return x
+
+
+def train_step_bench(ctx, B, H, W, steps, warmup):
+    """BASELINE.json configs[2]/[3]: the episode/L1 train step of train_seq2seqL1.py:74-88, FiveK-shaped
+    synthetic batch, random-init weights, fp32; exactly `steps` timed steps."""
+    import torch
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    dist, world, device = ctx['dist'], ctx['world'], ctx['device']
+    opt = t2onet_amd.default_options()
+    torch.manual_seed(10 + ctx['rank'])
+    model = Actor(opt).to(device).train()
+    if os.environ.get('T2O_NHWC', '0') != '0':
+        model.use_channels_last()
+    if dist is not None:                                   # identical replicas
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    want_graph = os.environ.get('T2O_GRAPH_ENCODER', '1') != '0'
+    tr = Trainer(model, opt, graph_encoder=want_graph)
+    g = torch.Generator().manual_seed(10 + ctx['rank'])
+    img = torch.rand(B, 3, H, W, generator=g).to(device)
+    tgt = torch.rand(B, 3, H, W, generator=g).to(device)
+    x = synthetic_requests(B, g)
     lengths = (x != 0).sum(1)
     x = x.to(device)
     for _ in range(warmup):
         tr.episode_step(x, img, tgt, lengths=lengths)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    ctx['barrier']()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.episode_step(x, img, tgt, lengths=lengths)
@@ -357,174 +567,229 @@ def train_step_bench(device, dist, world, B, H, W, steps, warmup):
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return {'images_per_sec': round(world * B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 2),
+    dt = ctx['max_over_ranks'](time.perf_counter() - t0)
+    flop = TRAIN_FLOP_PER_IMAGE * (H * W) / (256.0 * 256.0) * B
+    tf = flop / (dt / steps) / 1e12                        # per GPU
+    return {'images_per_sec': round(world * B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 3),
             'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 2),
             'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()),
+            'encoder_hipgraphs': bool(tr.graph_encoder and '_graphed_encoders' in model.__dict__),
+            'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
+                         'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,
+                         'note': 'whole step against the dense fp32 matrix peak: 5 x ResNet-18 forward+backward = '
+                                 '67.8 GFLOP/image at 256x256 (SURVEY 8(d)); per GPU'},
             'workload': 'episode/L1 train step (train_seq2seqL1.py:74-88), bs=%d/GPU %dx%d fp32, sampled ops, '
                         'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
-    ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=64)
-    ap.add_argument('--train-steps', type=int, default=3,
-                    help='also time this many full episode/L1 train steps (BASELINE configs[2]/[3], with the flat '
-                         'gradient all-reduce when N > 1) -> "train_step"; 0 to skip')
-    ap.add_argument('--train-warmup', type=int, default=2)
-    ap.add_argument('--train-timeout', type=int, default=420, help='seconds before the train-step leg is abandoned')
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------
+# selftest worker: the launcher / rendezvous / timing / aggregation path on CPU with gloo
+# ---------------------------------------------------------------------------------------------
+def selftest_worker(args):
+    """No GPU, no product path: a stand-in step (a small CPU all-reduce) run through exactly the rank set-up,
+    barrier-bracketed timing, MAX-over-ranks and rank-0 JSON code the real benchmark uses.  tests/ drive it at
+    world_size 2 (gloo) to prove `bench.py --gpus N` starts N ranks."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: WORLD_SIZE %d != --gpus %d\n' % (world, args.gpus))
+        return 2
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    buf = torch.ones(1 << 16) * (rank + 1)
 
+    def step():
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.div_(world)
+        else:
+            buf.mul_(1.0)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        seen = torch.zeros(world)
+        seen[rank] = os.getpid()
+        dist.all_reduce(seen)
+        pids = [int(v) for v in seen.tolist()]
+    else:
+        pids = [os.getpid()]
+    if rank == 0:
+        print(json.dumps({'metric': 'selftest steps/sec (launcher path only, not a benchmark)', 'selftest': True,
+                          'value': round(args.steps / dt, 1), 'unit': 'steps/sec', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+                          'config': {'world_size': world, 'backend': 'gloo', 'rank_pids': pids},
+                          'mean_after_allreduce': float(buf[0])}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+def worker(args):
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: WORLD_SIZE %d != --gpus %d (start it as `python bench.py --gpus N` or under '
+                         'torch.distributed.run with --nproc-per-node N)\n' % (world, args.gpus))
+        return 2
     if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+        sys.stderr.write('bench.py needs a GPU (the product path has no CPU fallback)\n')
+        return 2
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     dist = None
-    if world > 1 or 'RANK' in os.environ:          # launched by torch.distributed.run (also with one rank)
+    backend_info = {'world_size': world, 'backend': None}
+    if world > 1 or 'RANK' in os.environ:          # launched by this script's launcher or torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-
-    B, H, W = args.batch, args.size, args.size
-    P = B * H * W
+        backend_info['backend'] = 'nccl (RCCL)'
+        try:
+            backend_info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                      # noqa: BLE001
+            backend_info['rccl_version'] = None
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(run):
-        for _ in range(args.warmup):
-            run.step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run.step()
-        torch.cuda.synchronize()
+    def max_over_ranks(el):
+        if dist is None:
+            return el
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ctx = {'dist': dist, 'world': world, 'rank': rank, 'device': device, 'barrier': barrier, 'max_over_ranks': max_over_ranks}
+    B, H, W = args.batch, args.size, args.size
+    P = B * H * W
+    line = {
+        'metric': 'images/sec (train step: episode forward + END select + L1 + backward + gradient all-reduce + Adam, '
+                  'bs=%d/GPU, %dx%d fp32)' % (B, H, W),
+        'value': None, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': dict({'workload': 'BASELINE.json configs[%d]: full T2ONet episode/L1 train step (train_seq2seqL1.py:74-88), '
+                                    'bs=%d per GPU, %dx%d fp32, FiveK-shaped synthetic batch, random-init weights'
+                                    % (2 if world == 1 else 3, B, H, W),
+                        'global_batch': world * B,
+                        'parallelism': 'dp%d: batch shards, one flat fp32 gradient all-reduce (22.2 M floats) per step' % world},
+                       **backend_info),
+    }
+    executor = {}
+    try:
+        executor['cfg2_bs64'] = executor_leg(ctx, CFG2_OPS, B, H, W, args.exec_steps, args.exec_warmup, with_api=(world == 1))
+        if not args.quick:
+            executor['bs256'] = executor_leg(ctx, CFG2_OPS, 4 * B, H, W, max(args.exec_steps // 4, 10), max(args.exec_warmup // 2, 3))
+            executor['cfg5_16x512'] = executor_leg(ctx, CFG5_OPS, max(B // 4, 1), 2 * H, 2 * W, args.exec_steps, args.exec_warmup)
+        fk = executor['cfg2_bs64']['fused']['kernels']
+        dom = max(fk, key=lambda n: fk[n]['ms'])
+        line['roofline'] = {
+            'bound': 'hbm', 'kernel': dom, 'of': 'executor.cfg2_bs64.fused', 'achieved': fk[dom]['GBps'], 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(fk[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, P),
+            'algorithmic_bytes_per_launch': algorithmic_bytes(dom, P), 'avg_launch_ms': fk[dom]['ms'],
+            'note': 'dominant hand-written kernel of the op pipeline. algorithmic bytes = SURVEY 8(d) per-operator figure x '
+                    'operator applications in the launch (materialised accounting); a fused launch moves only hbm_min '
+                    'bytes, so frac includes fusion credit: fused_min_* give the fraction on the bytes it must move; '
+                    'traffic = PMC bytes when profiles/pmc_traffic.json was measured on this very library, else null',
+            'fused_min_bytes_per_launch': hbm_min_bytes(dom, P), 'fused_min_achieved': fk[dom]['hbm_min_GBps'],
+            'fused_min_frac': round(fk[dom]['hbm_min_GBps'] / HBM_PEAK_GBS, 4)}
+    except Exception as e:                     # noqa: BLE001
+        executor['error'] = '%s: %s' % (type(e).__name__, e)
+    line['executor'] = executor
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baselines(H, W, args.cpu_sample, args.cpu_train_sample)
+
+    rc = [0]
+    if args.no_train:
+        line['error'] = '--no-train: executor legs only, no headline value'
+        if rank == 0:
+            print(json.dumps(line), flush=True)
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        # second pass: the same launches, one HIP-event pair per kernel pair
-        rec = {}
-        for _ in range(args.steps):
-            run.profiled_step(rec)
-        torch.cuda.synchronize()
-        kernels = {}
-        for name, evs in rec.items():
-            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-            by = algorithmic_bytes(name, P)
-            kernels[name] = {'ms': round(ms, 5), 'algorithmic_MB': round(by / 1e6, 2), 'GBps': round(by / ms / 1e6, 1),
-                             'hbm_min_MB': round(hbm_min_bytes(name, P) / 1e6, 2),
-                             'hbm_min_GBps': round(hbm_min_bytes(name, P) / ms / 1e6, 1)}
-        return el, kernels, float(run.loss.item())
+            dist.destroy_process_group()
+        return 0
 
-    mat_elapsed, mat_kernels, mat_loss = measure(SequenceRunner(B, H, W, device))
-    torch.cuda.empty_cache()
-    elapsed, kernels, loss_value = measure(FusedRunner(B, H, W, device))
-    dom = max(kernels, key=lambda n: kernels[n]['ms'])
-    total_bytes = (6 * 60 + 12) * P                      # K*60*P + 12*P
-    sum_ms = sum(k['ms'] for k in kernels.values())
+    def emit():
+        if rank == 0:
+            print(json.dumps(line), flush=True)
 
-    api = None
+    # the train leg is the headline.  A hang in it (one rank failing inside a collective) must still leave a line
+    # with everything measured so far: a timer THREAD prints it and exits non-zero (a signal handler would not run
+    # while the main thread sits in a blocking device call).  Nothing GPU-side is touched from the timer thread.
+    def on_timeout():
+        line['error'] = 'train step did not finish within %d s' % args.train_timeout
+        emit()
+        os._exit(3)
+    watchdog = threading.Timer(args.train_timeout, on_timeout)
+    watchdog.daemon = True
+    watchdog.start()
     try:
-        api = api_path_bench(B, H, W, device, args.steps, args.warmup)
-    except Exception as e:                     # noqa: BLE001
-        api = {'error': '%s: %s' % (type(e).__name__, e)}
-    torch.cuda.empty_cache()
-
-    def emit(train):
-        if rank != 0:
-            return
-        ms_per_step = elapsed / args.steps * 1e3
-        n_gpus = world
-        line = {
-            'metric': 'images/sec (executor step: 6-op sequence fwd + L1 + bwd, bs=64/GPU, 256x256 fp32)',
-            'value': round(n_gpus * B * args.steps / elapsed, 1),
-            'unit': 'images/sec',
-            'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: bs=%d/GPU %dx%d fp32, executor ops %s forward + L1 + '
-                                   'backward to all parameters and the image, via t2o_fused_sequence_fwd/bwd (C ABI): '
-                                   'per-pixel operators fused in registers, sharpness+L1 stencil kernels' % (B, H, W, OPS),
-                       'global_batch': n_gpus * B, 'parallelism': 'batch shards, no collective on the executor path'},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['GBps'], 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, P),
-                         'algorithmic_bytes_per_launch': algorithmic_bytes(dom, P),
-                         'avg_launch_ms': kernels[dom]['ms'],
-                         'note': 'algorithmic bytes = SURVEY 8(d) per-operator figure x operator applications in the '
-                                 'launch (materialised accounting); a fused launch moves only hbm_min bytes, so frac can '
-                                 'exceed what HBM alone allows: fused_min_* give the fraction on the bytes it must move',
-                         'fused_min_bytes_per_launch': hbm_min_bytes(dom, P),
-                         'fused_min_achieved': kernels[dom]['hbm_min_GBps'],
-                         'fused_min_frac': round(kernels[dom]['hbm_min_GBps'] / HBM_PEAK_GBS, 4)},
-            'step_roofline': {'algorithmic_GB_per_step': round(total_bytes / 1e9, 4),
-                              'achieved_GBps_whole_step': round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                              'frac_of_peak': round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              'sum_kernel_ms': round(sum_ms, 4)},
-            'kernels': kernels,
-            'loss': loss_value,
-            'materialised_path': {
-                'what': 'same step through t2o_sequence_fwd/bwd: one kernel pair per operator, all 6 intermediates in '
-                        'HBM (what 6 Executor.execute calls + autograd do); HBM traffic = the algorithmic 1.56 GB',
-                'value': round(n_gpus * B * args.steps / mat_elapsed, 1), 'unit': 'images/sec',
-                'ms_per_step': round(mat_elapsed / args.steps * 1e3, 4),
-                'achieved_GBps_whole_step': round(total_bytes / (mat_elapsed / args.steps) / 1e9, 1),
-                'frac_of_peak': round(total_bytes / (mat_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                'loss': mat_loss, 'kernels': mat_kernels},
-        }
-        if api is not None:
-            line['executor_api_path'] = api
-        if train is not None:
-            line['train_step'] = train
-        if not args.no_cpu_baseline and n_gpus == 1:
-            line['cpu_baseline'] = cpu_baseline(args.cpu_sample, H, W)
-        print(json.dumps(line))
-
-    train = None
-    if args.train_steps > 0:
-        # secondary measurement: it must never take the headline line down.  Exceptions are reported in the
-        # line; a hang (e.g. one rank failing inside a collective) is cut by an alarm that still prints the line.
-        # (a timer THREAD: a signal handler would not run while the main thread sits in a blocking device call)
-        import threading
-
-        def on_timeout():
-            emit({'error': 'train step did not finish within %d s' % args.train_timeout})
-            sys.stdout.flush()
-            os._exit(0)
-        watchdog = threading.Timer(args.train_timeout, on_timeout)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            train = train_step_bench(device, dist, world, B, H, W, args.train_steps, args.train_warmup)
-        except Exception as e:                 # noqa: BLE001
-            train = {'error': '%s: %s' % (type(e).__name__, e)}
-        watchdog.cancel()
-    emit(train)
+        train = train_step_bench(ctx, B, H, W, args.steps, args.warmup)
+        line['value'] = train['images_per_sec']
+        line['ms_per_step'] = train['ms_per_step']
+        line['train_step'] = train
+        line['train_roofline'] = train['roofline']
+    except Exception as e:                 # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        line['error'] = 'train step: %s: %s' % (type(e).__name__, e)
+        rc[0] = 1
+    watchdog.cancel()
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return rc[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20, help='timed train steps')
+    ap.add_argument('--warmup', type=int, default=5, help='untimed train steps (the first also captures the encoder hipGraphs)')
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--exec-steps', type=int, default=200, help='timed steps of each executor leg')
+    ap.add_argument('--exec-warmup', type=int, default=20)
+    ap.add_argument('--quick', action='store_true', help='skip the bs=256 and cfg5 executor legs')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train', action='store_true',
+                    help='executor legs only (profiling passes; the line then has no headline value)')
+    ap.add_argument('--cpu-sample', type=int, default=64, help='images of the configs[1] CPU baseline')
+    ap.add_argument('--cpu-train-sample', type=int, default=8, help='images of the configs[2] CPU baseline')
+    ap.add_argument('--train-timeout', type=int, default=600, help='seconds before the train-step leg is abandoned')
+    ap.add_argument('--launch-timeout', type=int, default=1500, help='launcher: seconds before the ranks are stopped')
+    ap.add_argument('--selftest', action='store_true',
+                    help='CPU/gloo stand-in step through the launcher, rendezvous and timing code (tests only)')
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return launch(args, sys.argv[1:])
+    if args.selftest:
+        return selftest_worker(args)
+    return worker(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -1,0 +1,53 @@
+"""bench.py --gpus N must start N ranks itself (or refuse): driven here with the gloo stand-in step
+(`--selftest`), world size 2, through the same launcher / rendezvous / MAX-over-ranks / rank-0 JSON code."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _run(argv, env=None):
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + argv, capture_output=True, text=True, env=e, timeout=300)
+
+
+def test_launcher_starts_two_ranks_and_relays_one_line():
+    r = _run(['--gpus', '2', '--selftest', '--steps', '4', '--warmup', '1'])
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['world_size'] == 2 and d['config']['backend'] == 'gloo'
+    pids = d['config']['rank_pids']
+    assert len(set(pids)) == 2 and 0 not in pids            # two distinct processes took part in the collective
+    assert d['steps'] == 4 and d['warmup'] == 1 and d['ms_per_step'] > 0
+    assert abs(d['mean_after_allreduce'] - 1.5) < 1e-6      # mean of ranks' (rank + 1): the all-reduce really ran
+
+
+def test_refuses_to_run_on_fewer_devices_than_asked():
+    r = _run(['--gpus', '2', '--steps', '1'])                # no GPU in the build container
+    assert r.returncode == 2 and 'refusing' in r.stderr and '{' not in r.stdout
+
+
+def test_rank_refuses_a_world_size_that_is_not_gpus():
+    r = _run(['--gpus', '4', '--selftest'], env={'RANK': '0', 'WORLD_SIZE': '1'})
+    assert r.returncode == 2 and 'WORLD_SIZE 1 != --gpus 4' in r.stderr
+
+
+def test_under_torch_distributed_run():
+    """The driver's own launch form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ..."""
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29731', BENCH, '--gpus', '2', '--selftest',
+                        '--steps', '3', '--warmup', '1'], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2

@@ -3,17 +3,26 @@ import json
 import sys
 
 d = json.loads((open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()).strip().splitlines()[-1])
-print('value %.0f img/s  ms/step %.4f  dominant %s frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac']))
-for k, v in d['kernels'].items():
-    print('   %-20s %8.2f us  %7.0f GB/s alg  %7.0f GB/s min' % (k, v['ms'] * 1e3, v['GBps'], v.get('hbm_min_GBps', 0)))
-m = d.get('materialised_path')
-if m:
-    print(' materialised: %.0f img/s  ms/step %.4f  frac %.3f' % (m['value'], m['ms_per_step'], m['frac_of_peak']))
-    for k, v in m['kernels'].items():
-        print('   %-20s %8.2f us  %7.0f GB/s' % (k, v['ms'] * 1e3, v['GBps']))
-if 'cpu_baseline' in d:
-    print(' cpu:', d['cpu_baseline'])
-if 'train_step' in d:
-    print(' train:', d['train_step'])
-if 'executor_api_path' in d:
-    print(' api path:', d['executor_api_path'])
+print('HEADLINE train step: %s img/s  %s ms/step  (n_gpus %s)  %s' % (d.get('value'), d.get('ms_per_step'), d.get('n_gpus'), d.get('error', '')))
+t = d.get('train_step')
+if t:
+    print('   host enqueue %.1f ms, graphs %s, mfma frac %.3f (%.1f TF/s), loss %.5f' % (
+        t['host_enqueue_ms_per_step'], t.get('encoder_hipgraphs'), t['roofline']['frac'], t['roofline']['achieved'], t['loss']))
+r = d.get('roofline')
+if r:
+    print('roofline: %s %.0f GB/s frac %.3f (moved-bytes frac %.3f) traffic %s' % (r['kernel'], r['achieved'], r['frac'], r['fused_min_frac'], r['traffic']))
+for name, leg in d.get('executor', {}).items():
+    if not isinstance(leg, dict):
+        print('executor', name, leg)
+        continue
+    for path in ('fused', 'materialised'):
+        m = leg[path]
+        print('%-12s %-12s %9.0f img/s  %8.4f ms/step  frac %.3f' % (name, path, m['value'], m['ms_per_step'], m['frac_of_peak']))
+        for k, v in m['kernels'].items():
+            print('      %-22s %8.2f us  %7.0f GB/s alg  %7.0f GB/s moved' % (k, v['ms'] * 1e3, v['GBps'], v.get('hbm_min_GBps', 0)))
+    if 'api_path' in leg:
+        print('   api path:', leg['api_path'])
+c = d.get('cpu_baseline')
+if c:
+    print('cpu cfg2: %s img/s on %s threads; cfg1 %s; cfg3 %s; host %s' % (c['value'], c['cores'], c.get('cfg1', {}).get('value'), c.get('cfg3', {}).get('value', c.get('cfg3')), c.get('host')))
+    print('   parity:', c.get('parity'))

@@ -5,7 +5,7 @@ TAG=${1:-pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --train-steps 0"   # counters + captured hipGraphs abort the profiler: executor kernels only
+CMD="python bench.py --quick --exec-steps 4 --exec-warmup 2 --no-cpu-baseline --no-train"   # counters + captured hipGraphs abort the profiler: executor kernels only
 rocprofv3 -L > $OUT/counters.txt 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/sq -- $CMD > $OUT/sq.log 2>&1; echo "sq rc=$?"
 timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/sq2 -- $CMD > $OUT/sq2.log 2>&1; echo "sq2 rc=$?"
