@@ -170,6 +170,20 @@ int t2o_bn_relu_bwd(const float* x, const float* y, const float* dy, const float
                     float* dweight, float* dbias, int has_res, void* workspace, size_t workspace_bytes,
                     int N, int C, int HW, void* stream);
 
+/* The same pair on channels-last activations: x, res, out, y, dy, dx, dres are (M, C) with M = N*H*W rows of C
+ * contiguous channels (torch.channels_last storage of an (N,C,H,W) tensor), the layout the convolutions run in
+ * natively on MI355X.  C must be a power of two in [4, 1024].  Same arithmetic, same running-statistics update.
+ * workspace: t2o_bn_nhwc_workspace_bytes(M, C). */
+size_t t2o_bn_nhwc_workspace_bytes(int M, int C);
+int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, const float* bias,
+                         float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* out,
+                         float momentum, float eps, void* workspace, size_t workspace_bytes,
+                         int M, int C, void* stream);
+int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
+                         const float* save_mean, const float* save_invstd, float* dx, float* dres,
+                         float* dweight, float* dbias, int has_res, void* workspace, size_t workspace_bytes,
+                         int M, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,8 +77,10 @@ class Actor(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def use_channels_last(self, on=True):
-        """Run the ResNet in NHWC: MIOpen's fp32 NHWC kernels are ~20 % faster on MI355X
-        (tools/bench_resnet.py).  Same fp32 arithmetic; state_dict shapes are unchanged."""
+        """Run the image encoder channels-last end to end: MIOpen's fp32 implicit-GEMM kernels are NHWC-native
+        on MI355X (NCHW calls pay transposes around them: tools/bench_conv_layers.py, 10.9 -> 9.4 ms of
+        convolutions per encoder pass at bs=64 256x256) and the fused batch-norm kernels have an NHWC form.
+        Same fp32 arithmetic; state_dict shapes are unchanged."""
         self._nhwc = bool(on)
         self.vis_encoder.to(memory_format=torch.channels_last if on else torch.contiguous_format)
         return self
@@ -87,43 +89,20 @@ class Actor(nn.Module):
         """relu(bn1(vis_encoder(img))) (actor.py:142-143, :215-216).  `call` = index of this encoder call
         inside the step (0, 1, ...): selects the captured hipGraph of that call when graph_image_encoder()
         has been run for this image shape."""
-        if getattr(self, '_nhwc', False):
-            # the operators work on NCHW planes; give MIOpen a packed NHWC copy (12 B/pixel, once per step)
-            img = img.contiguous(memory_format=torch.channels_last)
         graphed = self.__dict__.get('_graphed_encoders')
-        if (graphed is not None and call is not None and call < len(graphed) and self.training
-                and tuple(img.shape) == self.__dict__['_graphed_shape'] and torch.is_grad_enabled()):
-            return F.relu(self.bn1(graphed[call](img)))
+        if graphed is not None and self.training and graphed.usable(img, call):
+            return F.relu(self.bn1(graphed(img, call)))
         return F.relu(self.bn1(self.vis_encoder(img)))
 
     def graph_image_encoder(self, sample_img, calls):
-        """Capture the image encoder's forward and backward as hipGraphs, one pair per encoder call of a
-        step (the activations of all `calls` forwards are alive until the backward, so every call needs its
-        own graph memory).  ~350 kernel launches per encoder forward+backward become 2 graph launches: the
-        train step is host-bound otherwise.  Training mode, fixed (B,3,H,W); anything else runs eagerly.
-        The wrappers share vis_encoder's parameters and are not registered as submodules (state_dict and
-        parameters() are unchanged)."""
-        class _Call(nn.Module):
-            def __init__(self, enc):
-                super().__init__()
-                self.enc = enc
-
-            def forward(self, img):
-                return self.enc(img)
-
-        wrappers = tuple(_Call(self.vis_encoder).train() for _ in range(calls))
-        samples = tuple((sample_img.detach().clone().requires_grad_(k > 0),) for k in range(calls))
-        # capture runs warm-up iterations: keep them out of the batch-norm running statistics (restored in
-        # place, the graphs keep pointing at the same buffers); parameter .grad does receive the warm-up
-        # gradients -- zero it before the next real step (Trainer does)
-        buffers = list(self.vis_encoder.buffers())
-        saved = [t.clone() for t in buffers]
-        graphed = torch.cuda.make_graphed_callables(wrappers, samples)
-        with torch.no_grad():
-            for t, keep in zip(buffers, saved):
-                t.copy_(keep)
-        self.__dict__['_graphed_encoders'] = graphed
-        self.__dict__['_graphed_shape'] = tuple(sample_img.shape)
+        """Capture the image encoder's forward and backward as hipGraphs, one pair per encoder call of a step
+        (t2onet_amd/graphs.py): ~350 kernel launches per encoder forward+backward become 2 graph launches and the
+        parameter gradients are accumulated into the existing .grad tensors inside the backward graph.  Training
+        mode, fixed (B,3,H,W); anything else runs eagerly.  Needs persistent .grad tensors (Trainer's flat
+        buffer).  Not a submodule: state_dict and parameters() are unchanged."""
+        from .graphs import GraphedEncoder
+        self.vis_encoder.train()
+        self.__dict__['_graphed_encoders'] = GraphedEncoder(self.vis_encoder, sample_img, calls)
         return self
 
     def get_gt_mask(self, img, mask_dict, op):

@@ -6,6 +6,7 @@ apply pass (t2o_bn_relu_fwd / _bwd); evaluation mode and CPU tensors take PyTorc
 Module names follow the reference so its checkpoints load."""
 import os
 
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -63,6 +64,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def forward(self, x):
+        if self.conv1.weight.is_contiguous(memory_format=torch.channels_last) and x.is_cuda:
+            # channels-last encoder (Actor.use_channels_last): one packed NHWC copy of the 3-channel image, then every
+            # convolution and every fused batch-norm pass runs NHWC -- no layout transposes inside the encoder
+            x = x.contiguous(memory_format=torch.channels_last)
         x = _bn_relu(self.bn1, self.conv1(x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = x.mean((2, 3))

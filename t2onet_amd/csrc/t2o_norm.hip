@@ -91,11 +91,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_stats(BnArgs a) {
   block_sum2_store(sum, sq, a.partials + ((size_t)c * a.splits + s) * 2);
 }
 
-__global__ __launch_bounds__(kThreads) void k_bn_finalize(BnArgs a) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= a.C) return;
-  double sum = 0.0, sq = 0.0;
-  for (int s = 0; s < a.splits; ++s) { sum += a.partials[((size_t)c * a.splits + s) * 2]; sq += a.partials[((size_t)c * a.splits + s) * 2 + 1]; }
+// per-channel epilogue of the statistics pass: mean, biased variance -> invstd, scale / shift, running statistics
+__device__ __forceinline__ void bn_finalize_channel(const BnArgs& a, int c, double sum, double sq) {
   const double m = (double)a.N * a.HW;
   const double mean = sum / m;
   double var = sq / m - mean * mean;
@@ -111,6 +108,14 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize(BnArgs a) {
     a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
     a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
   }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_finalize(BnArgs a) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= a.C) return;
+  double sum = 0.0, sq = 0.0;
+  for (int s = 0; s < a.splits; ++s) { sum += a.partials[((size_t)c * a.splits + s) * 2]; sq += a.partials[((size_t)c * a.splits + s) * 2 + 1]; }
+  bn_finalize_channel(a, c, sum, sq);
 }
 
 // channel of flat element e (32-bit arithmetic when the tensor has < 2^32 elements: the 64-bit divide is
@@ -208,17 +213,22 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_sums(BnArgs a) {
   block_sum2_store(sg, sgx, a.partials + ((size_t)c * a.splits + s) * 2);
 }
 
-__global__ __launch_bounds__(kThreads) void k_bn_bwd_finalize(BnArgs a) {
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= a.C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (int s = 0; s < a.splits; ++s) { sg += a.partials[((size_t)c * a.splits + s) * 2]; sgx += a.partials[((size_t)c * a.splits + s) * 2 + 1]; }
+// per-channel epilogue of the backward sums: dgamma, dbeta and the coefficients of the apply pass
+__device__ __forceinline__ void bn_bwd_finalize_channel(const BnArgs& a, int c, double sg, double sgx) {
   const double m = (double)a.N * a.HW;
   if (a.dbias) a.dbias[c] = (float)sg;
   if (a.dweight) a.dweight[c] = (float)sgx;
   a.coef[c] = a.weight[c] * a.save_invstd[c];     // a_c
   a.coef[a.C + c] = (float)(sg / m);             // mean of g
   a.coef[2 * a.C + c] = (float)(sgx / m);        // mean of g * xhat
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_finalize(BnArgs a) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= a.C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int s = 0; s < a.splits; ++s) { sg += a.partials[((size_t)c * a.splits + s) * 2]; sgx += a.partials[((size_t)c * a.splits + s) * 2 + 1]; }
+  bn_bwd_finalize_channel(a, c, sg, sgx);
 }
 
 template <int V, bool HAS_RES>
@@ -272,6 +282,195 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(BnArgs a, size_t tota
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NHWC (channels-last) forms: x is (M, C) with M = N*H*W rows of C contiguous channels -- the layout MIOpen's
+// fp32 implicit-GEMM kernels run in natively, so the encoder needs no layout transposes around its convolutions.
+// Thread t of a 256-thread workgroup owns the channel quad (t % (C/4)) for the whole kernel: its scale / shift /
+// mean coefficients are loaded ONCE into registers (no per-element channel arithmetic at all), every access is
+// a 16-byte load of 4 consecutive channels, a wave reads 1 KiB of consecutive memory.  C must be a power of two
+// in [4, 1024] (the encoder: 64 / 128 / 256 / 512).
+//   sums kernels   workgroup b reduces rows [b * rows_per_block, ...): per-thread fp32, LDS across the R = 1024/C
+//                  row slots of the workgroup, one (2, C) fp32 row of partials per workgroup
+//   finalize       fp64 over the workgroups' partials in a fixed order, then exactly the NCHW finalize arithmetic
+//   apply kernels  flat over the float4s, kUnroll independent loads per thread
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kNhwcMaxBlocks = 1024;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+
+// reduce the workgroup's per-thread quads over its R row slots and store one partial row: dst[0..C) and dst[C..2C)
+__device__ __forceinline__ void nhwc_block_store(float4 s1, float4 s2, int q, float* dst, int C) {
+  __shared__ float4 sm[2][kThreads];
+  sm[0][threadIdx.x] = s1;
+  sm[1][threadIdx.x] = s2;
+  __syncthreads();
+  if ((int)threadIdx.x < q) {
+    float4 a = sm[0][threadIdx.x], b = sm[1][threadIdx.x];
+    for (int t = threadIdx.x + q; t < kThreads; t += q) {          // fixed order
+      const float4 u = sm[0][t], v = sm[1][t];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dst + 4 * threadIdx.x) = a;
+    *reinterpret_cast<float4*>(dst + C + 4 * threadIdx.x) = b;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_stats(BnArgs a, int M, int rows_per_block, float* partial) {
+  const int q = a.C >> 2, cq = threadIdx.x % q, r = threadIdx.x / q, R = kThreads / q;
+  const int row0 = blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, M);
+  const float* base = a.x + 4 * cq;
+  float4 s = f4(0.0f), ss = f4(0.0f);
+  for (int row = row0 + r; row < row1; row += R * kUnroll) {
+    float4 v[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const int rr = row + k * R;
+      v[k] = rr < row1 ? ld4(base + (size_t)rr * a.C) : f4(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w;
+      ss.x += v[k].x * v[k].x; ss.y += v[k].y * v[k].y; ss.z += v[k].z * v[k].z; ss.w += v[k].w * v[k].w;
+    }
+  }
+  nhwc_block_store(s, ss, q, partial + (size_t)blockIdx.x * 2 * a.C, a.C);
+}
+
+// partial (nblk, 2, C) fp32 -> per-channel fp64 totals in a fixed order, then the channel epilogue.  A workgroup
+// takes 4 channels: thread = (slice s of 64, channel quad), each slice adds the workgroups b = s, s + 64, ...
+// (one 16-byte load per partial row), slices are combined through LDS by the first 4 threads.
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize(BnArgs a, const float* partial, int nblk) {
+  __shared__ double sm[2][kThreads / 64][4];
+  const int sl = threadIdx.x >> 2, j = threadIdx.x & 3;
+  const int c = blockIdx.x * 4 + j;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = sl; b < nblk; b += 64) {
+    s0 += (double)partial[(size_t)b * 2 * a.C + c];
+    s1 += (double)partial[(size_t)b * 2 * a.C + a.C + c];
+  }
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {                 // the 16 slices of this wave (lane = slice * 4 + channel)
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < 4) { sm[0][wave][lane] = s0; sm[1][wave][lane] = s1; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    s0 = (sm[0][0][j] + sm[0][1][j]) + (sm[0][2][j] + sm[0][3][j]);
+    s1 = (sm[1][0][j] + sm[1][1][j]) + (sm[1][2][j] + sm[1][3][j]);
+    if (BWD) bn_bwd_finalize_channel(a, c, s0, s1); else bn_finalize_channel(a, c, s0, s1);
+  }
+}
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply(BnArgs a, size_t total4) {
+  const int q = a.C >> 2, cq = threadIdx.x % q;
+  const float4 sc = ld4(a.coef + 4 * cq), sh = ld4(a.coef + a.C + 4 * cq);
+  const size_t span = (size_t)kThreads * kUnroll, stride = (size_t)gridDim.x * span;
+  for (size_t i0 = (size_t)blockIdx.x * span + threadIdx.x; i0 < total4; i0 += stride) {
+    float4 v[kUnroll], rs[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      const bool in = i < total4;
+      v[k] = in ? ld4(a.x + 4 * i) : f4(0.0f);
+      rs[k] = (HAS_RES && in) ? ld4(a.res + 4 * i) : f4(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      if (i >= total4) break;
+      float4 o = make_float4(v[k].x * sc.x + sh.x, v[k].y * sc.y + sh.y, v[k].z * sc.z + sh.z, v[k].w * sc.w + sh.w);
+      if (HAS_RES) { o.x += rs[k].x; o.y += rs[k].y; o.z += rs[k].z; o.w += rs[k].w; }
+      o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f);
+      *reinterpret_cast<float4*>(a.out + 4 * i) = o;
+    }
+  }
+}
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_sums(BnArgs a, int M, int rows_per_block, float* partial) {
+  constexpr int U = 2;
+  const int q = a.C >> 2, cq = threadIdx.x % q, r = threadIdx.x / q, R = kThreads / q;
+  const int row0 = blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, M);
+  const float4 mean = ld4(a.save_mean + 4 * cq), invstd = ld4(a.save_invstd + 4 * cq);
+  const float4 w = ld4(a.weight + 4 * cq), bi = ld4(a.bias + 4 * cq);
+  const float4 sc = make_float4(w.x * invstd.x, w.y * invstd.y, w.z * invstd.z, w.w * invstd.w);
+  const float4 sh = make_float4(bi.x - mean.x * sc.x, bi.y - mean.y * sc.y, bi.z - mean.z * sc.z, bi.w - mean.w * sc.w);
+  float4 sg = f4(0.0f), sgx = f4(0.0f);
+  for (int row = row0 + r; row < row1; row += R * U) {
+    float4 xq[U], dq[U], yq[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int rr = row + k * R;
+      const bool in = rr < row1;
+      const size_t off = (size_t)rr * a.C + 4 * cq;
+      xq[k] = in ? ld4(a.x + off) : f4(0.0f);
+      dq[k] = in ? ld4(a.dy + off) : f4(0.0f);
+      yq[k] = (HAS_RES && in) ? ld4(a.y + off) : f4(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const float g0 = gated<HAS_RES>(dq[k].x, xq[k].x, yq[k].x, sc.x, sh.x), g1 = gated<HAS_RES>(dq[k].y, xq[k].y, yq[k].y, sc.y, sh.y);
+      const float g2 = gated<HAS_RES>(dq[k].z, xq[k].z, yq[k].z, sc.z, sh.z), g3 = gated<HAS_RES>(dq[k].w, xq[k].w, yq[k].w, sc.w, sh.w);
+      sg.x += g0; sg.y += g1; sg.z += g2; sg.w += g3;
+      sgx.x += g0 * ((xq[k].x - mean.x) * invstd.x); sgx.y += g1 * ((xq[k].y - mean.y) * invstd.y);
+      sgx.z += g2 * ((xq[k].z - mean.z) * invstd.z); sgx.w += g3 * ((xq[k].w - mean.w) * invstd.w);
+    }
+  }
+  nhwc_block_store(sg, sgx, q, partial + (size_t)blockIdx.x * 2 * a.C, a.C);
+}
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply(BnArgs a, size_t total4) {
+  constexpr int U = 2;
+  const int q = a.C >> 2, cq = threadIdx.x % q;
+  const float4 mean = ld4(a.save_mean + 4 * cq), invstd = ld4(a.save_invstd + 4 * cq), bi = ld4(a.bias + 4 * cq);
+  const float4 ac = ld4(a.coef + 4 * cq), mg = ld4(a.coef + a.C + 4 * cq), mgx = ld4(a.coef + 2 * a.C + 4 * cq);
+  const float4 sh = make_float4(bi.x - mean.x * ac.x, bi.y - mean.y * ac.y, bi.z - mean.z * ac.z, bi.w - mean.w * ac.w);
+  const size_t span = (size_t)kThreads * U, stride = (size_t)gridDim.x * span;
+  for (size_t i0 = (size_t)blockIdx.x * span + threadIdx.x; i0 < total4; i0 += stride) {
+    float4 xq[U], dq[U], yq[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      const bool in = i < total4;
+      xq[k] = in ? ld4(a.x + 4 * i) : f4(0.0f);
+      dq[k] = in ? ld4(a.dy + 4 * i) : f4(0.0f);
+      yq[k] = (HAS_RES && in) ? ld4(a.y + 4 * i) : f4(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      if (i >= total4) break;
+      float4 g;
+      g.x = gated<HAS_RES>(dq[k].x, xq[k].x, yq[k].x, ac.x, sh.x); g.y = gated<HAS_RES>(dq[k].y, xq[k].y, yq[k].y, ac.y, sh.y);
+      g.z = gated<HAS_RES>(dq[k].z, xq[k].z, yq[k].z, ac.z, sh.z); g.w = gated<HAS_RES>(dq[k].w, xq[k].w, yq[k].w, ac.w, sh.w);
+      float4 o;
+      o.x = ac.x * ((g.x - mg.x) - ((xq[k].x - mean.x) * invstd.x) * mgx.x);
+      o.y = ac.y * ((g.y - mg.y) - ((xq[k].y - mean.y) * invstd.y) * mgx.y);
+      o.z = ac.z * ((g.z - mg.z) - ((xq[k].z - mean.z) * invstd.z) * mgx.z);
+      o.w = ac.w * ((g.w - mg.w) - ((xq[k].w - mean.w) * invstd.w) * mgx.w);
+      *reinterpret_cast<float4*>(a.out + 4 * i) = o;
+      if (HAS_RES && a.dres) *reinterpret_cast<float4*>(a.dres + 4 * i) = g;
+    }
+  }
+}
+
+bool nhwc_channels_ok(int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0; }
+// rows per workgroup (a multiple of the workgroup's R = 1024 / C row slots x the unroll) and the workgroup count
+void nhwc_partition(int M, int C, int unroll, int* rows_per_block, int* nblk) {
+  const int R = kThreads / (C >> 2), step = R * unroll;
+  int rpb = (M + kNhwcMaxBlocks - 1) / kNhwcMaxBlocks;
+  rpb = ((rpb + step - 1) / step) * step;
+  *rows_per_block = rpb;
+  *nblk = (M + rpb - 1) / rpb;
 }
 
 int bn_splits(int N, int C) {
@@ -349,6 +548,63 @@ int t2o_bn_relu_bwd(const float* x, const float* y, const float* dy, const float
   k_bn_bwd_finalize<<<(C + kThreads - 1) / kThreads, kThreads, 0, st>>>(a);
   if (v4) { if (has_res) k_bn_bwd_apply<4, true><<<flat_grid(total, 4, 2), kThreads, 0, st>>>(a, total); else k_bn_bwd_apply<4, false><<<flat_grid(total, 4, 2), kThreads, 0, st>>>(a, total); }
   else    { if (has_res) k_bn_bwd_apply<1, true><<<flat_grid(total, 1, 2), kThreads, 0, st>>>(a, total); else k_bn_bwd_apply<1, false><<<flat_grid(total, 1, 2), kThreads, 0, st>>>(a, total); }
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
+}
+
+size_t t2o_bn_nhwc_workspace_bytes(int M, int C) {
+  (void)M;
+  return sizeof(double) * 2 * (size_t)C + sizeof(float) * 4 * (size_t)C + sizeof(float) * 2 * (size_t)C * kNhwcMaxBlocks;   // (the fp64 slot is unused now, kept for alignment)
+}
+
+int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
+                         float* running_var, float* save_mean, float* save_invstd, float* out, float momentum, float eps,
+                         void* workspace, size_t workspace_bytes, int M, int C, void* stream) {
+  if (!x || M <= 0 || !nhwc_channels_ok(C) || !weight || !bias || !save_mean || !save_invstd || !out)
+    return set_error(T2O_EINVAL, "bn_relu_nhwc_fwd: null pointer or bad shape (C must be a power of two in [4, 1024])");
+  if ((running_mean == nullptr) != (running_var == nullptr))
+    return set_error(T2O_EINVAL, "bn_relu_nhwc_fwd: running_mean and running_var must both be given or both be null");
+  if (!workspace || workspace_bytes < t2o_bn_nhwc_workspace_bytes(M, C)) return set_error(T2O_EWORKSPACE, "bn_relu_nhwc_fwd: workspace too small");
+  BnArgs a = {};
+  a.x = x; a.res = res; a.out = out; a.weight = weight; a.bias = bias;
+  a.running_mean = running_mean; a.running_var = running_var; a.save_mean = save_mean; a.save_invstd = save_invstd;
+  a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.eps = eps; a.momentum = momentum;     // finalize: m = N * HW = M
+  a.partials = (double*)workspace;
+  a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
+  float* partial = a.coef + 4 * (size_t)C;
+  hipStream_t st = (hipStream_t)stream;
+  int rpb, nblk;
+  nhwc_partition(M, C, kUnroll, &rpb, &nblk);
+  k_bn_nhwc_stats<<<nblk, kThreads, 0, st>>>(a, M, rpb, partial);
+  k_bn_nhwc_finalize<false><<<C / 4, kThreads, 0, st>>>(a, partial, nblk);
+  const size_t total4 = (size_t)M * (C >> 2);
+  const unsigned grid = flat_grid(total4, 1, kUnroll);
+  if (res) k_bn_nhwc_apply<true><<<grid, kThreads, 0, st>>>(a, total4); else k_bn_nhwc_apply<false><<<grid, kThreads, 0, st>>>(a, total4);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
+}
+
+int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
+                         const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
+                         float* dbias, int has_res, void* workspace, size_t workspace_bytes, int M, int C, void* stream) {
+  if (!x || M <= 0 || !nhwc_channels_ok(C) || !dy || !weight || !bias || !save_mean || !save_invstd || !dx)
+    return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd: null pointer or bad shape (C must be a power of two in [4, 1024])");
+  if (has_res && !y) return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd: y is needed when a residual was added");
+  if (!workspace || workspace_bytes < t2o_bn_nhwc_workspace_bytes(M, C)) return set_error(T2O_EWORKSPACE, "bn_relu_nhwc_bwd: workspace too small");
+  BnArgs a = {};
+  a.x = x; a.y = y; a.dy = dy; a.out = dx; a.dres = dres; a.weight = weight; a.bias = bias;
+  a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
+  a.dweight = dweight; a.dbias = dbias;
+  a.N = M; a.C = C; a.HW = 1; a.splits = 1;
+  a.partials = (double*)workspace;
+  a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
+  float* partial = a.coef + 4 * (size_t)C;
+  hipStream_t st = (hipStream_t)stream;
+  int rpb, nblk;
+  nhwc_partition(M, C, 2, &rpb, &nblk);
+  if (has_res) k_bn_nhwc_bwd_sums<true><<<nblk, kThreads, 0, st>>>(a, M, rpb, partial); else k_bn_nhwc_bwd_sums<false><<<nblk, kThreads, 0, st>>>(a, M, rpb, partial);
+  k_bn_nhwc_finalize<true><<<C / 4, kThreads, 0, st>>>(a, partial, nblk);
+  const size_t total4 = (size_t)M * (C >> 2);
+  const unsigned grid = flat_grid(total4, 1, 2);
+  if (has_res) k_bn_nhwc_bwd_apply<true><<<grid, kThreads, 0, st>>>(a, total4); else k_bn_nhwc_bwd_apply<false><<<grid, kThreads, 0, st>>>(a, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 

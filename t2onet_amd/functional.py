@@ -214,27 +214,43 @@ def attention_core(q, context):
     return _AttnFn.apply(q, context)
 
 
+def _is_nhwc(x):
+    """4-D activations stored channels-last with a channel count the NHWC kernels take (power of two in [4, 1024])."""
+    C = x.shape[1]
+    return (x.dim() == 4 and C >= 4 and C <= 1024 and (C & (C - 1)) == 0 and x.shape[2] * x.shape[3] > 1
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
 class _BnReluFn(torch.autograd.Function):
-    """relu(batch_norm(x) (+ res)) with batch statistics (training mode), running stats updated in place."""
+    """relu(batch_norm(x) (+ res)) with batch statistics (training mode), running stats updated in place.
+    Channels-last activations stay channels-last (t2o_bn_relu_nhwc_*); anything else runs on NCHW planes."""
 
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, momentum, eps):
         _need_gpu(x, res, weight, bias)
-        x = x.contiguous()
-        res = None if res is None else res.contiguous()
+        nhwc = _is_nhwc(x)
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        x = x.contiguous(memory_format=fmt)
+        res = None if res is None else res.contiguous(memory_format=fmt)
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         lib = _lib.load()
-        out = torch.empty_like(x)
+        out = torch.empty_like(x)                              # preserves the memory format
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = _bn_workspace(lib, N, C, x.device)
-        rc = lib.t2o_bn_relu_fwd(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
-                                 _ptr(save_mean), _ptr(save_invstd), _ptr(out), float(momentum), float(eps),
-                                 _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
+        ws = _bn_workspace(lib, N, C, x.device, nhwc, HW)
+        if nhwc:
+            rc = lib.t2o_bn_relu_nhwc_fwd(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                          _ptr(save_mean), _ptr(save_invstd), _ptr(out), float(momentum), float(eps),
+                                          _ptr(ws), ws.numel(), N * HW, C, _stream(x.device))
+        else:
+            rc = lib.t2o_bn_relu_fwd(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                                     _ptr(save_mean), _ptr(save_invstd), _ptr(out), float(momentum), float(eps),
+                                     _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
         _lib.check(rc, 't2o_bn_relu_fwd')
         ctx.save_for_backward(x, out if res is not None else None, weight, bias, save_mean, save_invstd)
         ctx.has_res = res is not None
+        ctx.nhwc = nhwc
         return out
 
     @staticmethod
@@ -243,15 +259,20 @@ class _BnReluFn(torch.autograd.Function):
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         lib = _lib.load()
-        dy = dy.contiguous()
+        dy = dy.contiguous(memory_format=torch.channels_last if ctx.nhwc else torch.contiguous_format)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res and ctx.needs_input_grad[1] else None
         dweight = torch.empty_like(weight)
         dbias = torch.empty_like(bias)
-        ws = _bn_workspace(lib, N, C, x.device)
-        rc = lib.t2o_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean), _ptr(save_invstd),
-                                 _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), 1 if ctx.has_res else 0,
-                                 _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
+        ws = _bn_workspace(lib, N, C, x.device, ctx.nhwc, HW)
+        if ctx.nhwc:
+            rc = lib.t2o_bn_relu_nhwc_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean),
+                                          _ptr(save_invstd), _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias),
+                                          1 if ctx.has_res else 0, _ptr(ws), ws.numel(), N * HW, C, _stream(x.device))
+        else:
+            rc = lib.t2o_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean), _ptr(save_invstd),
+                                     _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), 1 if ctx.has_res else 0,
+                                     _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
         _lib.check(rc, 't2o_bn_relu_bwd')
         return dx, dres, dweight, dbias, None, None, None, None
 
@@ -259,11 +280,12 @@ class _BnReluFn(torch.autograd.Function):
 _bn_ws = {}
 
 
-def _bn_workspace(lib, N, C, device):
-    key = (device.index, _stream(device), N, C)
+def _bn_workspace(lib, N, C, device, nhwc=False, HW=1):
+    key = (device.index, _stream(device), N, C, nhwc)
     ws = _bn_ws.get(key)
     if ws is None:
-        ws = _bn_ws[key] = torch.empty(lib.t2o_bn_workspace_bytes(N, C), dtype=torch.uint8, device=device)
+        nbytes = lib.t2o_bn_nhwc_workspace_bytes(N * HW, C) if nhwc else lib.t2o_bn_workspace_bytes(N, C)
+        ws = _bn_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return ws
 
 

@@ -33,7 +33,11 @@ class FlatGradients:
         self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            # same strides as the parameter (channels-last convolution weights stay channels-last): optimiser and
+            # gradient accumulation then run their dense fast paths; the flat all-reduce does not care about layout
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            seg = self.flat[off:off + p.numel()]
+            p.grad = seg.as_strided(p.size(), p.stride()) if dense else seg.view_as(p)
             off += p.numel()
 
     def zero(self):
@@ -62,18 +66,14 @@ class Trainer:
         if self.graph_encoder and img.is_cuda and '_graphed_encoders' not in self.model.__dict__:
             self.model.train()
             try:
-                self.model.graph_image_encoder(img, self.opt.decoder_max_len)
-                # the captured backward hands its parameter gradients over from the capture stream: expected here
-                quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
-                if quiet is not None:
-                    quiet(False)
+                # one slot per encoder call of either step: decoder_max_len for the episode, one more for the
+                # teacher-forced step (its y holds decoder_max_len operators + END) -- no step mixes replayed and eager calls
+                self.model.graph_image_encoder(img, self.opt.decoder_max_len + 1)
             except Exception as e:                     # noqa: BLE001 -- an optimisation only: run eagerly instead
                 import warnings
                 warnings.warn('image-encoder graph capture failed (%s: %s); continuing without it' % (type(e).__name__, e))
                 self.graph_encoder = False
-            # capture ran warm-up forwards/backwards: drop what they left in the gradient buffer (the
-            # batch-norm running statistics are restored by graph_image_encoder itself)
-            self.grads.zero()
+            # (the warm-up iterations neither touch .grad nor leave anything in the batch-norm running statistics)
 
     def _finish(self, loss):
         self.grads.zero()
