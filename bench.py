@@ -543,7 +543,7 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
     opt = t2onet_amd.default_options()
     torch.manual_seed(10 + ctx['rank'])
     model = Actor(opt).to(device).train()
-    if os.environ.get('T2O_NHWC', '0') != '0':
+    if os.environ.get('T2O_NHWC', '1') != '0':
         model.use_channels_last()
     if dist is not None:                                   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):

@@ -135,12 +135,22 @@ class Actor(nn.Module):
     # ------------------------------------------------------------------ teacher forcing
     def supervised_forward(self, x, y, img_x, img_y, gt_params, mask, lengths=None):
         """actor.py:116-181.  Returns (pred_imgs (B,step-2,3,H,W), pred_params (B,step-2,24),
-        pred_logprobs (B,step-1,n_cls))."""
+        pred_logprobs (B,step-1,n_cls)).
+
+        mask: None (every caller of the reference) or the documented (B, step-2, 1|3, H, W) local-edit masks,
+        one per executed step: step i blends with mask[:, i-1].  The reference unpacks a 5-D mask the same way
+        (actor.py:136-137) but then hands the WHOLE 5-D tensor to every operator, which only broadcasts for one
+        sample and one masked step; in that case both give the same images (golden `sup_mask_*`).  Anything
+        that is not 5-D fails the reference's unpack and is rejected here too."""
         if mask is not None:
-            raise NotImplementedError('local-edit masks belong to the GIER path (SURVEY.md 8(f) rank 4)')
+            if mask.dim() != 5 or mask.shape[0] != x.shape[0] or mask.shape[2] not in (1, 3):
+                raise ValueError('mask must be (bs, n_steps, 1|3, h, w), got %s' % (tuple(mask.shape),))
+            mask = mask.to(img_x.device)
         enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
         hidden = self.decoder._init_state(enc_hidden)
         step = int((y != self.null_id).sum(1).max())
+        if mask is not None and mask.shape[1] < step - 2:
+            raise ValueError('mask covers %d steps, the operator sequence has %d' % (mask.shape[1], step - 2))
         pred_params, pred_imgs, logprobs = [], [], []
         ops = y[:, 0].unsqueeze(-1)
         for i in range(1, step):
@@ -150,7 +160,7 @@ class Actor(nn.Module):
             ops = y[:, i].unsqueeze(-1)
             if i == step - 1:
                 break
-            out, par = self._execute(img_x, ops, context)
+            out, par = self._execute(img_x, ops, context, None if mask is None else mask[:, i - 1])
             pred_imgs.append(out)
             pred_params.append(par)
             img_x = img_y[:, i - 1]                        # next input = planned ground-truth intermediate

@@ -311,6 +311,186 @@ def gen_data():
     print('data.npz: %d arrays' % len(g))
 
 
+
+# --------------------------------------------------------------------------
+GRAD_PICKS = [  # (parameter name, slice) -- small tensors whole, big ones a corner: element-wise gradient parity
+    ('decoder.out_linear.weight', None), ('decoder.out_linear.bias', None),
+    ('executor.contrast_op.fc2.weight', None), ('executor.color_op.fc2.weight', None), ('executor.tone_op.fc1.bias', None),
+    ('vis_encoder.conv1.weight', None), ('vis_encoder.layer4.1.bn2.weight', None), ('vis_encoder.fc.bias', None),
+    ('vis_encoder.layer2.0.conv1.weight', (slice(0, 8), slice(0, 8))),
+    ('lang_encoder.rnn.weight_hh_l0', (slice(0, 32), slice(0, 64))), ('lang_encoder.rnn.bias_ih_l1_reverse', None),
+    ('decoder.rnn.weight_ih_l1', (slice(0, 32), slice(0, 64))), ('decoder.vis_linear.bias', None),
+    ('decoder.attention.linear_out.weight', (slice(0, 16), slice(0, 128))), ('bn1.weight', None),
+    ('lang_encoder.embedding.weight', (slice(0, 8), slice(0, 32))),
+]
+
+
+def _store_grads(g, prefix, model):
+    named = dict(model.named_parameters())
+    for name, sl in GRAD_PICKS:
+        q = named[name]
+        t = torch.zeros_like(q) if q.grad is None else q.grad
+        g[prefix + name] = (t if sl is None else t[sl]).detach().numpy().copy()
+
+
+def gen_extra(opt):
+    """Second actor fixture file (extra.npz): full gradient tensors, Actor.forward, local-edit masks,
+    has_noise.  Same weights / inputs as gen_actor (seed 7, dropout 0)."""
+    from models.actor import Actor
+    from executors.executor import Executor
+    torch.manual_seed(0)
+    opt.input_dropout_p = 0.0
+    opt.dropout_p = 0.0
+    model = Actor(opt)
+    model.load_state_dict(synth.fill_state_dict(model.state_dict(), seed=7))
+    g = {'grad_picks': np.array([n for n, _ in GRAD_PICKS])}
+    B, H, W, L = 4, 64, 64, opt.encoder_max_len
+    x = synth.requests(B, L, 41)
+    img = synth.images(B, H, W, 42)
+    tgt = synth.images(B, H, W, 43)
+
+    # ---- element-wise gradients of the two train steps (train mode, argmax episode)
+    model.train()
+    model.zero_grad()
+    state, pred_imgs, pred_ops, pred_params = model.episode_forward(x, img, None, reinforce_sample=0)
+    picked = []
+    for b in range(B):
+        idxs = (pred_ops[b] == opt.end_id).nonzero()
+        col = idxs[0][0] if len(idxs) > 0 else pred_imgs.shape[1] - 1
+        picked.append(pred_imgs[b, col])
+    torch.abs(torch.stack(picked) - tgt).mean().backward()
+    _store_grads(g, 'ep_train_grad:', model)
+    model.load_state_dict(synth.fill_state_dict(model.state_dict(), seed=7))
+    y = synth.op_targets(B, 45)
+    img_y = synth.uniform((B, 6, 3, H, W), 46)
+    gt_params = synth.uniform((B, 5, 24), 47, -1, 1)
+    nparam = {3: 1, 4: 1, 5: 1, 6: 24, 8: 8, 9: 1}
+    for b in range(B):
+        for k in range(5):
+            gt_params[b, k, nparam[int(y[b, k + 1])]:] = 0
+    model.zero_grad()
+    _, sp, sl = model.supervised_forward(x, y, img, img_y, gt_params, mask=None)
+    step = (y != opt.null_id).sum(1).max().item()
+    op_loss = torch.nn.NLLLoss()(sl.view(-1, 11), y[:, 1:step].contiguous().view(-1))
+    param_loss = torch.nn.MSELoss(reduction='sum')(sp, gt_params[:, :step - 2]) / ((gt_params[:, :step - 2] != 0).sum())
+    (op_loss + param_loss).backward()
+    _store_grads(g, 'sup_train_grad:', model)
+    model.load_state_dict(synth.fill_state_dict(model.state_dict(), seed=7))
+
+    # ---- Actor.forward (models/actor.py:286-354), eval mode; the sampled operator is stored so that a
+    # counterpart with a different sampler can be fed the same draw
+    model.eval()
+    with torch.no_grad():
+        _, enc_hidden, _ = model.lang_encoder(x)
+        hidden = model.decoder._init_state(enc_hidden)
+    op0 = torch.full((B,), opt.start_id, dtype=torch.long)
+    drawn = {}
+    import torch.distributions as D
+    orig_sample = D.Categorical.sample
+
+    def spy_sample(self, *a, **k):
+        r = orig_sample(self, *a, **k)
+        drawn['op'], drawn['probs'] = r.clone(), self.probs.clone()
+        return r
+    D.Categorical.sample = spy_sample
+    torch.manual_seed(5)
+    with torch.no_grad():
+        pred_img, logp, ent, ctx, nctx = model.forward(x, img, hidden, op0)
+    D.Categorical.sample = orig_sample
+    g['fwd_pred_op'] = drawn['op'].numpy()
+    g['fwd_op_probs'] = drawn['probs'].numpy()
+    g['fwd_logprob'] = logp.numpy()
+    g['fwd_entropy_penalty'] = ent.numpy()
+    g['fwd_context'] = ctx.numpy()
+    g['fwd_next_context'] = nctx.numpy()
+    g['fwd_pred_img_crop'] = pred_img[:, :, 8:24, 8:24].numpy()
+    g['fwd_pred_img_mean'] = pred_img.double().mean((1, 2, 3)).numpy()
+    lp = synth.uniform((3, 11), 71, -4.0, -0.5)
+    g['entropy_penalty_2d'] = model.get_entropy_penalty(lp).numpy()
+
+    # ---- local-edit masks: get_gt_mask (actor.py:78-98) and episode_forward(mask_dict) (eval, argmax).
+    # The reference hard-codes .cuda(); on this CPU-only container it is made the identity for the call.
+    mask_dict = []
+    for b in range(B):
+        d = {}
+        for op_id in (3, 4, 5, 6, 8, 9):
+            if (b + op_id) % 3 != 0:                   # some samples have no mask for some operators -> all-ones
+                m = (synth.uniform((1, 1, H, W), 600 + 10 * b + op_id) > 0.4).float().numpy()
+                d[str(op_id)] = [m]
+        if b == 2:
+            d['4'] = ['not an array']                  # the reference's bare except: falls back to ones
+        mask_dict.append(d)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ops_probe = np.array([[3], [4], [4], [9]])
+        g['gt_mask_probe_ops'] = ops_probe
+        g['gt_mask_probe'] = model.get_gt_mask(img, mask_dict, ops_probe).numpy()
+        with torch.no_grad():
+            state, pi, po, pp = model.episode_forward(x, img, mask_dict, reinforce_sample=0)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    g['mask_ep_pred_ops'] = po.numpy()
+    g['mask_ep_pred_params'] = torch.stack(pp, 0).numpy()
+    g['mask_ep_imgs_crop'] = pi[:, :, :, 8:24, 8:24].numpy()
+    g['mask_ep_imgs_mean'] = pi.double().mean((2, 3, 4)).numpy()
+    g['mask_ep_masks_mean'] = state['masks'].double().mean((2, 3, 4)).numpy()
+    g['mask_dict_keys'] = np.array([','.join(sorted(d.keys())) for d in mask_dict])
+
+    # ---- supervised_forward with a mask: the reference unpacks a 5-D mask and hands the WHOLE (m,L,1,h,w) tensor to
+    # the operator, which only broadcasts for one sample and one masked step (bs = 1, L = 1); that case is pinned.
+    x1, img1 = x[:1], img[:1]
+    y1 = torch.tensor([[opt.start_id, 4, opt.end_id, 0, 0, 0, 0]])
+    img_y1 = synth.uniform((1, 6, 3, H, W), 48)
+    m5 = (synth.uniform((1, 1, 1, H, W), 49) > 0.5).float()
+    with torch.no_grad():
+        pi1, pp1, pl1 = model.supervised_forward(x1, y1, img1, img_y1, torch.zeros(1, 5, 24), m5)
+    g['sup_mask_imgs'] = pi1.reshape(1, 1, 3, H, W)[:, :, :, 8:24, 8:24].numpy()
+    g['sup_mask_imgs_mean'] = np.array(pi1.double().mean().item())
+    g['sup_mask_params'] = pp1.numpy()
+    g['sup_mask_logprobs'] = pl1.numpy()
+
+    # ---- has_noise (operators.py:57-60, :118-121): CPU generator seeded right before each call
+    ex = Executor(opt)
+    ex.load_state_dict(synth.fill_state_dict(ex.state_dict(), seed=3))
+    im = synth.images(3, 24, 20, 11)
+    for op in [0, 1, 2, 3, 5, 6]:
+        p = synth.op_params(op, 3, 100 + 10 * op, 'mid')
+        torch.manual_seed(100 + op)
+        out, par = ex.execute(im, op, None, specified_param=p, has_noise=True)
+        g['noise_op%d_out' % op] = out.numpy()
+        g['noise_op%d_param' % op] = par.numpy()
+    np.savez_compressed(os.path.join(OUT, 'extra.npz'), **g)
+    print('extra.npz: %d arrays' % len(g))
+
+
+def gen_planner(opt):
+    """utils/beam_search.py: get_param (Nelder-Mead) and beam_search on one 32x32 pair, operations [0,1,2]."""
+    import utils.beam_search as bs
+    from executors.executor import Executor
+    ex = Executor(opt)
+    names = ['brightness', 'contrast', 'saturation', 'color', 'inpaint', 'tone', 'sharpness', 'white']
+    I0 = synth.images(1, 32, 32, 61)
+    mid, _ = ex.execute(I0, 0, None, specified_param=torch.tensor([[0.25]]))
+    tgt, _ = ex.execute(mid, 1, None, specified_param=torch.tensor([[0.3]]))
+    g = {'target': tgt.numpy()}
+    with torch.no_grad():
+        for op in (0, 1, 2, 6):
+            p, ok = bs.get_param(I0, tgt, None, op, ex, None, 'L1', 'Nelder-Mead')
+            g['nm_param_op%d' % op] = p.numpy()
+            g['nm_dist_op%d' % op] = np.array(bs.get_dist(bs.execute(I0, op, p, ex), tgt, 'L1').item())
+            g['nm_ok_op%d' % op] = np.array(bool(ok))
+        actions, Is = bs.beam_search(I0, tgt, None, ex, None, 2, [0, 1, 2], names, 3, 1e-3, 'L1', 'Nelder-Mead')
+    g['beam_n'] = np.array(len(actions))
+    for k, seq in enumerate(actions):
+        g['beam%d_ops' % k] = np.array([names.index(a[0]) for a in seq])
+        g['beam%d_params' % k] = np.array([a[1][0] for a in seq], dtype=np.float64)
+        g['beam%d_dists' % k] = np.array([a[2] for a in seq], dtype=np.float64)
+        g['beam%d_final_crop' % k] = Is[k][-1][:, :, 8:24, 8:24].numpy()
+    np.savez_compressed(os.path.join(OUT, 'planner.npz'), **g)
+    print('planner.npz: %d arrays' % len(g), {k: v for k, v in g.items() if k.startswith('beam') and 'crop' not in k})
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'run in the build container (needs /root/reference)'
     os.makedirs(OUT, exist_ok=True)
@@ -322,7 +502,13 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'data':
         gen_data()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'extra':          # extra.npz / planner.npz only (the others are unchanged)
+        gen_extra(opt)
+        gen_planner(opt)
+        sys.exit(0)
     gen_operators(opt)
     gen_ssim()
     gen_actor(opt)
     gen_data()
+    gen_extra(reference_opt())
+    gen_planner(reference_opt())
