@@ -184,6 +184,18 @@ int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const 
                          float* dweight, float* dbias, int has_res, void* workspace, size_t workspace_bytes,
                          int M, int C, void* stream);
 
+/* ---- 3x3 stride-1 padding-1 convolution of the image encoder, weight gradient (models/actor_resnet.py:27-44,
+ * the BasicBlock convolutions) on the fp32 matrix cores (t2o_conv.hip).  Replaces the library's weight-gradient call
+ * (torch.ops.aten.convolution_backward, output_mask [0,1,0]) for these layers.
+ *   x  (N,H,W,Ci) and dy (N,H,W,Co): NHWC = torch.channels_last storage of (N,C,H,W) tensors
+ *   dw (Co,3,3,Ci)                 = channels_last storage of a (Co,Ci,3,3) weight gradient
+ *   dw[co][kh][kw][ci] = sum_{n,h,w} dy[n][h][w][co] * x[n][h+kh-1][w+kw-1][ci]   (zero padding)
+ * Ci and Co must be multiples of 64.  Deterministic: split-K partial sums in `workspace`
+ * (t2o_conv3x3_wgrad_workspace_bytes) are added in a fixed order. */
+size_t t2o_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
+int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                           int N, int H, int W, int Ci, int Co, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

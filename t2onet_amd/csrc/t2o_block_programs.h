@@ -834,6 +834,109 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same backward for an operator list known at COMPILE time (template arguments): the two sweeps are
+// unrolled over the operators, so there is no `for k` / `switch (op)` control flow and none of its scalar
+// traffic, every operator's raw parameter sums live in their own registers for ALL the thread's pixels and
+// are flushed (quad reduction + owner-lane LDS add) once per thread instead of once per pixel, and the saved
+// operator inputs are plain registers (no LDS save area).  Same arithmetic per pixel as chain_bwd_thread.
+// Instantiated for the sequences callers actually fix ahead of time (t2o_kernels.hip: kStaticChains).
+template <int... OPS>
+struct StaticChain {
+  static constexpr int K = sizeof...(OPS);
+  static constexpr int ops[K > 0 ? K : 1] = {OPS...};
+};
+T2O_HD constexpr int chain_nred(int op) { return op == OP_COLOR ? 24 : op == OP_TONE ? 8 : op == OP_WHITE ? 0 : 1; }
+
+template <bool L1, class SEQ, bool SV_LDS, class ACC>
+T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* svl, ACC& acc) {
+  constexpr int K = SEQ::K;
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const size_t sb = (size_t)b * 3 * hw;
+  const float* xin = a.img + sb;
+  const float* gin = (L1 ? a.target : a.gout) + sb;
+  const float gs = L1 ? a.gloss[0] * a.inv_n : 0.0f;
+  float red[K][24];                                  // statically indexed everywhere: registers, unused entries vanish
+  T2O_UNROLL
+  for (int k = 0; k < K; ++k) red[k][0] = 0.0f;      // curve rows are ASSIGNED on the first pixel instead
+  // software prefetch: the loads of pixel it+1 are issued before the ~900 vector instructions of pixel it, so the
+  // 3 waves per SIMD this kernel's registers allow no longer sit in s_waitcnt at the top of every iteration
+  // (SQ_WAIT_ANY was 33 % of the wave cycles without it)
+  float xn[3], gn[3];
+  {
+    const unsigned g0 = ((unsigned)blk * a.iters) * kThreads + tid;
+    const unsigned p0 = g0 < hw ? g0 : 0;
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) { xn[c] = xin[c * hw + p0]; gn[c] = gin[c * hw + p0]; }
+  }
+  for (int it = 0; it < a.iters; ++it) {
+    const unsigned g = ((unsigned)blk * a.iters + it) * kThreads + tid;
+    const bool live = g < hw;                        // dead threads carry zeros into the reductions
+    const unsigned px = live ? g : 0;
+    float x[3], gg[3], sv[SV_LDS ? 1 : K][3];        // SV_LDS: operator inputs saved in the LDS area instead (fewer registers)
+    unsigned pass = 0u;
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) { x[c] = xn[c]; gg[c] = gn[c]; }
+    if (it + 1 < a.iters) {
+      const unsigned g1 = g + kThreads;
+      const unsigned p1 = g1 < hw ? g1 : 0;
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) { xn[c] = xin[c * hw + p1]; gn[c] = gin[c * hw + p1]; }
+    }
+    T2O_UNROLL
+    for (int k = 0; k < K; ++k) {
+      Rgb xi = {{x[0], x[1], x[2]}};
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        if (SV_LDS) svl[(k * 3 + c) * kThreads + tid] = xi.c[c]; else sv[k][c] = xi.c[c];
+      }
+      const Rgb r = chain_op_fwd(SEQ::ops[k], xi, tab + k * kTabStride);
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        pass |= (r.c[c] >= 0.0f && r.c[c] <= 1.0f) ? (1u << (3 * k + c)) : 0u;
+        x[c] = clamp01(r.c[c]);
+      }
+    }
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      if (L1) gg[c] = sign_of(x[c] - gg[c]) * gs;
+      if (!live) gg[c] = 0.0f;
+    }
+    T2O_UNROLL
+    for (int kk = 0; kk < K; ++kk) {
+      const int k = K - 1 - kk;
+      const int op = SEQ::ops[k];
+      const float* t = tab + k * kTabStride;
+      Rgb xi, gi;
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        xi.c[c] = SV_LDS ? svl[(k * 3 + c) * kThreads + tid] : sv[k][c];
+        gi.c[c] = ((pass >> (3 * k + c)) & 1u) ? gg[c] : 0.0f;
+      }
+      Rgb gx;
+      if (op == OP_COLOR) gx = chain_curve_bwd<true>(xi, t, gi, red[k], it == 0);
+      else if (op == OP_TONE) gx = chain_curve_bwd<false>(xi, t, gi, red[k], it == 0);
+      else if (op == OP_WHITE) gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
+      else gx = chain_scalar_bwd(op, xi, t, gi, red[k]);
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) gg[c] = gx.c[c];
+    }
+    if (a.gimg && live) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) a.gimg[sb + c * hw + px] = gg[c];
+    }
+  }
+  T2O_UNROLL
+  for (int k = 0; k < K; ++k) {                      // one flush per thread
+    constexpr int kZero = 0;
+    (void)kZero;
+    const int op = SEQ::ops[k];
+    if (op == OP_COLOR) { float (&r)[24] = red[k]; acc.template add_n<24>(a.bin_off[k], r); }
+    else if (op == OP_TONE) { float (&r)[8] = reinterpret_cast<float (&)[8]>(red[k]); acc.template add_n<8>(a.bin_off[k], r); }
+    else if (op != OP_WHITE) { float (&r)[1] = reinterpret_cast<float (&)[1]>(red[k]); acc.template add_n<1>(a.bin_off[k], r); }
+  }
+}
+
 // ===================================================================== SSIM (evaluation metric)
 // utils/ssim/__init__.py:20-40: 11x11 Gaussian window (sigma 1.5, zero padding 5) over x, y,
 // x^2, y^2, xy per channel; C1 = 0.01^2, C2 = 0.03^2; mean of the SSIM map.  The 2-D window is the

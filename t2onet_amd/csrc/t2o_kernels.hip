@@ -414,6 +414,32 @@ __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
     a.partials[((size_t)b * a.nblk + blk) * S + s] = chain_slot_value(a, s, bsum);
 }
 
+// the backward for an operator list fixed at compile time (chain_bwd_thread_static): no save area in LDS, no
+// per-pixel flush.  One instantiation per entry of the dispatch in fused_chain_launch_bwd.
+template <bool L1, class SEQ, bool SV_LDS, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_chain_bwd_static(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // accumulator cells: NB rows of kAccStride [+ save area]
+  __shared__ float tab[kMaxChain * kTabStride];
+  __shared__ float bsum[kMaxChainBins];
+  int b, blk;
+  wg_coords(a.nblk, b, blk);
+  const int S = a.slot_off[kMaxChain], NB = a.bin_off[kMaxChain];
+  for (int i = threadIdx.x; i < NB * kAccStride; i += kThreads) lds[i] = 0.0f;
+  if ((int)threadIdx.x < SEQ::K) chain_build_table(a, b, threadIdx.x, tab);
+  __syncthreads();
+  LdsAcc acc{lds};
+  chain_bwd_thread_static<L1, SEQ, SV_LDS>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
+  __syncthreads();
+  for (int s = threadIdx.x; s < NB; s += kThreads) {
+    float sum = 0.0f;
+    for (int q = 0; q < kThreads / 4; ++q) sum += lds[s * kAccStride + q];
+    bsum[s] = sum;
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += kThreads)
+    a.partials[((size_t)b * a.nblk + blk) * S + s] = chain_slot_value(a, s, bsum);
+}
+
 // one workgroup per sample: per-block sums -> raw sums -> parameter gradients of every chain operator.
 // 8 threads per slot walk the block rows (stride 8), then a fixed-order LDS combine.
 __global__ __launch_bounds__(kThreads) void k_chain_finalize(ChainArgs a, float* gparams) {
@@ -1075,7 +1101,51 @@ static int fused_chain_launch_fwd(ChainArgs& a, int vec, bool l1, hipStream_t st
   else          { if (l1) k_chain_fwd<1, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<1, false><<<grid, kThreads, 0, st>>>(a); }
   return 0;
 }
+}  // extern "C" (templates need C++ linkage)
+
+// operator lists with a compile-time instantiation of the backward: the benchmark / planner sequences
+// (BASELINE.json configs[1] and configs[4] without their closing sharpness)
+using SeqCfg2 = StaticChain<OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION, OP_COLOR, OP_TONE>;
+using SeqCfg5 = StaticChain<OP_TONE, OP_COLOR, OP_TONE, OP_COLOR, OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION>;
+
+template <class SEQ>
+static bool chain_is(const ChainArgs& a) {
+  if (a.K != SEQ::K) return false;
+  for (int k = 0; k < SEQ::K; ++k)
+    if (a.ops[k] != SEQ::ops[k]) return false;
+  return true;
+}
+template <class SEQ, bool SV_LDS, int MINW>
+static void launch_static_bwd(ChainArgs& a, bool l1, hipStream_t st) {
+  const unsigned grid = (unsigned)a.B * a.nblk;
+  const size_t lds = sizeof(float) * ((size_t)a.bin_off[kMaxChain] * kAccStride + (SV_LDS ? chain_save_floats<1>(SEQ::K) : 0));
+  if (l1) k_chain_bwd_static<true, SEQ, SV_LDS, MINW><<<grid, kThreads, lds, st>>>(a);
+  else k_chain_bwd_static<false, SEQ, SV_LDS, MINW><<<grid, kThreads, lds, st>>>(a);
+}
+template <class SEQ>
+static void launch_static_bwd_variant(ChainArgs& a, int variant, bool l1, hipStream_t st) {
+  switch (variant) {
+    case 2: launch_static_bwd<SEQ, true, 1>(a, l1, st); break;       // operator inputs saved in LDS: no faster (106.9 vs 104.2 us)
+    default: launch_static_bwd<SEQ, false, 1>(a, l1, st); break;
+  }
+}
+
+extern "C" {
+
+static int chain_static_variant() {
+  static const int v = env_int("T2O_CHAIN_STATIC", 1);                   // 0: the run-time loop kernel for every list (A/B runs)
+  return v;
+}
+static bool chain_has_static_bwd(const ChainArgs& a, int vec) {
+  return vec == 1 && chain_static_variant() && (chain_is<SeqCfg2>(a) || chain_is<SeqCfg5>(a));
+}
+
 static int fused_chain_launch_bwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
+  const int use_static = chain_static_variant();
+  if (vec == 1 && use_static) {
+    if (chain_is<SeqCfg2>(a)) { launch_static_bwd_variant<SeqCfg2>(a, use_static, l1, st); return 0; }
+    if (chain_is<SeqCfg5>(a)) { launch_static_bwd_variant<SeqCfg5>(a, use_static, l1, st); return 0; }
+  }
   const unsigned grid = (unsigned)a.B * a.nblk;
   const size_t lds = sizeof(float) * ((size_t)a.bin_off[kMaxChain] * kAccStride +
                                       (vec == 2 ? chain_save_floats<2>(a.K) : chain_save_floats<1>(a.K)));
@@ -1163,6 +1233,13 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
       ChainArgs a;
       memset(&a, 0, sizeof(a));
       chain_fill(a, seg[s], B, H, W, iters, nblk);
+      if (!forced && chain_has_static_bwd(a, vec)) {
+        // the compile-time kernel flushes its parameter sums once per THREAD: twice the pixels per thread halves
+        // that again (bs=64 256x256: 104.9 us at 4, 100.6 us at 8 pixels per thread); fewer, longer workgroups
+        const int it2 = iters * 2 > 16 ? 16 : iters * 2;
+        const size_t groups = (size_t)H * W;
+        chain_fill(a, seg[s], B, H, W, it2, (int)((groups + (size_t)kThreads * it2 - 1) / ((size_t)kThreads * it2)));
+      }
       a.img = in; a.params = params; a.gimg = gnext; a.partials = (float*)workspace;
       if (last) { a.target = target; a.gloss = gloss; } else { a.gout = gcur; }
       fused_chain_launch_bwd(a, vec, last, st);

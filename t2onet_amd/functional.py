@@ -299,6 +299,64 @@ def batch_norm_relu(x, bn, residual=None):
     return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
 
 
+_conv_ws = {}
+
+
+def conv3x3_wgrad(x, dy):
+    """Weight gradient of a 3x3 stride-1 padding-1 convolution on the fp32 matrix cores (t2o_conv3x3_wgrad_nhwc).
+    x (N,Ci,H,W), dy (N,Co,H,W), both channels-last; returns dw (Co,Ci,3,3) channels-last."""
+    _need_gpu(x, dy)
+    N, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    x = x.contiguous(memory_format=torch.channels_last)
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co)
+    if need == 0:
+        raise RuntimeError('conv3x3_wgrad: unsupported shape (channels must be multiples of 64)')
+    key = (x.device.index, _stream(x.device))
+    ws = _conv_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _conv_ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    rc = lib.t2o_conv3x3_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(x.device))
+    _lib.check(rc, 't2o_conv3x3_wgrad_nhwc')
+    return dw
+
+
+def conv3x3_supported(x, weight, stride, padding):
+    """Layers the matrix-core weight gradient takes: channels-last fp32 activations on the GPU, 3x3 / stride 1 /
+    padding 1, channel counts multiples of 64 (every BasicBlock convolution of the encoder except the strided ones)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and weight.shape[0] % 64 == 0
+            and weight.shape[1] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """conv2d(x, w, 3x3, stride 1, padding 1): forward and data gradient stay library calls (MIOpen), the weight
+    gradient is the hand-written MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        dw = conv3x3_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def conv3x3(x, weight):
+    return _Conv3x3Fn.apply(x, weight)
+
+
 class _SequenceFn(torch.autograd.Function):
     """A known operator list with every intermediate materialised + L1 on the last output."""
 

@@ -154,6 +154,13 @@ def test_train_cli_runs_and_checkpoints(tmp_path):
     sd = torch.load(str(path))
     assert len(sd) == 199
     Actor(default_options()).load_state_dict(sd)
+    # evaluation ran at the checkpoint and the best model was kept (train_seq2seqL1.py:105-131)
+    st = avg['stats']
+    assert st['train_iter'] == [4] and len(st['val_dist']) == 1 and st['best_iter'] == 4 and 0 < st['best_val_dist'] < 1
+    assert (tmp_path / 'seq2seqL1_model' / 'checkpoint_best' / 'model.pth').exists()
+    # real data without the GloVe table is refused (the word rows would stay frozen at random values)
+    with pytest.raises(SystemExit):
+        train_cli.main(['--batch_size', '4', '--num_iters', '1', '--run_dir', str(tmp_path)])
 
 
 def test_episode_with_local_edit_masks():

@@ -1,0 +1,35 @@
+"""Own MFMA weight gradient vs MIOpen's for the encoder's 3x3 stride-1 layers (bs=64, 256x256 input)."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import t2onet_amd.functional as T  # noqa: E402
+
+dev = torch.device('cuda')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for name, c, h in (('l1.s1', 64, 64), ('l2.s1', 128, 32), ('l3.s1', 256, 16), ('l4.s1', 512, 8)):
+    x = torch.randn(B, c, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(c, c, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, c, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    gf = 2.0 * B * h * h * c * c * 9 / 1e9
+    t_lib = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+    t_own = timeit(lambda: T.conv3x3_wgrad(x, gy))
+    ref = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    err = ((T.conv3x3_wgrad(x, gy) - ref).abs().max() / ref.abs().max()).item()
+    print('%-6s %6.2f GFLOP  MIOpen %.3f ms (%6.1f TF/s)   own %.3f ms (%6.1f TF/s)   x%.2f   rel err vs MIOpen %.1e' % (
+        name, gf, t_lib, gf / t_lib, t_own, gf / t_own, t_lib / t_own, err), flush=True)

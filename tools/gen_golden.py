@@ -316,7 +316,8 @@ def gen_data():
 GRAD_PICKS = [  # (parameter name, slice) -- small tensors whole, big ones a corner: element-wise gradient parity
     ('decoder.out_linear.weight', None), ('decoder.out_linear.bias', None),
     ('executor.contrast_op.fc2.weight', None), ('executor.color_op.fc2.weight', None), ('executor.tone_op.fc1.bias', None),
-    ('vis_encoder.conv1.weight', None), ('vis_encoder.layer4.1.bn2.weight', None), ('vis_encoder.fc.bias', None),
+    ('vis_encoder.conv1.weight', None), ('vis_encoder.layer4.1.bn2.weight', None),
+    ('vis_encoder.fc.weight', (slice(0, 16), slice(0, 64))),     # (fc.bias feeds a train-mode batch norm: its gradient is exactly zero)
     ('vis_encoder.layer2.0.conv1.weight', (slice(0, 8), slice(0, 8))),
     ('lang_encoder.rnn.weight_hh_l0', (slice(0, 32), slice(0, 64))), ('lang_encoder.rnn.bias_ih_l1_reverse', None),
     ('decoder.rnn.weight_ih_l1', (slice(0, 32), slice(0, 64))), ('decoder.vis_linear.bias', None),
