@@ -14,6 +14,17 @@ from . import functional as T
 
 
 _FUSED = os.environ.get('T2O_FUSED_BN', '1') != '0'      # 0: PyTorch's batch norm everywhere (A/B timing)
+# 1: the hand-written MFMA weight gradient (t2o_conv3x3_wgrad_nhwc) for the 3x3 stride-1 convolutions in channels-last
+# mode.  Deterministic (fixed-order split-K; the library's kernel adds atomically) but 5-15 % slower than the library's
+# on MI355X -- both sit at ~70 % matrix-pipe occupancy (profiles/r02_wgrad_*.txt) -- so it is opt-in.
+_OWN_WGRAD = os.environ.get('T2O_OWN_WGRAD', '0') != '0'
+
+
+def _conv(conv, x):
+    if _OWN_WGRAD and conv.bias is None and T.conv3x3_supported(x, conv.weight, conv.stride, conv.padding) \
+            and conv.weight.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled():
+        return T.conv3x3(x, conv.weight)
+    return conv(x)
 
 
 def _bn_relu(bn, x, residual=None):
@@ -38,8 +49,8 @@ class BasicBlock(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
     def forward(self, x):
-        out = _bn_relu(self.bn1, self.conv1(x))
-        return _bn_relu(self.bn2, self.conv2(out), self.shortcut(x))
+        out = _bn_relu(self.bn1, _conv(self.conv1, x))
+        return _bn_relu(self.bn2, _conv(self.conv2, out), self.shortcut(x))
 
 
 class ResNet(nn.Module):

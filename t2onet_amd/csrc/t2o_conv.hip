@@ -21,6 +21,8 @@
 //   block indices congruent mod 8, i.e. land on the same XCD and share its L2.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "t2onet_hip.h"
 
 namespace t2o { int set_error(int code, const char* msg); }
@@ -31,7 +33,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kConvThreads = 256;
-constexpr int kStagePix = 32;                 // K per stage
 
 struct WgradArgs {
   const float* x;      // (N,H,W,Ci)
@@ -40,12 +41,13 @@ struct WgradArgs {
   int N, H, W, Ci, Co;
   int tiles_m, tiles_n;       // channel tiles
   int splits, stages_per_split, total_stages;
+  unsigned long long* stamps;   // diagnostic builds only (tools/diag/wgrad_clock.hip): per-workgroup clock stamps; null in the product
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(WgradArgs a) {
+template <int TM, int TN, int kStagePix, int kMinWaves>
+__global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(WgradArgs a) {
   constexpr int BM = TM / 64, BN = TN / 64;          // MFMA blocks per wave along m / n (wave tile = TM/2 x TN/2)
   constexpr int RA = TM / 4, RB = TN / 4;            // float4 per tile row
   constexpr int PA = kStagePix * RA / kConvThreads;  // float4 loads per thread per stage (dy / x)
@@ -53,17 +55,21 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(WgradArgs a) 
   __shared__ __attribute__((aligned(16))) float As[2][kStagePix][TM];
   __shared__ __attribute__((aligned(16))) float Bs[2][kStagePix][TN];
 
-  // block index -> (split, tap, channel tile); blocks of one split are congruent mod 8 (same XCD)
-  const int group = 9 * a.tiles_m * a.tiles_n;
+  // block index -> (split, channel tile, tap).  The 9 taps of one (split, tile) re-read the same dy / x tile rows:
+  // they get block indices congruent mod 8 (same XCD, shared L2) and adjacent in dispatch order; consecutive
+  // (split, tile) units go to consecutive XCDs, so every XCD gets the same number of workgroups.
+  const int units = a.splits * a.tiles_m * a.tiles_n;
   const int b = blockIdx.x;
-  const int chunk = b / (8 * group), within = b % (8 * group);
-  const int split = chunk * 8 + within % 8;
-  const int j = within / 8;
-  if (split >= a.splits) return;
-  const int tap = j % 9, tile = j / 9;
+  const int unit = (b / 72) * 8 + b % 8;
+  const int tap = (b % 72) / 8;
+  if (unit >= units) return;
+  const int tiles = a.tiles_m * a.tiles_n;
+  const int split = unit / tiles, tile = unit % tiles;
   const int m0 = (tile / a.tiles_n) * TM, n0 = (tile % a.tiles_n) * TN;
   const int dh = tap / 3 - 1, dw = tap % 3 - 1;
 
+  unsigned long long t0 = 0, r0 = 0;
+  if (a.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   const int P = a.N * a.H * a.W;
   const int s0 = split * a.stages_per_split;
   int s1 = s0 + a.stages_per_split;
@@ -82,6 +88,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(WgradArgs a) 
       for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
 
   float4 ra[PA], rb[PB];
+  // per load slot: the pixel's (h, w), advanced by one stage (32 pixels) at a time -- no division in the loop
+  int ph[PB], pw[PB];
+  {
+    const int pbase = s0 * kStagePix;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int p = pbase + (tid + i * kConvThreads) / RB;
+      pw[i] = p % a.W;
+      ph[i] = (p / a.W) % a.H;
+    }
+  }
+  const int adv_w = kStagePix % a.W, adv_h = kStagePix / a.W;
   auto load_stage = [&](int st) {
     const int pbase = st * kStagePix;
 #pragma unroll
@@ -96,9 +114,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(WgradArgs a) 
       const int idx = tid + i * kConvThreads;
       const int row = idx / RB, c4 = idx % RB;
       const int p = pbase + row;
-      const int w = p % a.W, h = (p / a.W) % a.H;
-      const bool ok = p < P && (unsigned)(h + dh) < (unsigned)a.H && (unsigned)(w + dw) < (unsigned)a.W;
+      const bool ok = p < P && (unsigned)(ph[i] + dh) < (unsigned)a.H && (unsigned)(pw[i] + dw) < (unsigned)a.W;
       rb[i] = ok ? ldg4(a.x + (size_t)(p + dh * a.W + dw) * a.Ci + n0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pw[i] += adv_w;                                   // -> the same slot's pixel of the next stage
+      const int carry = pw[i] >= a.W ? 1 : 0;
+      pw[i] -= carry * a.W;
+      ph[i] += adv_h + carry;
+      while (ph[i] >= a.H) ph[i] -= a.H;
     }
   };
   auto store_stage = [&](int buf) {
@@ -114,31 +136,66 @@ __global__ __launch_bounds__(kConvThreads, 2) void k_conv3x3_wgrad(WgradArgs a) 
     }
   };
 
+  // One continuous MFMA stream across stages.  Per stage (kStagePix / 2 k-pairs, 4 MFMAs of 64 cycles each per pair):
+  //   k-pair 0        the next stage's global loads are issued (they land in registers under ~2000 cycles of MFMAs)
+  //   k-pairs kS..    one 16-byte LDS store of the next stage per k-pair, into the OTHER buffer
+  //   k-pair  last-1  barrier: every wave's stores are done -- it does not have to wait for anybody's reads of the
+  //                   current buffer, and the matrix pipe still holds 256 cycles of this wave's MFMAs to cover the skew
+  //   k-pair  last    its fragment prefetch already reads k-pair 0 of the NEXT stage, so the first MFMAs after the
+  //                   stage boundary find their operands in registers: no bubble at the boundary
+  constexpr int KP = kStagePix / 2;                       // k-pairs per stage
+  constexpr int NST = PA + PB;                            // LDS stores per thread per stage
+  constexpr int kS = KP - 2 - NST >= 1 ? KP - 2 - NST : 1;  // first k-pair that carries a store
+  static_assert(kS + NST <= KP - 1, "stage too short for its stores");
+  auto store_one = [&](int buf, int i) {
+    if (i < PA) {
+      const int idx = tid + i * kConvThreads;
+      *reinterpret_cast<float4*>(&As[buf][idx / RA][(idx % RA) * 4]) = ra[i < PA ? i : 0];
+    } else {
+      const int idx = tid + (i - PA) * kConvThreads;
+      *reinterpret_cast<float4*>(&Bs[buf][idx / RB][(idx % RB) * 4]) = rb[i >= PA ? i - PA : 0];
+    }
+  };
+  float fa[2][BM], fb[2][BN];
+  auto read_frags = [&](int buf, int kk, int slot) {
+    const int k = kk * 2 + lk;
+#pragma unroll
+    for (int i = 0; i < BM; ++i) fa[slot][i] = As[buf][k][wm * (TM / 2) + i * 32 + lr];
+#pragma unroll
+    for (int jn = 0; jn < BN; ++jn) fb[slot][jn] = Bs[buf][k][wn * (TN / 2) + jn * 32 + lr];
+  };
+
   if (s0 < s1) {
     load_stage(s0);
     store_stage(0);
   }
   __syncthreads();
+  if (s0 < s1) read_frags(0, 0, 0);
   for (int st = s0; st < s1; ++st) {
     const int buf = (st - s0) & 1;
-    if (st + 1 < s1) load_stage(st + 1);              // global loads in flight under this stage's MFMAs
+    const bool has_next = st + 1 < s1;
+    if (has_next) load_stage(st + 1);
 #pragma unroll
-    for (int kk = 0; kk < kStagePix / 2; ++kk) {
-      const int k = kk * 2 + lk;
-      float fa[BM], fb[BN];
-#pragma unroll
-      for (int i = 0; i < BM; ++i) fa[i] = As[buf][k][wm * (TM / 2) + i * 32 + lr];
-#pragma unroll
-      for (int jn = 0; jn < BN; ++jn) fb[jn] = Bs[buf][k][wn * (TN / 2) + jn * 32 + lr];
+    for (int kk = 0; kk < KP; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < KP) read_frags(buf, kk + 1, nxt);
+      else if (has_next) read_frags(buf ^ 1, 0, nxt);     // (after the barrier of k-pair KP-2)
+      if (has_next && kk >= kS && kk < kS + NST) store_one(buf ^ 1, kk - kS);
+      __builtin_amdgcn_sched_barrier(0);                  // keep reads / stores above the MFMAs (the scheduler sinks them)
 #pragma unroll
       for (int i = 0; i < BM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < BN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+        for (int jn = 0; jn < BN; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][jn], acc[i][jn], 0, 0, 0);
+      if (kk == KP - 2) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (st + 1 < s1) store_stage(buf ^ 1);
-    __syncthreads();
   }
 
+  if (a.stamps && threadIdx.x == 0) {
+    a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+    a.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
   // C/D layout: column (n) = lane % 32, row (m) = (reg % 4) + 8 * (reg / 4) + 4 * (lane / 32)
   float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
 #pragma unroll
@@ -165,7 +222,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv_wgrad_reduce(const float*
   *reinterpret_cast<float4*>(dw + 4 * i) = s;
 }
 
-struct WgradPlan { int tm, tn, tiles_m, tiles_n, splits, stages_per_split, total_stages; };
+struct WgradPlan { int tm, tn, tiles_m, tiles_n, splits, stages_per_split, total_stages, stage_pix; };
+
+int conv_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 
 bool wgrad_supported(int N, int H, int W, int Ci, int Co) {
   return N > 0 && H > 0 && W > 0 && Ci >= 64 && Co >= 64 && Ci % 64 == 0 && Co % 64 == 0 &&
@@ -179,10 +241,16 @@ WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co) {
   p.tiles_m = Co / p.tm;
   p.tiles_n = Ci / p.tn;
   const int P = N * H * W;
-  p.total_stages = (P + kStagePix - 1) / kStagePix;
+  static const int stage_pix = conv_env("T2O_WGRAD_STAGE", 32);          // 16: three workgroups per CU (A/B runs)
+  p.stage_pix = stage_pix == 16 ? 16 : 32;
+  p.total_stages = (P + p.stage_pix - 1) / p.stage_pix;
   const int group = 9 * p.tiles_m * p.tiles_n;
-  // ~4 workgroups per CU in total (2 resident per CU, two rounds), at least 8 stages of K per workgroup
-  int splits = (1024 + group - 1) / group;
+  // ONE round of workgroups: 2 are resident per CU (LDS), 64 slots per XCD; a second, partly filled round would
+  // cost a whole round's time.  (split, tile) units are dealt to the 8 XCDs in turn, 9 workgroups (taps) each:
+  // 7 units per XCD = 63 slots.  At least 8 stages of K per workgroup.
+  static const int units = conv_env("T2O_WGRAD_UNITS", 0);
+  int splits = (units > 0 ? units : p.stage_pix == 16 ? 80 : 56) / (p.tiles_m * p.tiles_n);
+  (void)group;
   if (splits > p.total_stages / 8) splits = p.total_stages / 8;
   if (splits < 1) splits = 1;
   p.stages_per_split = (p.total_stages + splits - 1) / splits;
@@ -213,13 +281,20 @@ int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* wor
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n;
   a.splits = p.splits; a.stages_per_split = p.stages_per_split; a.total_stages = p.total_stages;
-  const int group = 9 * p.tiles_m * p.tiles_n;
-  const unsigned grid = (unsigned)(((p.splits + 7) / 8) * 8 * group);
+  a.stamps = nullptr;
+  const int units = p.splits * p.tiles_m * p.tiles_n;
+  const unsigned grid = (unsigned)(((units + 7) / 8) * 72);
   hipStream_t st = (hipStream_t)stream;
-  if (p.tm == 128 && p.tn == 128) k_conv3x3_wgrad<128, 128><<<grid, kConvThreads, 0, st>>>(a);
-  else if (p.tm == 128) k_conv3x3_wgrad<128, 64><<<grid, kConvThreads, 0, st>>>(a);
-  else if (p.tn == 128) k_conv3x3_wgrad<64, 128><<<grid, kConvThreads, 0, st>>>(a);
-  else k_conv3x3_wgrad<64, 64><<<grid, kConvThreads, 0, st>>>(a);
+#define T2O_WGRAD_LAUNCH(TM_, TN_)                                                                     \
+  do {                                                                                                 \
+    if (p.stage_pix == 16) k_conv3x3_wgrad<TM_, TN_, 16, 3><<<grid, kConvThreads, 0, st>>>(a);           \
+    else k_conv3x3_wgrad<TM_, TN_, 32, 2><<<grid, kConvThreads, 0, st>>>(a);                              \
+  } while (0)
+  if (p.tm == 128 && p.tn == 128) T2O_WGRAD_LAUNCH(128, 128);
+  else if (p.tm == 128) T2O_WGRAD_LAUNCH(128, 64);
+  else if (p.tn == 128) T2O_WGRAD_LAUNCH(64, 128);
+  else T2O_WGRAD_LAUNCH(64, 64);
+#undef T2O_WGRAD_LAUNCH
   const size_t n = (size_t)Co * 9 * Ci, n4 = n / 4;
   k_conv_wgrad_reduce<<<(unsigned)((n4 + kConvThreads - 1) / kConvThreads), kConvThreads, 0, st>>>(
       (const float*)workspace, dw, n4, p.splits, n);

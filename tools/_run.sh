@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r02u; export TMPDIR=/tmp; O=gpurun_out/r02u
-timeout 900 python -m pytest tests/test_gpu_operators.py tests/test_gpu_actor.py -q --tb=short -x > $O/pytest.log 2>&1; echo pytest rc=$?; tail -4 $O/pytest.log | cut -c1-250
-python bench.py --no-train --no-cpu-baseline --exec-steps 100 --exec-warmup 10 > $O/bench.json 2>$O/err.txt; python tools/bench_summary.py $O/bench.json | grep -i "_chain\|fused"
+mkdir -p gpurun_out/r03b; export TMPDIR=/tmp
+hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -Iinclude -o /tmp/wgrad_clock tools/diag/wgrad_clock.hip 2>/dev/null
+for a in "128 32" "64 64" "256 16" "512 8"; do timeout 120 /tmp/wgrad_clock $a; done > gpurun_out/r03b/wgrad_clock.txt 2>&1; cat gpurun_out/r03b/wgrad_clock.txt
