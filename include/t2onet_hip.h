@@ -173,16 +173,17 @@ int t2o_bn_relu_bwd(const float* x, const float* y, const float* dy, const float
 /* The same pair on channels-last activations: x, res, out, y, dy, dx, dres are (M, C) with M = N*H*W rows of C
  * contiguous channels (torch.channels_last storage of an (N,C,H,W) tensor), the layout the convolutions run in
  * natively on MI355X.  C must be a power of two in [4, 1024].  Same arithmetic, same running-statistics update.
+ * relu = 0: plain batch norm without the activation (the shortcut branch, models/actor_resnet.py:33-36).
  * workspace: t2o_bn_nhwc_workspace_bytes(M, C). */
 size_t t2o_bn_nhwc_workspace_bytes(int M, int C);
 int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, const float* bias,
                          float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* out,
-                         float momentum, float eps, void* workspace, size_t workspace_bytes,
+                         float momentum, float eps, int relu, void* workspace, size_t workspace_bytes,
                          int M, int C, void* stream);
 int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
                          const float* save_mean, const float* save_invstd, float* dx, float* dres,
-                         float* dweight, float* dbias, int has_res, void* workspace, size_t workspace_bytes,
-                         int M, int C, void* stream);
+                         float* dweight, float* dbias, int has_res, int relu, void* workspace,
+                         size_t workspace_bytes, int M, int C, void* stream);
 
 /* ---- 3x3 stride-1 padding-1 convolution of the image encoder, weight gradient (models/actor_resnet.py:27-44,
  * the BasicBlock convolutions) on the fp32 matrix cores (t2o_conv.hip).  Replaces the library's weight-gradient call

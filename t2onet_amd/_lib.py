@@ -49,8 +49,8 @@ SIGNATURES = {
     't2o_bn_relu_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _Z, _I, _I, _I, _P]),
     't2o_bn_relu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _P]),
     't2o_bn_nhwc_workspace_bytes': (_Z, [_I, _I]),
-    't2o_bn_relu_nhwc_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _Z, _I, _I, _P]),
-    't2o_bn_relu_nhwc_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _I, _I, _P]),
+    't2o_bn_relu_nhwc_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _Z, _I, _I, _P]),
+    't2o_bn_relu_nhwc_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _Z, _I, _I, _P]),
     't2o_conv3x3_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
 }
@@ -58,7 +58,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def load():

@@ -27,12 +27,20 @@ def _conv(conv, x):
     return conv(x)
 
 
-def _bn_relu(bn, x, residual=None):
-    """relu(bn(x) (+ residual)): fused kernels in training mode on the GPU."""
+def _bn_relu(bn, x, residual=None, counted=False):
+    """relu(bn(x) (+ residual)): fused kernels in training mode on the GPU.  counted: num_batches_tracked of the
+    fused layers was already advanced for this forward (ResNet.forward, one launch for all of them)."""
     if _FUSED and bn.training and x.is_cuda:
-        return T.batch_norm_relu(x, bn, residual)
+        return T.batch_norm_relu(x, bn, residual, count=not counted)
     out = bn(x)
     return F.relu(out if residual is None else out + residual)
+
+
+def _bn_plain(bn, x, counted=False):
+    """bn(x) of the shortcut branch: the fused kernels without the activation on channels-last activations."""
+    if _FUSED and bn.training and x.is_cuda and T._is_nhwc(x):
+        return T.batch_norm_relu(x, bn, None, relu=False, count=not counted)
+    return bn(x)
 
 
 class BasicBlock(nn.Module):
@@ -48,9 +56,10 @@ class BasicBlock(nn.Module):
         if stride != 1 or in_planes != planes:
             self.shortcut = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
-    def forward(self, x):
-        out = _bn_relu(self.bn1, _conv(self.conv1, x))
-        return _bn_relu(self.bn2, _conv(self.conv2, out), self.shortcut(x))
+    def forward(self, x, counted=False):
+        out = _bn_relu(self.bn1, _conv(self.conv1, x), None, counted)
+        sc = _bn_plain(self.shortcut[1], self.shortcut[0](x), counted) if len(self.shortcut) else x
+        return _bn_relu(self.bn2, _conv(self.conv2, out), sc, counted)
 
 
 class ResNet(nn.Module):
@@ -67,6 +76,12 @@ class ResNet(nn.Module):
         self.layer4 = self._make_layer(512, 2, 2)
         self.fc = nn.Linear(512, num_outputs)
 
+    def _batch_counters(self):
+        cached = self.__dict__.get('_nbt')
+        if cached is None or cached[0] is not self.bn1.num_batches_tracked:      # (.to() replaces the buffer tensors)
+            cached = self.__dict__['_nbt'] = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        return cached
+
     def _make_layer(self, planes, num_blocks, stride):
         blocks = []
         for s in [stride] + [1] * (num_blocks - 1):
@@ -79,7 +94,14 @@ class ResNet(nn.Module):
             # channels-last encoder (Actor.use_channels_last): one packed NHWC copy of the 3-channel image, then every
             # convolution and every fused batch-norm pass runs NHWC -- no layout transposes inside the encoder
             x = x.contiguous(memory_format=torch.channels_last)
-        x = _bn_relu(self.bn1, self.conv1(x))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        counted = False
+        if _FUSED and self.training and x.is_cuda and self.conv1.weight.is_contiguous(memory_format=torch.channels_last):
+            # num_batches_tracked of all 21 batch norms: one multi-tensor launch instead of 21 one-element kernels
+            torch._foreach_add_(self._batch_counters(), 1)
+            counted = True
+        x = _bn_relu(self.bn1, self.conv1(x), None, counted)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for block in layer:
+                x = block(x, counted)
         x = x.mean((2, 3))
         return self.fc(x.view(x.size(0), -1))

@@ -938,7 +938,7 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
 // ==================================================================== C ABI
 extern "C" {
 
-int t2o_abi_version(void) { return 2; }
+int t2o_abi_version(void) { return 3; }
 #ifndef T2O_SRC_DIGEST
 #define T2O_SRC_DIGEST "unstamped"
 #endif

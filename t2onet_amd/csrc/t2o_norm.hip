@@ -41,6 +41,7 @@ struct BnArgs {
   double* partials;      // (C, splits, 2)
   int N, C, HW, splits;
   float eps, momentum;
+  int relu;              // NHWC kernels: 0 = plain batch norm (the shortcut branch, no activation); the NCHW kernels always apply it
 };
 
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -170,6 +171,12 @@ template <bool HAS_RES>
 __device__ __forceinline__ float gated(float dy, float x, float y, float sc, float sh) {
   const bool pass = HAS_RES ? (y > 0.0f) : (x * sc + sh > 0.0f);
   return pass ? dy : 0.0f;
+}
+
+// the same with the activation optional (NHWC kernels; relu == 0: the gradient passes unchanged)
+template <bool HAS_RES>
+__device__ __forceinline__ float gated_opt(int relu, float dy, float x, float y, float sc, float sh) {
+  return relu ? gated<HAS_RES>(dy, x, y, sc, sh) : dy;
 }
 
 template <int V, bool HAS_RES>
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply(BnArgs a, size_t tot
       if (i >= total4) break;
       float4 o = make_float4(v[k].x * sc.x + sh.x, v[k].y * sc.y + sh.y, v[k].z * sc.z + sh.z, v[k].w * sc.w + sh.w);
       if (HAS_RES) { o.x += rs[k].x; o.y += rs[k].y; o.z += rs[k].z; o.w += rs[k].w; }
-      o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f);
+      if (a.relu) { o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f); }
       *reinterpret_cast<float4*>(a.out + 4 * i) = o;
     }
   }
@@ -417,8 +424,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_sums(BnArgs a, int M, 
     }
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-      const float g0 = gated<HAS_RES>(dq[k].x, xq[k].x, yq[k].x, sc.x, sh.x), g1 = gated<HAS_RES>(dq[k].y, xq[k].y, yq[k].y, sc.y, sh.y);
-      const float g2 = gated<HAS_RES>(dq[k].z, xq[k].z, yq[k].z, sc.z, sh.z), g3 = gated<HAS_RES>(dq[k].w, xq[k].w, yq[k].w, sc.w, sh.w);
+      const float g0 = gated_opt<HAS_RES>(a.relu, dq[k].x, xq[k].x, yq[k].x, sc.x, sh.x), g1 = gated_opt<HAS_RES>(a.relu, dq[k].y, xq[k].y, yq[k].y, sc.y, sh.y);
+      const float g2 = gated_opt<HAS_RES>(a.relu, dq[k].z, xq[k].z, yq[k].z, sc.z, sh.z), g3 = gated_opt<HAS_RES>(a.relu, dq[k].w, xq[k].w, yq[k].w, sc.w, sh.w);
       sg.x += g0; sg.y += g1; sg.z += g2; sg.w += g3;
       sgx.x += g0 * ((xq[k].x - mean.x) * invstd.x); sgx.y += g1 * ((xq[k].y - mean.y) * invstd.y);
       sgx.z += g2 * ((xq[k].z - mean.z) * invstd.z); sgx.w += g3 * ((xq[k].w - mean.w) * invstd.w);
@@ -450,8 +457,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply(BnArgs a, size_t
       const size_t i = i0 + (size_t)k * kThreads;
       if (i >= total4) break;
       float4 g;
-      g.x = gated<HAS_RES>(dq[k].x, xq[k].x, yq[k].x, ac.x, sh.x); g.y = gated<HAS_RES>(dq[k].y, xq[k].y, yq[k].y, ac.y, sh.y);
-      g.z = gated<HAS_RES>(dq[k].z, xq[k].z, yq[k].z, ac.z, sh.z); g.w = gated<HAS_RES>(dq[k].w, xq[k].w, yq[k].w, ac.w, sh.w);
+      g.x = gated_opt<HAS_RES>(a.relu, dq[k].x, xq[k].x, yq[k].x, ac.x, sh.x); g.y = gated_opt<HAS_RES>(a.relu, dq[k].y, xq[k].y, yq[k].y, ac.y, sh.y);
+      g.z = gated_opt<HAS_RES>(a.relu, dq[k].z, xq[k].z, yq[k].z, ac.z, sh.z); g.w = gated_opt<HAS_RES>(a.relu, dq[k].w, xq[k].w, yq[k].w, ac.w, sh.w);
       float4 o;
       o.x = ac.x * ((g.x - mg.x) - ((xq[k].x - mean.x) * invstd.x) * mgx.x);
       o.y = ac.y * ((g.y - mg.y) - ((xq[k].y - mean.y) * invstd.y) * mgx.y);
@@ -558,7 +565,7 @@ size_t t2o_bn_nhwc_workspace_bytes(int M, int C) {
 
 int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
                          float* running_var, float* save_mean, float* save_invstd, float* out, float momentum, float eps,
-                         void* workspace, size_t workspace_bytes, int M, int C, void* stream) {
+                         int relu, void* workspace, size_t workspace_bytes, int M, int C, void* stream) {
   if (!x || M <= 0 || !nhwc_channels_ok(C) || !weight || !bias || !save_mean || !save_invstd || !out)
     return set_error(T2O_EINVAL, "bn_relu_nhwc_fwd: null pointer or bad shape (C must be a power of two in [4, 1024])");
   if ((running_mean == nullptr) != (running_var == nullptr))
@@ -568,6 +575,7 @@ int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, 
   a.x = x; a.res = res; a.out = out; a.weight = weight; a.bias = bias;
   a.running_mean = running_mean; a.running_var = running_var; a.save_mean = save_mean; a.save_invstd = save_invstd;
   a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.eps = eps; a.momentum = momentum;     // finalize: m = N * HW = M
+  a.relu = relu;
   a.partials = (double*)workspace;
   a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
   float* partial = a.coef + 4 * (size_t)C;
@@ -584,16 +592,17 @@ int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, 
 
 int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
                          const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
-                         float* dbias, int has_res, void* workspace, size_t workspace_bytes, int M, int C, void* stream) {
+                         float* dbias, int has_res, int relu, void* workspace, size_t workspace_bytes, int M, int C,
+                         void* stream) {
   if (!x || M <= 0 || !nhwc_channels_ok(C) || !dy || !weight || !bias || !save_mean || !save_invstd || !dx)
     return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd: null pointer or bad shape (C must be a power of two in [4, 1024])");
-  if (has_res && !y) return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd: y is needed when a residual was added");
+  if (has_res && relu && !y) return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd: y is needed when a residual was added");
   if (!workspace || workspace_bytes < t2o_bn_nhwc_workspace_bytes(M, C)) return set_error(T2O_EWORKSPACE, "bn_relu_nhwc_bwd: workspace too small");
   BnArgs a = {};
   a.x = x; a.y = y; a.dy = dy; a.out = dx; a.dres = dres; a.weight = weight; a.bias = bias;
   a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
   a.dweight = dweight; a.dbias = dbias;
-  a.N = M; a.C = C; a.HW = 1; a.splits = 1;
+  a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.relu = relu;
   a.partials = (double*)workspace;
   a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
   float* partial = a.coef + 4 * (size_t)C;

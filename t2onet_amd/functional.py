@@ -226,9 +226,11 @@ class _BnReluFn(torch.autograd.Function):
     Channels-last activations stay channels-last (t2o_bn_relu_nhwc_*); anything else runs on NCHW planes."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, momentum, eps, relu=True):
         _need_gpu(x, res, weight, bias)
         nhwc = _is_nhwc(x)
+        if not relu and not nhwc:
+            raise RuntimeError('batch norm without the activation is only built for channels-last activations')
         fmt = torch.channels_last if nhwc else torch.contiguous_format
         x = x.contiguous(memory_format=fmt)
         res = None if res is None else res.contiguous(memory_format=fmt)
@@ -242,15 +244,16 @@ class _BnReluFn(torch.autograd.Function):
         if nhwc:
             rc = lib.t2o_bn_relu_nhwc_fwd(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                                           _ptr(save_mean), _ptr(save_invstd), _ptr(out), float(momentum), float(eps),
-                                          _ptr(ws), ws.numel(), N * HW, C, _stream(x.device))
+                                          1 if relu else 0, _ptr(ws), ws.numel(), N * HW, C, _stream(x.device))
         else:
             rc = lib.t2o_bn_relu_fwd(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                                      _ptr(save_mean), _ptr(save_invstd), _ptr(out), float(momentum), float(eps),
                                      _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
         _lib.check(rc, 't2o_bn_relu_fwd')
-        ctx.save_for_backward(x, out if res is not None else None, weight, bias, save_mean, save_invstd)
+        ctx.save_for_backward(x, out if (res is not None and relu) else None, weight, bias, save_mean, save_invstd)
         ctx.has_res = res is not None
         ctx.nhwc = nhwc
+        ctx.relu = bool(relu)
         return out
 
     @staticmethod
@@ -268,13 +271,14 @@ class _BnReluFn(torch.autograd.Function):
         if ctx.nhwc:
             rc = lib.t2o_bn_relu_nhwc_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean),
                                           _ptr(save_invstd), _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias),
-                                          1 if ctx.has_res else 0, _ptr(ws), ws.numel(), N * HW, C, _stream(x.device))
+                                          1 if ctx.has_res else 0, 1 if ctx.relu else 0, _ptr(ws), ws.numel(), N * HW, C,
+                                          _stream(x.device))
         else:
             rc = lib.t2o_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean), _ptr(save_invstd),
                                      _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), 1 if ctx.has_res else 0,
                                      _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
         _lib.check(rc, 't2o_bn_relu_bwd')
-        return dx, dres, dweight, dbias, None, None, None, None
+        return dx, dres, dweight, dbias, None, None, None, None, None
 
 
 _bn_ws = {}
@@ -289,14 +293,17 @@ def _bn_workspace(lib, N, C, device, nhwc=False, HW=1):
     return ws
 
 
-def batch_norm_relu(x, bn, residual=None):
+def batch_norm_relu(x, bn, residual=None, relu=True, count=True):
     """relu(bn(x) (+ residual)) for a torch.nn.BatchNorm2d `bn` in TRAINING mode on the GPU: batch
     statistics, running statistics and num_batches_tracked updated as nn.BatchNorm2d does
-    (models/actor_resnet.py:38-44, :99-100).  One statistics pass + one fused normalise/add/ReLU pass."""
+    (models/actor_resnet.py:38-44, :99-100).  One statistics pass + one fused normalise/add/ReLU pass.
+    relu=False: plain bn(x) (channels-last only: the shortcut branch).  count=False: the caller advances
+    num_batches_tracked itself (the encoder does it for all its layers with one launch)."""
     if bn.momentum is None or not bn.affine or not bn.track_running_stats:
         raise NotImplementedError('batch_norm_relu: affine BatchNorm2d with running statistics and a fixed momentum only')
-    bn.num_batches_tracked.add_(1)
-    return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+    if count:
+        bn.num_batches_tracked.add_(1)
+    return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu)
 
 
 _conv_ws = {}

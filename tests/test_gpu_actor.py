@@ -246,6 +246,45 @@ def test_fused_batchnorm_relu_matches_torch(shape, with_res, nhwc):
 
 
 @pytest.mark.gpu
+def test_channels_last_encoder_matches_torch_batchnorm():
+    """The whole image encoder in channels-last mode (fused batch norm with and without the activation -- the
+    shortcut branch --, one multi-tensor launch for the 21 num_batches_tracked counters) against the same module
+    with PyTorch's own batch norm: output, input gradient, running statistics, counters."""
+    import copy
+    import t2onet_amd.actor_resnet as R
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    net = R.ResNet().to(dev).train()
+    x = synth.images(4, 64, 64, 91).to(dev)
+    gy = synth.uniform((4, 512), 92, -1.0, 1.0).to(dev)
+    ref = copy.deepcopy(net)
+    fast = copy.deepcopy(net).to(memory_format=torch.channels_last)
+    saved = R._FUSED
+    try:
+        R._FUSED = False
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        yr.backward(gy)
+        R._FUSED = True
+        xf = x.clone().requires_grad_(True)
+        yf = fast(xf)
+        yf.backward(gy)
+    finally:
+        R._FUSED = saved
+    np.testing.assert_allclose(yf.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    g = xr.grad.cpu().numpy()
+    np.testing.assert_allclose(xf.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-3 * np.abs(g).max())
+    for (n, a), (_, b) in zip(fast.named_buffers(), ref.named_buffers()):
+        if n.endswith('num_batches_tracked'):
+            assert int(a) == int(b) == 1, n
+        else:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=n)
+    for (n, a), (_, b) in zip(fast.named_parameters(), ref.named_parameters()):
+        gb = b.grad.cpu().numpy()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gb, rtol=2e-3, atol=2e-3 * max(np.abs(gb).max(), 1e-8), err_msg=n)
+
+
+@pytest.mark.gpu
 def test_trainer_with_graphed_encoder_matches_eager():
     """Trainer(graph_encoder=True): the image encoder replayed from hipGraphs gives the same losses and the
     same flat gradient as eager execution, for the teacher-forced and the episode step, and capture leaves the

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r03b; export TMPDIR=/tmp
-hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -Iinclude -o /tmp/wgrad_clock tools/diag/wgrad_clock.hip 2>/dev/null
-for a in "128 32" "64 64" "256 16" "512 8"; do timeout 120 /tmp/wgrad_clock $a; done > gpurun_out/r03b/wgrad_clock.txt 2>&1; cat gpurun_out/r03b/wgrad_clock.txt
+mkdir -p gpurun_out/r03c; export TMPDIR=/tmp; O=gpurun_out/r03c
+timeout 1200 python -m pytest tests -m gpu -q --tb=short -x > $O/pytest.log 2>&1; echo pytest rc=$?; tail -12 $O/pytest.log | cut -c1-250
+bash tools/ab_train.sh "T2O_NHWC=1" "T2O_NHWC=1 T2O_OWN_WGRAD=1" > $O/ab.txt 2>&1; cat $O/ab.txt
