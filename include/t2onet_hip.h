@@ -133,6 +133,15 @@ int t2o_op_candidates_l1(int op, const float* img, const float* target, const fl
                          int param_stride, float* loss, void* workspace, size_t workspace_bytes,
                          int H, int W, void* stream);
 
+/* The same for up to 64 (image, operator) jobs in ONE launch -- a whole beam-search step of the planner
+ * (utils/beam_search.py:218-231: every beam image x every operation): job j evaluates its C candidate rows
+ * params[j] of operator ops[j] on image imgs[img_index[j]] against the common target.  ops / img_index are HOST
+ * arrays (copied into the kernel arguments); loss is (J, C). */
+size_t t2o_candidates_multi_workspace_bytes(int J, int C, int H, int W);
+int t2o_op_candidates_multi_l1(const int* ops, const int* img_index, int J, const float* imgs, int n_img,
+                               const float* target, const float* params, int C, int param_stride, float* loss,
+                               void* workspace, size_t workspace_bytes, int H, int W, void* stream);
+
 /* ---- SSIM (evaluation metric, forward only): utils/ssim/__init__.py:20-40 ----
  * 11x11 Gaussian window (sigma 1.5), zero padding, C1 = 1e-4, C2 = 9e-4.
  * out[b] = mean over (C,H,W) of the SSIM map of sample b (size_average=False of the reference;

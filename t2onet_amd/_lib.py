@@ -41,6 +41,8 @@ SIGNATURES = {
     't2o_fused_sequence_bwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     't2o_candidates_workspace_bytes': (_Z, [_I, _I, _I]),
     't2o_op_candidates_l1': (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P]),
+    't2o_candidates_multi_workspace_bytes': (_Z, [_I, _I, _I, _I]),
+    't2o_op_candidates_multi_l1': (_I, [c_i, c_i, _I, _P, _I, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P]),
     't2o_ssim_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     't2o_ssim_fwd': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     't2o_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -655,6 +655,48 @@ __global__ __launch_bounds__(kThreads) void k_candidates_l1(CandArgs a) {
   }
 }
 
+// many (image, operator) jobs in one launch (a whole beam-search step: every beam x every 1-parameter operator):
+// blockIdx.y = job; each job is the single-job kernel above on its own image / operator / candidate rows
+constexpr int kMaxCandJobs = 64;
+struct MultiCandArgs {
+  const float* imgs;      // (n_img, 3, H, W)
+  const float* target;    // (3, H, W)
+  const float* params;    // (J, C, param_stride)
+  float* partials;        // (J, C, nblk)
+  int op[kMaxCandJobs];
+  int img_index[kMaxCandJobs];
+  int C, param_stride, H, W, nblk;
+};
+
+__global__ __launch_bounds__(kThreads) void k_candidates_multi_l1(MultiCandArgs m) {
+  __shared__ float tab[kCandPerBlock * kTabStride];
+  __shared__ float wsum[kCandPerBlock][kThreads / 64];
+  const int job = blockIdx.y;
+  CandArgs a;
+  a.img = m.imgs + (size_t)m.img_index[job] * 3 * m.H * m.W;
+  a.target = m.target;
+  a.params = m.params + (size_t)job * m.C * m.param_stride;
+  a.partials = m.partials + (size_t)job * m.C * m.nblk;
+  a.op = m.op[job]; a.C = m.C; a.param_stride = m.param_stride; a.H = m.H; a.W = m.W; a.nblk = m.nblk;
+  const int blk = blockIdx.x % a.nblk, group = blockIdx.x / a.nblk;
+  const int c0 = group * kCandPerBlock;
+  if ((int)threadIdx.x < kCandPerBlock && c0 + (int)threadIdx.x < a.C)
+    cand_build_table(a, c0 + threadIdx.x, tab + threadIdx.x * kTabStride);
+  float x[3][kCandPix], tg[3][kCandPix];
+  const int npx = cand_load(a, blk, threadIdx.x, x, tg);
+  __syncthreads();
+  for (int j = 0; j < kCandPerBlock; ++j) {
+    if (c0 + j >= a.C) break;
+    const float s = wave_sum(cand_eval(a, tab + j * kTabStride, x, tg, npx));
+    if ((threadIdx.x & 63) == 0) wsum[j][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < kCandPerBlock && c0 + (int)threadIdx.x < a.C) {
+    const int j = threadIdx.x;
+    a.partials[(size_t)(c0 + j) * a.nblk + blk] = ((wsum[j][0] + wsum[j][1]) + wsum[j][2]) + wsum[j][3];
+  }
+}
+
 __global__ __launch_bounds__(64) void k_candidates_finalize(const float* partials, int nblk, float inv_n, float* loss) {
   float acc = 0.0f;
   for (int k = threadIdx.x; k < nblk; k += 64) acc += partials[(size_t)blockIdx.x * nblk + k];
@@ -1274,6 +1316,39 @@ int t2o_op_candidates_l1(int op, const float* img, const float* target, const fl
   k_candidates_l1<<<(unsigned)a.nblk * groups, kThreads, 0, st>>>(a);
   k_candidates_finalize<<<(unsigned)C, 64, 0, st>>>(a.partials, a.nblk, 1.0f / (3.0f * (float)H * (float)W), loss);
   return check_launch("candidate sweep");
+}
+
+size_t t2o_candidates_multi_workspace_bytes(int J, int C, int H, int W) {
+  if (J <= 0) return 0;
+  return (size_t)J * t2o_candidates_workspace_bytes(C, H, W);
+}
+
+int t2o_op_candidates_multi_l1(const int* ops, const int* img_index, int J, const float* imgs, int n_img, const float* target,
+                               const float* params, int C, int param_stride, float* loss, void* workspace,
+                               size_t workspace_bytes, int H, int W, void* stream) {
+  if (!ops || !img_index || !imgs || !target || !params || !loss) return fail(T2O_EINVAL, "candidates_multi_l1: null pointer");
+  if (J <= 0 || J > kMaxCandJobs) return fail(T2O_EINVAL, "candidates_multi_l1: 1 <= J <= 64 jobs per launch");
+  if (C <= 0 || H <= 0 || W <= 0 || n_img <= 0) return fail(T2O_EINVAL, "C, H, W, n_img must be positive");
+  if (!workspace || workspace_bytes < t2o_candidates_multi_workspace_bytes(J, C, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
+  MultiCandArgs m;
+  memset(&m, 0, sizeof(m));
+  for (int j = 0; j < J; ++j) {
+    const int op = ops[j];
+    if (op == OP_SHARPNESS || op == OP_IDENTITY || !op_supported(op))
+      return fail(T2O_EUNSUPPORTED, "candidate sweep supports the per-pixel operators (0,1,2,3,5,7)");
+    if (param_stride < op_num_params(op)) return fail(T2O_EINVAL, "param_stride < number of operator parameters");
+    if (img_index[j] < 0 || img_index[j] >= n_img) return fail(T2O_EINVAL, "img_index out of range");
+    m.op[j] = op;
+    m.img_index[j] = img_index[j];
+  }
+  m.imgs = imgs; m.target = target; m.params = params; m.partials = (float*)workspace;
+  m.C = C; m.param_stride = param_stride; m.H = H; m.W = W;
+  m.nblk = (int)(((size_t)H * W + (size_t)kThreads * kCandPix - 1) / ((size_t)kThreads * kCandPix));
+  const unsigned groups = (unsigned)((C + kCandPerBlock - 1) / kCandPerBlock);
+  hipStream_t st = (hipStream_t)stream;
+  k_candidates_multi_l1<<<dim3((unsigned)m.nblk * groups, (unsigned)J), kThreads, 0, st>>>(m);
+  k_candidates_finalize<<<(unsigned)(J * C), 64, 0, st>>>(m.partials, m.nblk, 1.0f / (3.0f * (float)H * (float)W), loss);
+  return check_launch("candidate sweep (multi)");
 }
 
 size_t t2o_ssim_workspace_bytes(int B, int C, int H, int W) {

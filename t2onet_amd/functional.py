@@ -462,6 +462,26 @@ def fused_sequence_l1(img, ops, params, target):
     return _FusedSequenceFn.apply(img, params, target, [int(o) for o in ops])
 
 
+def candidates_multi_l1(ops, img_index, imgs, target, params):
+    """loss[j, c] = mean |execute(imgs[img_index[j]], ops[j], params[j, c]) - target| for J jobs x C candidates in
+    ONE launch (t2o_op_candidates_multi_l1).  ops / img_index: python ints; imgs (n,3,H,W); params (J,C,n)."""
+    _need_gpu(imgs, target, params)
+    imgs = imgs.reshape(-1, 3, *imgs.shape[-2:]).contiguous()
+    target = target.reshape(3, *target.shape[-2:]).contiguous()
+    params = params.contiguous()
+    J, C = params.shape[0], params.shape[1]
+    H, W = imgs.shape[-2:]
+    lib = _lib.load()
+    loss = torch.empty(J, C, dtype=torch.float32, device=imgs.device)
+    ws = torch.empty(max(lib.t2o_candidates_multi_workspace_bytes(J, C, H, W), 4), dtype=torch.uint8, device=imgs.device)
+    c_ops = (ctypes.c_int * J)(*[int(o) for o in ops])
+    c_idx = (ctypes.c_int * J)(*[int(i) for i in img_index])
+    rc = lib.t2o_op_candidates_multi_l1(c_ops, c_idx, J, _ptr(imgs), imgs.shape[0], _ptr(target), _ptr(params), C,
+                                        params.shape[2], _ptr(loss), _ptr(ws), ws.numel(), H, W, _stream(imgs.device))
+    _lib.check(rc, 't2o_op_candidates_multi_l1')
+    return loss
+
+
 def ssim(img1, img2, size_average=True):
     """SSIM of utils/ssim/__init__.py (11x11 Gaussian, sigma 1.5), forward only (evaluation metric).
     Returns a scalar (size_average) or one value per sample."""

@@ -5,9 +5,11 @@ every objective evaluation is an `executor.execute(..., specified_param=...)` pl
 host sync (`get_param_naive`, beam_search.py:65-91).  Same surface here (`get_param`, `execute`,
 `get_dist`, `beam_search` with the reference's arguments), plus a GPU-native optimiser:
 
-  optimizer='sweep'   1-parameter per-pixel operators: three rounds of a 64-candidate sweep
-                      (t2o_op_candidates_l1: the image pair is read once per 8 candidates), each
-                      round shrinking the bracket around the best candidate -> 3 launches, 3 syncs;
+  optimizer='sweep'   1-parameter per-pixel operators: three rounds of a 64-candidate sweep, each round
+                      shrinking the bracket around the best candidate.  Inside beam_search every such fit of a
+                      step -- all beams x all 1-parameter operations -- runs in ONE launch per round
+                      (t2o_op_candidates_multi_l1) with the bracket update on the device: 3 launches and ONE
+                      host sync per beam step instead of one per candidate fit;
                       curve operators (8 / 24 parameters) and sharpness: Adam on the fused
                       operator+L1 forward/backward kernels with no per-iteration sync.
   'Nelder-Mead' | 'adam' | 'lbfgs'  the reference's procedures, objective evaluated by the HIP kernels.
@@ -56,6 +58,29 @@ def _fit_sweep_1d(I0, I1, operation, executor, rounds=3):
         step = (hi - lo) / (SWEEP_C - 1)
         lo, hi = max(float(lb), float(best) - step), min(float(ub), float(best) + step)
     return best.clone(), True
+
+
+def fit_sweep_batch(images, jobs, target, executor, rounds=3):
+    """1-parameter fits of many (image, operator) jobs at once.  images: list of (1,3,H,W); jobs: list of
+    (image index, operation).  Returns (params (J,1), dists (J,)) on the device -- no host synchronisation here."""
+    dev = target.device
+    imgs = torch.cat([im.reshape(1, 3, *im.shape[-2:]) for im in images], 0)
+    ops = [op for _, op in jobs]
+    idx = [i for i, _ in jobs]
+    bnd = [executor.get_param_bnd(op) for op in ops]
+    lb = torch.tensor([float(b[1]) for b in bnd], device=dev).view(-1, 1)
+    ub = torch.tensor([float(b[0]) for b in bnd], device=dev).view(-1, 1)
+    lo, hi = lb.clone(), ub.clone()
+    t = torch.linspace(0.0, 1.0, SWEEP_C, device=dev).view(1, -1)
+    best = best_loss = None
+    for _ in range(rounds):
+        cand = lo + (hi - lo) * t                                        # (J, C)
+        loss = T.candidates_multi_l1(ops, idx, imgs, target, cand.unsqueeze(-1))
+        best_loss, i = loss.min(dim=1, keepdim=True)
+        best = cand.gather(1, i)
+        step = (hi - lo) / (SWEEP_C - 1)
+        lo, hi = torch.maximum(lb, best - step), torch.minimum(ub, best + step)
+    return best, best_loss.view(-1)
 
 
 def _fit_adam(I0, I1, operation, executor, param0, steps=300, lr=2e-2, check_every=50, tol=1e-6):
@@ -121,20 +146,37 @@ def beam_search(I_0, I_gt, txt, executor, discriminator, beam_size, operations, 
     for _ in range(max_step):
         all_candidates, I_tmp_list, tmp_min_dists = [], [], []
         no_update, finished = True, False
-        for j, I in enumerate(I_buff):
+        # candidate (beam, operation) pairs of this step, in the reference's visiting order
+        pairs = []
+        for j in range(len(I_buff)):
             used = [operation_names.index(v[0]) for v in sequences[j][0]]
-            for operation in operations:
-                if not replace and operation in used:
-                    continue
+            pairs += [(j, operation) for operation in operations if replace or operation not in used]
+        fitted = {}
+        if optimizer == 'sweep':
+            batch = [pr for pr in pairs if pr[1] in PER_PIXEL_SWEEP_OPS]
+            for c0 in range(0, len(batch), 64):                              # (the kernel takes 64 jobs per launch)
+                chunk = batch[c0:c0 + 64]
+                params, dists = fit_sweep_batch(I_buff, chunk, I_gt, executor)
+                params, dists = params.cpu(), dists.cpu()                    # the one host sync of these fits
+                for k, pr in enumerate(chunk):
+                    fitted[pr] = (params[k:k + 1].to(I_gt.device), float(dists[k]))
+        for j, operation in pairs:
+            I = I_buff[j]
+            if (j, operation) in fitted:
+                param, dist = fitted[(j, operation)]
+                I_out = None                                                 # executed below only if it enters the beam
+            else:
                 param, _ = get_param(I, I_gt, txt, operation, executor, None, dist_type, optimizer)
                 I_out = execute(I, operation, param, executor)
                 dist = get_dist(I_out, I_gt, dist_type).item()
-                if dist < min_dist:
-                    tmp_min_dists.append(dist)
-                    all_candidates.append([sequences[j][0] + [(operation_names[operation], param[0].tolist(), dist, I_out)], dist])
-                    I_tmp_list.append(I_out)
-                    no_update = False
-                    finished = finished or dist < err
+            if dist < min_dist:
+                if I_out is None:
+                    I_out = execute(I, operation, param, executor)
+                tmp_min_dists.append(dist)
+                all_candidates.append([sequences[j][0] + [(operation_names[operation], param[0].tolist(), dist, I_out)], dist])
+                I_tmp_list.append(I_out)
+                no_update = False
+                finished = finished or dist < err
         min_dist = min(tmp_min_dists) if tmp_min_dists else min_dist
         if len(all_candidates) < beam_size:
             all_candidates += sequences

@@ -58,3 +58,31 @@ def test_curve_fit_and_beam_search(executor):
     best = actions[0]
     assert best[-1][2] < 5e-3                                            # final distance of the best sequence
     assert {a[0] for a in best} <= {'brightness', 'contrast', 'saturation'} and len(Is[0]) == len(best)
+
+
+def test_multi_job_sweep_equals_single_job_launches(executor):
+    """t2o_op_candidates_multi_l1: a whole beam step (several images x several operators) in one launch gives
+    exactly the per-job kernel's numbers; the batched three-round fit returns the single-job fit's parameters."""
+    import t2onet_amd.functional as T
+    from t2onet_amd import planner
+    H, W = 37, 53
+    imgs = [synth.images(1, H, W, 40 + k).cuda() for k in range(3)]
+    tgt = synth.images(1, H, W, 50).cuda()
+    jobs = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 2), (2, 1), (2, 5), (1, 3)]
+    C = 19
+    params = torch.stack([torch.cat([synth.op_params(op, C, 60 + k, 'mid'),
+                                     torch.zeros(C, 24 - cpu_ref.OP_NPARAM[op])], 1) for k, (_, op) in enumerate(jobs)]).cuda()
+    got = T.candidates_multi_l1([op for _, op in jobs], [i for i, _ in jobs], torch.cat(imgs), tgt, params)
+    for k, (i, op) in enumerate(jobs):
+        one = T.candidates_l1(op, imgs[i], tgt, params[k])
+        assert torch.equal(got[k], one), (k, i, op)
+    # batched fit == per-job fit (1-parameter operators)
+    jobs1 = [(0, 0), (1, 1), (2, 2), (1, 0)]
+    p, d = planner.fit_sweep_batch(imgs, jobs1, tgt, executor)
+    for k, (i, op) in enumerate(jobs1):
+        p1, _ = planner._fit_sweep_1d(imgs[i], tgt, op, executor)
+        assert abs(float(p[k]) - float(p1)) < 1e-6
+        out, _ = executor.execute(imgs[i], op, None, specified_param=p[k:k + 1])
+        assert abs(planner.get_dist(out, tgt).item() - float(d[k])) < 1e-6
+    with pytest.raises(RuntimeError):                                 # sharpness is a stencil: not a candidate-sweep operator
+        T.candidates_multi_l1([6], [0], torch.cat(imgs), tgt, params[:1])

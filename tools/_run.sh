@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r03c; export TMPDIR=/tmp; O=gpurun_out/r03c
-timeout 1200 python -m pytest tests -m gpu -q --tb=short -x > $O/pytest.log 2>&1; echo pytest rc=$?; tail -12 $O/pytest.log | cut -c1-250
-bash tools/ab_train.sh "T2O_NHWC=1" "T2O_NHWC=1 T2O_OWN_WGRAD=1" > $O/ab.txt 2>&1; cat $O/ab.txt
+mkdir -p gpurun_out/r03d; export TMPDIR=/tmp; O=gpurun_out/r03d
+timeout 900 python -m pytest tests/test_gpu_planner.py tests/test_gpu_actor_extra.py -q --tb=short > $O/pytest.log 2>&1; echo pytest rc=$?; tail -12 $O/pytest.log | cut -c1-250
+timeout 300 python tools/bench_planner.py > $O/planner.txt 2>&1; cat $O/planner.txt

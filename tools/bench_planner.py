@@ -32,6 +32,8 @@ mid, _ = ex.execute(img, 0, None, specified_param=torch.tensor([[0.25]]).cuda())
 tgt2, _ = ex.execute(mid, 1, None, specified_param=torch.tensor([[0.3]]).cuda())
 names = ['brightness', 'contrast', 'saturation', 'color', 'inpaint', 'tone', 'sharpness', 'white']
 for optm in ['Nelder-Mead', 'sweep']:
+    planner.beam_search(img, tgt2, None, ex, None, 3, [0, 1, 2], names, 3, 1e-3, 'L1', optm)      # warm up
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     actions, _ = planner.beam_search(img, tgt2, None, ex, None, 3, [0, 1, 2], names, 3, 1e-3, 'L1', optm)
     torch.cuda.synchronize()
