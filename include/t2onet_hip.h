@@ -206,6 +206,25 @@ size_t t2o_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream);
 
+/* ---- operator parameter heads for a batch whose samples use different operators: models/operators.py:73-88
+ * (param = op_param_regressor(fc2(LeakyReLU_0.01(fc1(features))))) as called per operator group by
+ * models/actor.py:244-255.  op_id (B) device int32: executor index of each sample, < 0 or 4 -> no head, zeros.
+ * w1/b1/w2/b2: HOST arrays of 8 device pointers indexed by executor index (entry 4 may be NULL): fc1 (512,512) /
+ * (512), fc2 (n,512) / (n), n = 1, 8 (tone) or 24 (color).  ctx (B,512) -> param (B,24) zero padded; hidden (B,512)
+ * and raw (B,24) are written for the backward.  Regressor constants: brightness_range, saturation_range (lo, hi),
+ * sharpness_range of the options.  D must be 512. */
+int t2o_param_heads_fwd(const int* op_id, const float* ctx, const float* const* w1, const float* const* b1,
+                        const float* const* w2, const float* const* b2, float* hidden, float* raw, float* param,
+                        float brightness_range, float sat_lo, float sat_hi, float sharpness_range, int B, int D,
+                        void* stream);
+/* gparam (B,24) -> gctx (B,512) and DENSE gradients of every head (gw1 .. gb2: HOST arrays of 8 device pointers;
+ * heads no sample selected receive zeros).  dpre (B,512): scratch.  Deterministic (batch-order sums). */
+int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* w1, const float* const* b1,
+                        const float* const* w2, const float* const* b2, const float* hidden, const float* raw,
+                        const float* gparam, float* gctx, float* dpre, float* const* gw1, float* const* gb1,
+                        float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
+                        float sharpness_range, int B, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

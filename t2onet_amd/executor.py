@@ -56,10 +56,19 @@ class Executor(nn.Module):
 
     # ------------------------------------------------------------------ batched extensions
     def predict_params(self, op_ids, features):
-        """(B,24) zero-padded parameters: row b from the head of operator op_ids[b].
-        Every per-pixel head runs on the whole batch (six 512x512 GEMMs: negligible) and rows are
-        picked with a gather, so there is no host sync and no regrouping of the batch; heads
-        that no sample selected get an all-zero gradient."""
+        """(B,24) zero-padded parameters: row b from the head of operator op_ids[b] (t2o_param_heads_fwd: one
+        workgroup per sample evaluates that sample's own head).  No host sync, no regrouping of the batch; heads
+        that no sample selected get an all-zero gradient.  Identity / inpaint rows are zeros."""
+        if features.is_cuda and features.shape[1] == 512 and self.opt.operator_fc_dim == 512:
+            heads = {k: (Op.fc1.weight, Op.fc1.bias, Op.fc2.weight, Op.fc2.bias) for k, Op in enumerate(self.ops) if k != 4}
+            lo, hi = self.opt.saturation_range
+            return T.param_heads(features, op_ids.to(torch.int32), heads,
+                                 (self.opt.brightness_range, lo, hi, self.opt.sharpness_range))
+        return self.predict_params_gemm(op_ids, features)
+
+    def predict_params_gemm(self, op_ids, features):
+        """The same through library GEMMs: every head on the whole batch, rows picked with a gather (other feature
+        widths; also the comparison the tests hold the fused kernels to)."""
         B = features.shape[0]
         table = features.new_zeros(len(self.ops) + 1, B, PARAM_PAD)        # last slot: identity / unsupported
         for k, Op in enumerate(self.ops):

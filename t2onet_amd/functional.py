@@ -306,6 +306,67 @@ def batch_norm_relu(x, bn, residual=None, relu=True, count=True):
     return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu)
 
 
+HEAD_OPS = (0, 1, 2, 3, 5, 6, 7)          # executor indices with a parameter head on this path (4 = inpaint: none)
+
+
+def _ptr_table(tensors_by_op):
+    """8 device pointers indexed by executor index (entry 4 null) as a ctypes array: the C ABI copies them into
+    the kernel arguments."""
+    arr = (ctypes.c_void_p * 8)()
+    for op, t in tensors_by_op.items():
+        arr[op] = t.data_ptr()
+    return arr
+
+
+class _ParamHeadsFn(torch.autograd.Function):
+    """param (B,24) = regressor_op(fc2_op(lrelu(fc1_op(features)))) with op = op_ids[b]: one launch forward, two
+    backward (t2o_param_heads_*), instead of every head on the whole batch + gather."""
+
+    @staticmethod
+    def forward(ctx, features, op_ids, consts, *flat):
+        _need_gpu(features, *flat)
+        features = features.contiguous()
+        B, D = features.shape
+        flat = [t.contiguous() for t in flat]
+        tabs = [{op: flat[4 * k + j] for k, op in enumerate(HEAD_OPS)} for j in range(4)]
+        hidden = torch.empty(B, D, dtype=torch.float32, device=features.device)
+        raw = torch.empty(B, PARAM_PAD, dtype=torch.float32, device=features.device)
+        param = torch.empty(B, PARAM_PAD, dtype=torch.float32, device=features.device)
+        rc = _lib.load().t2o_param_heads_fwd(_ptr(op_ids), _ptr(features), _ptr_table(tabs[0]), _ptr_table(tabs[1]),
+                                             _ptr_table(tabs[2]), _ptr_table(tabs[3]), _ptr(hidden), _ptr(raw), _ptr(param),
+                                             consts[0], consts[1], consts[2], consts[3], B, D, _stream(features.device))
+        _lib.check(rc, 't2o_param_heads_fwd')
+        ctx.save_for_backward(features, op_ids, hidden, raw, *flat)
+        ctx.consts = consts
+        return param
+
+    @staticmethod
+    def backward(ctx, gparam):
+        features, op_ids, hidden, raw = ctx.saved_tensors[:4]
+        flat = ctx.saved_tensors[4:]
+        B, D = features.shape
+        tabs = [{op: flat[4 * k + j] for k, op in enumerate(HEAD_OPS)} for j in range(4)]
+        grads = [torch.empty_like(t) for t in flat]
+        gtabs = [{op: grads[4 * k + j] for k, op in enumerate(HEAD_OPS)} for j in range(4)]
+        gctx = torch.empty_like(features)
+        dpre = torch.empty_like(features)
+        c = ctx.consts
+        rc = _lib.load().t2o_param_heads_bwd(_ptr(op_ids), _ptr(features), _ptr_table(tabs[0]), _ptr_table(tabs[1]),
+                                             _ptr_table(tabs[2]), _ptr_table(tabs[3]), _ptr(hidden), _ptr(raw),
+                                             _ptr(gparam.contiguous()), _ptr(gctx), _ptr(dpre), _ptr_table(gtabs[0]),
+                                             _ptr_table(gtabs[1]), _ptr_table(gtabs[2]), _ptr_table(gtabs[3]),
+                                             c[0], c[1], c[2], c[3], B, D, _stream(features.device))
+        _lib.check(rc, 't2o_param_heads_bwd')
+        return (gctx, None, None) + tuple(grads)
+
+
+def param_heads(features, op_ids, heads, consts):
+    """heads: {executor index: (fc1.weight, fc1.bias, fc2.weight, fc2.bias)} for HEAD_OPS; consts =
+    (brightness_range, saturation lo, saturation hi, sharpness_range); op_ids (B,) int32 on the GPU."""
+    flat = [t for op in HEAD_OPS for t in heads[op]]
+    return _ParamHeadsFn.apply(features, op_ids, tuple(float(v) for v in consts), *flat)
+
+
 _conv_ws = {}
 
 

@@ -249,8 +249,10 @@ def test_per_sample_learned_heads_match_grouped_execute(executor, dev):
     out, par = executor.execute_per_sample(img, ops, None, features=feats)
     for b in range(B):
         o, p = executor.execute(img[b:b + 1], int(ops[b]), None, features=feats[b:b + 1])
-        assert torch.allclose(out[b:b + 1], o, atol=1e-6)
-        assert torch.allclose(par[b:b + 1, :p.shape[1]], p, atol=1e-6)
+        # (the batched heads sum their 512-term dot products in another order than the library GEMM of the
+        # single-operator path: parameters agree to ~1e-6, images to that times the operator's gain)
+        assert torch.allclose(par[b:b + 1, :p.shape[1]], p, atol=5e-6)
+        assert torch.allclose(out[b:b + 1], o, atol=2e-5)
 
 
 def test_golden_cfg1_and_chain6(executor, gold, dev):
@@ -598,3 +600,34 @@ def test_forward_bit_identical_to_reference_arithmetic(executor, dev):
     ref = cpu_ref.operator_apply(1, img, p, None, OPT)
     out, _ = executor.execute(img.to(dev), 1, None, specified_param=p.to(dev))
     assert (out.cpu() - ref).abs().max().item() <= 2.4e-7
+
+
+def test_fused_param_heads_match_library_gemms(dev):
+    """t2o_param_heads_fwd/_bwd (each sample evaluates only its own operator's head) against the same heads through
+    library GEMMs + gather (Executor.predict_params_gemm): parameters, feature gradient and all 28 head gradients,
+    with identity / inpaint rows and heads that no sample selected."""
+    import copy
+    import t2onet_amd
+    torch.manual_seed(5)
+    ex_a = t2onet_amd.Executor(t2onet_amd.default_options()).to(dev)
+    ex_b = copy.deepcopy(ex_a)
+    B = 37
+    feats = synth.uniform((B, 512), 801, -1.0, 1.0).to(dev)
+    op_ids = torch.tensor([0, 1, 2, 3, 5, 6, -1, 4, 3, 5, 0, 2] * 4)[:B].to(dev).to(torch.int32)     # no sample uses op 7
+    gout = synth.uniform((B, 24), 802, -1.0, 1.0).to(dev)
+    fa, fb = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    pa = ex_a.predict_params(op_ids, fa)
+    pb = ex_b.predict_params_gemm(op_ids, fb)
+    np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    assert float(pa[6].detach().abs().max()) == 0.0 and float(pa[7].detach().abs().max()) == 0.0          # identity, inpaint
+    (pa * gout).sum().backward()
+    (pb * gout).sum().backward()
+    g = fb.grad.cpu().numpy()
+    np.testing.assert_allclose(fa.grad.cpu().numpy(), g, rtol=1e-4, atol=1e-5 * np.abs(g).max())
+    for (n, qa), (_, qb) in zip(ex_a.named_parameters(), ex_b.named_parameters()):
+        if 'inpaint' in n:
+            continue
+        ga = torch.zeros_like(qa) if qa.grad is None else qa.grad
+        gb = torch.zeros_like(qb) if qb.grad is None else qb.grad
+        np.testing.assert_allclose(ga.cpu().numpy(), gb.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(float(gb.abs().max()), 1e-6), err_msg=n)
+    assert float(ex_a.white_op.fc1.weight.grad.abs().max()) == 0.0                      # unused head: exact zeros

@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r03d; export TMPDIR=/tmp; O=gpurun_out/r03d
-timeout 900 python -m pytest tests/test_gpu_planner.py tests/test_gpu_actor_extra.py -q --tb=short > $O/pytest.log 2>&1; echo pytest rc=$?; tail -12 $O/pytest.log | cut -c1-250
-timeout 300 python tools/bench_planner.py > $O/planner.txt 2>&1; cat $O/planner.txt
+mkdir -p gpurun_out/r03e; export TMPDIR=/tmp; O=gpurun_out/r03e
+timeout 1200 python -m pytest tests -m gpu -q --tb=short > $O/pytest.log 2>&1; echo pytest rc=$?; grep -n "passed\|failed\|FAILED\|Mismatched\|Max abs\|err_msg" $O/pytest.log | head -20
