@@ -225,6 +225,12 @@ int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* 
                         float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
                         float sharpness_range, int B, int D, void* stream);
 
+/* ---- Adam over one flat fp32 buffer: experiments/t2onet/train_seq2seqL1.py:169 (torch.optim.Adam, default betas and
+ * eps, no weight decay) -- param, grad, exp_avg, exp_avg_sq: n floats each, 16-byte aligned; `step` = 1 for the first
+ * update (bias corrections are computed on the host in double).  In place; one streaming pass. */
+int t2o_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                  float beta2, float eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,9 +35,7 @@ class FlatGradients:
         for p in self.params:
             # same strides as the parameter (channels-last convolution weights stay channels-last): optimiser and
             # gradient accumulation then run their dense fast paths; the flat all-reduce does not care about layout
-            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
-            seg = self.flat[off:off + p.numel()]
-            p.grad = seg.as_strided(p.size(), p.stride()) if dense else seg.view_as(p)
+            p.grad = _view_like(self.flat[off:off + p.numel()], p)
             off += p.numel()
 
     def zero(self):
@@ -50,6 +48,60 @@ class FlatGradients:
             self.flat.div_(dist.get_world_size())
 
 
+def _view_like(seg, p):
+    """The flat segment with the parameter's own shape and strides (channels-last weights stay channels-last)."""
+    dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+    return seg.as_strided(p.size(), p.stride()) if dense else seg.view_as(p)
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8) -- what train_seq2seqL1.py:169 constructs -- over flat
+    buffers: the parameters are re-homed into one flat fp32 buffer (each keeps its shape and strides), the
+    gradients already live in FlatGradients' buffer, the two moments are flat too, and a step is ONE streaming
+    kernel (t2o_adam_step) instead of a multi-tensor pass over 199 tensors.  GPU only; hyper-parameters as
+    attributes (`lr` may be changed between steps)."""
+
+    def __init__(self, grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.grads = grads
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.step_count = 0
+        dev = grads.flat.device
+        self.flat_param = torch.empty_like(grads.flat)
+        off = 0
+        with torch.no_grad():
+            for p in grads.params:
+                seg = self.flat_param[off:off + p.numel()]
+                view = _view_like(seg, p)
+                view.copy_(p.data)
+                p.data = view                               # the module's parameter now IS a slice of the flat buffer
+                off += p.numel()
+        self.exp_avg = torch.zeros_like(grads.flat)
+        self.exp_avg_sq = torch.zeros_like(grads.flat)
+        self._ptr0 = grads.params[0].data_ptr()
+        assert dev.type == 'cuda'
+
+    def step(self):
+        from . import _lib, functional as T
+        if self.grads.params[0].data_ptr() != self._ptr0:
+            raise RuntimeError('FlatAdam: a parameter was re-allocated after the optimiser was built (module.to(...), '
+                               'use_channels_last() ...): build the Trainer afterwards')
+        self.step_count += 1
+        rc = _lib.load().t2o_adam_step(self.flat_param.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],
+                                       self.betas[1], self.eps, self.step_count, T._stream(self.flat_param.device))
+        _lib.check(rc, 't2o_adam_step')
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr,
+                'betas': self.betas, 'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.lr, self.betas, self.eps = float(sd['lr']), tuple(sd['betas']), float(sd['eps'])
+
+
 class Trainer:
     """Drives the reference's alternation: odd iterations supervised, even iterations episode/L1."""
 
@@ -58,7 +110,11 @@ class Trainer:
         batch and image size from then on; other shapes run eagerly) -- see Actor.graph_image_encoder."""
         self.model, self.opt = model, opt
         self.grads = FlatGradients(model.parameters())
-        self.optimizer = torch.optim.Adam(self.grads.params, lr=lr if lr is not None else opt.learning_rate)
+        lr = lr if lr is not None else opt.learning_rate
+        if self.grads.flat.is_cuda:
+            self.optimizer = FlatAdam(self.grads, lr=lr)
+        else:                                              # (host tensors: the multi-process CPU tests)
+            self.optimizer = torch.optim.Adam(self.grads.params, lr=lr)
         self.itr = 0
         self.graph_encoder = graph_encoder
 

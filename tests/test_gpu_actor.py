@@ -359,3 +359,35 @@ def test_trainer_with_graphed_encoder_matches_eager():
         # the episode samples operators: same seed, same draws (encoder graphs consume no random numbers)
         assert abs(e0 - e1) < 1e-5
         np.testing.assert_allclose(ge1.cpu().numpy(), ge0.cpu().numpy(), rtol=0, atol=1e-3 * float(ge0.abs().max()))
+
+
+@pytest.mark.gpu
+def test_flat_adam_matches_torch_adam():
+    """FlatAdam (one t2o_adam_step launch over the flat parameter / gradient / moment buffers) against
+    torch.optim.Adam with the reference's settings (train_seq2seqL1.py:169), several steps, a channels-last weight and
+    an odd total size (tail elements)."""
+    import copy
+    from t2onet_amd.train import FlatGradients, FlatAdam
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    net = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 3, 3, padding=1)).to(dev)
+    net[0].to(memory_format=torch.channels_last)
+    extra = torch.nn.Parameter(torch.randn(7, device=dev))              # 4*8*9 + 8 + 8*3*9 + 3 + 7 = 522 = 4 * 130 + 2
+    params = list(net.parameters()) + [extra]
+    ref_params = [p.detach().clone().requires_grad_(True) for p in params]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3)
+    grads = FlatGradients(params)
+    opt = FlatAdam(grads, lr=1e-3)
+    assert params[0].is_contiguous(memory_format=torch.channels_last) and params[0].data_ptr() == opt.flat_param.data_ptr()
+    for it in range(5):
+        g = [synth.uniform(tuple(p.shape), 900 + 10 * it + k, -1.0, 1.0).to(dev) * (10.0 ** (k - 2)) for k, p in enumerate(params)]
+        grads.zero()
+        for p, q, gi in zip(params, ref_params, g):
+            p.grad.copy_(gi)
+            q.grad = gi.clone()
+        opt.step()
+        ref_opt.step()
+        for p, q in zip(params, ref_params):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    x = torch.randn(2, 4, 5, 5, device=dev)
+    assert torch.isfinite(net(x)).all()                                  # the module still runs on its re-homed parameters
