@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "t2onet_hip.h"
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
 
-  float4 ra[PA], rb[PB];
+  float4 ra[2][PA], rb[2][PB];                     // two register sets: the global loads run TWO stages ahead
   // per load slot: the pixel's (h, w), advanced by one stage (32 pixels) at a time -- no division in the loop
   int ph[PB], pw[PB];
   {
@@ -100,14 +101,14 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
     }
   }
   const int adv_w = kStagePix % a.W, adv_h = kStagePix / a.W;
-  auto load_stage = [&](int st) {
+  auto load_stage = [&](int st, int set) {
     const int pbase = st * kStagePix;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int idx = tid + i * kConvThreads;
       const int row = idx / RA, c4 = idx % RA;
       const int p = pbase + row;
-      ra[i] = p < P ? ldg4(a.dy + (size_t)p * a.Co + m0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[set][i] = p < P ? ldg4(a.dy + (size_t)p * a.Co + m0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
       const int row = idx / RB, c4 = idx % RB;
       const int p = pbase + row;
       const bool ok = p < P && (unsigned)(ph[i] + dh) < (unsigned)a.H && (unsigned)(pw[i] + dw) < (unsigned)a.W;
-      rb[i] = ok ? ldg4(a.x + (size_t)(p + dh * a.W + dw) * a.Ci + n0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[set][i] = ok ? ldg4(a.x + (size_t)(p + dh * a.W + dw) * a.Ci + n0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       pw[i] += adv_w;                                   // -> the same slot's pixel of the next stage
       const int carry = pw[i] >= a.W ? 1 : 0;
       pw[i] -= carry * a.W;
@@ -123,39 +124,33 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
       while (ph[i] >= a.H) ph[i] -= a.H;
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, int set) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int idx = tid + i * kConvThreads;
-      *reinterpret_cast<float4*>(&As[buf][idx / RA][(idx % RA) * 4]) = ra[i];
+      *reinterpret_cast<float4*>(&As[buf][idx / RA][(idx % RA) * 4]) = ra[set][i];
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int idx = tid + i * kConvThreads;
-      *reinterpret_cast<float4*>(&Bs[buf][idx / RB][(idx % RB) * 4]) = rb[i];
+      *reinterpret_cast<float4*>(&Bs[buf][idx / RB][(idx % RB) * 4]) = rb[set][i];
     }
   };
 
-  // One continuous MFMA stream across stages.  Per stage (kStagePix / 2 k-pairs, 4 MFMAs of 64 cycles each per pair):
-  //   k-pair 0        the next stage's global loads are issued (they land in registers under ~2000 cycles of MFMAs)
-  //   k-pairs kS..    one 16-byte LDS store of the next stage per k-pair, into the OTHER buffer
+  // One continuous MFMA stream across stages, global loads two stages ahead.  Stage st (LDS buffer q = parity of
+  // st - s0, kStagePix / 2 k-pairs, 4 MFMAs of 64 cycles each per pair):
+  //   k-pair 0        the loads of stage st+2 are issued into register set q (its previous content, stage st, went to
+  //                   LDS during stage st-1): they have a whole stage (~10k cycles) to land, HBM latency never shows
+  //   k-pairs kS..    one 16-byte LDS store per k-pair of stage st+1 (register set q^1, loaded during stage st-1)
+  //                   into the OTHER buffer
   //   k-pair  last-1  barrier: every wave's stores are done -- it does not have to wait for anybody's reads of the
   //                   current buffer, and the matrix pipe still holds 256 cycles of this wave's MFMAs to cover the skew
-  //   k-pair  last    its fragment prefetch already reads k-pair 0 of the NEXT stage, so the first MFMAs after the
-  //                   stage boundary find their operands in registers: no bubble at the boundary
+  //   k-pair  last    its fragment prefetch already reads k-pair 0 of stage st+1, so the first MFMAs after the stage
+  //                   boundary find their operands in registers: no bubble at the boundary
   constexpr int KP = kStagePix / 2;                       // k-pairs per stage
   constexpr int NST = PA + PB;                            // LDS stores per thread per stage
-  constexpr int kS = KP - 2 - NST >= 1 ? KP - 2 - NST : 1;  // first k-pair that carries a store
+  constexpr int kS = 1;                                   // first k-pair that carries a store
   static_assert(kS + NST <= KP - 1, "stage too short for its stores");
-  auto store_one = [&](int buf, int i) {
-    if (i < PA) {
-      const int idx = tid + i * kConvThreads;
-      *reinterpret_cast<float4*>(&As[buf][idx / RA][(idx % RA) * 4]) = ra[i < PA ? i : 0];
-    } else {
-      const int idx = tid + (i - PA) * kConvThreads;
-      *reinterpret_cast<float4*>(&Bs[buf][idx / RB][(idx % RB) * 4]) = rb[i >= PA ? i - PA : 0];
-    }
-  };
   float fa[2][BM], fb[2][BN];
   auto read_frags = [&](int buf, int kk, int slot) {
     const int k = kk * 2 + lk;
@@ -164,23 +159,26 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
 #pragma unroll
     for (int jn = 0; jn < BN; ++jn) fb[slot][jn] = Bs[buf][k][wn * (TN / 2) + jn * 32 + lr];
   };
-
-  if (s0 < s1) {
-    load_stage(s0);
-    store_stage(0);
-  }
-  __syncthreads();
-  if (s0 < s1) read_frags(0, 0, 0);
-  for (int st = s0; st < s1; ++st) {
-    const int buf = (st - s0) & 1;
+  // one stage; Q (compile time) = LDS buffer and register-set parity of this stage
+  auto stage = [&](auto Qc, int st) {
+    constexpr int Q = decltype(Qc)::value;
     const bool has_next = st + 1 < s1;
-    if (has_next) load_stage(st + 1);
+    if (st + 2 < s1) load_stage(st + 2, Q);
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < KP) read_frags(buf, kk + 1, nxt);
-      else if (has_next) read_frags(buf ^ 1, 0, nxt);     // (after the barrier of k-pair KP-2)
-      if (has_next && kk >= kS && kk < kS + NST) store_one(buf ^ 1, kk - kS);
+      if (kk + 1 < KP) read_frags(Q, kk + 1, nxt);
+      else if (has_next) read_frags(Q ^ 1, 0, nxt);       // (after the barrier of k-pair KP-2)
+      if (has_next && kk >= kS && kk < kS + NST) {
+        const int i = kk - kS;
+        if (i < PA) {
+          const int idx = tid + i * kConvThreads;
+          *reinterpret_cast<float4*>(&As[Q ^ 1][idx / RA][(idx % RA) * 4]) = ra[Q ^ 1][i < PA ? i : 0];
+        } else {
+          const int idx = tid + (i - PA) * kConvThreads;
+          *reinterpret_cast<float4*>(&Bs[Q ^ 1][idx / RB][(idx % RB) * 4]) = rb[Q ^ 1][i >= PA ? i - PA : 0];
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);                  // keep reads / stores above the MFMAs (the scheduler sinks them)
 #pragma unroll
       for (int i = 0; i < BM; ++i)
@@ -190,6 +188,18 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
       if (kk == KP - 2) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+
+  if (s0 < s1) {
+    load_stage(s0, 0);
+    store_stage(0, 0);
+    if (s0 + 1 < s1) load_stage(s0 + 1, 1);
+  }
+  __syncthreads();
+  if (s0 < s1) read_frags(0, 0, 0);
+  for (int st = s0; st < s1; st += 2) {
+    stage(std::integral_constant<int, 0>{}, st);
+    if (st + 1 < s1) stage(std::integral_constant<int, 1>{}, st + 1);
   }
 
   if (a.stamps && threadIdx.x == 0) {
