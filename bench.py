@@ -78,17 +78,27 @@ def launch(args, argv):
                                       start_new_session=True))
     deadline = time.time() + args.launch_timeout
     line, rc = None, 0
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     try:
-        out0, _ = procs[0].communicate(timeout=args.launch_timeout)
-        for ln in out0.decode('utf-8', 'replace').splitlines():
-            if ln.startswith('{'):
-                line = ln
-        for p in procs:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-            rc = max(rc, abs(p.returncode))
-    except subprocess.TimeoutExpired:
-        rc = 124
-        sys.stderr.write('bench.py: ranks did not finish within %d s; stopping them\n' % args.launch_timeout)
+        # poll: a rank that dies takes the others into a collective that never completes -- stop them at once instead
+        # of waiting for the communicator's own timeout
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                rc = max(abs(c) for c in codes)
+                break
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = abs(bad[0][1])
+                sys.stderr.write('bench.py: rank %d exited with code %d; stopping the other ranks\n' % bad[0])
+                break
+            if time.time() > deadline:
+                rc = 124
+                sys.stderr.write('bench.py: ranks did not finish within %d s; stopping them\n' % args.launch_timeout)
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -96,6 +106,10 @@ def launch(args, argv):
                     os.killpg(p.pid, 15)             # the exact process groups started above
                 except OSError:
                     pass
+    reader.join(timeout=10)
+    for ln in (out0[0] if out0 else b'').decode('utf-8', 'replace').splitlines():
+        if ln.startswith('{'):
+            line = ln
     if line is not None:
         print(line, flush=True)
     elif rc == 0:
@@ -597,6 +611,8 @@ def selftest_worker(args):
         return 2
     if world > 1:
         dist.init_process_group('gloo', rank=rank, world_size=world)
+    if os.environ.get('T2O_SELFTEST_FAIL_RANK') == str(rank):          # (tests: a rank that dies after the rendezvous)
+        os._exit(7)
     buf = torch.ones(1 << 16) * (rank + 1)
 
     def step():

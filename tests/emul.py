@@ -58,7 +58,7 @@ def bwd(op, img, param, gout=None, mask=None, op_id=None, target=None, gloss=1.0
     return gimg, gparam
 
 
-def fused(ops, img, params, target, gloss=1.0, iters=0):
+def fused(ops, img, params, target, gloss=1.0, iters=0, use_static=0):
     """Fused sequence forward + backward.  params (K,B,24).  Returns out, loss, gimg, gparams."""
     img, params, target = _f(img), _f(params), _f(target)
     B, _, H, W = img.shape
@@ -75,7 +75,7 @@ def fused(ops, img, params, target, gloss=1.0, iters=0):
     gparams = np.zeros_like(params)
     gl = np.array([gloss], np.float32)
     assert lib().emul_fused_bwd(c_ops, K, _p(img), _p(params), _p(target), _p(gl), _p(gimg), _p(gparams), _p(seg),
-                                _p(gbuf), B, H, W, iters) == 0
+                                _p(gbuf), B, H, W, iters, use_static) == 0
     return out, float(loss[0]), gimg, gparams
 
 

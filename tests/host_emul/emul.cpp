@@ -57,6 +57,18 @@ struct HostAcc {
   void add_n(int slot0, float (&v)[N]) { for (int j = 0; j < N; ++j) sums[slot0 + j] += v[j]; }
 };
 
+// the operator lists with a compile-time backward (mirrors t2o_kernels.hip: SeqCfg2 / SeqCfg5)
+using EmuSeq2 = StaticChain<OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION, OP_COLOR, OP_TONE>;
+using EmuSeq5 = StaticChain<OP_TONE, OP_COLOR, OP_TONE, OP_COLOR, OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION>;
+template <class SEQ>
+static bool emu_chain_is(const ChainArgs& a) {
+  if (a.K != SEQ::K) return false;
+  for (int k = 0; k < SEQ::K; ++k)
+    if (a.ops[k] != SEQ::ops[k]) return false;
+  return true;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -168,14 +180,16 @@ int emul_fused_fwd(const int* ops, int K, const float* img, const float* params,
   return 0;
 }
 
+// use_static != 0: segments whose operator list has a compile-time instantiation run chain_bwd_thread_static (one
+// pixel per thread-iteration, parameter sums kept across the thread's pixels), as the device dispatch does
 int emul_fused_bwd(const int* ops, int K, const float* img, const float* params, const float* target,
                    const float* gloss, float* gimg, float* gparams, const float* seg_bufs, float* gbuf, int B, int H,
-                   int W, int forced_iters) {
+                   int W, int forced_iters, int use_static) {
   Segment seg[64];
   const int ns = plan_segments(ops, K, seg, 64);
   if (ns < 0) return 2;
   int vec, iters, nblk;
-  chain_geometry(B, H, W, forced_iters, vec, iters, nblk);
+  chain_geometry(B, H, W, forced_iters, vec, iters, nblk, use_static ? 1 : 0);
   const size_t img_floats = (size_t)B * 3 * H * W;
   memset(gparams, 0, sizeof(float) * (size_t)K * B * kMaxParam);
   const float* gcur = nullptr;
@@ -202,9 +216,12 @@ int emul_fused_bwd(const int* ops, int K, const float* img, const float* params,
         for (int i = 0; i < kMaxChainBins; ++i) bins[i] = 0.0f;
         HostAcc acc{bins};
         std::vector<float> sv(chain_save_floats<2>(kMaxChain));
+        const bool st2 = use_static && vec == 1 && emu_chain_is<EmuSeq2>(a), st5 = use_static && vec == 1 && emu_chain_is<EmuSeq5>(a);
         for (int blk = 0; blk < nblk; ++blk)
           for (int tid = 0; tid < kThreads; ++tid) {
-            if (vec == 2) { if (last) chain_bwd_thread<2, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            if (st2) { if (last) chain_bwd_thread_static<true, EmuSeq2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread_static<false, EmuSeq2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            else if (st5) { if (last) chain_bwd_thread_static<true, EmuSeq5, false>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread_static<false, EmuSeq5, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            else if (vec == 2) { if (last) chain_bwd_thread<2, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
             else { if (last) chain_bwd_thread<1, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<1, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
           }
         for (int sl = 0; sl < a.slot_off[kMaxChain]; ++sl) sums[sl] = chain_slot_value(a, sl, bins);

@@ -51,3 +51,12 @@ def test_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_a_dying_rank_stops_the_job_quickly():
+    """If one rank exits with an error the launcher must not wait for the others to time out in a collective."""
+    import time
+    t0 = time.time()
+    r = _run(['--gpus', '2', '--selftest', '--steps', '3', '--warmup', '1'], env={'T2O_SELFTEST_FAIL_RANK': '1'})
+    assert r.returncode != 0 and 'exited with code' in r.stderr
+    assert time.time() - t0 < 60

@@ -157,6 +157,27 @@ def test_fused_sequence_equals_oracle_chain(ops, shape):
             assert np.all(gparams[k] == 0)
 
 
+@pytest.mark.parametrize('ops', [[0, 1, 2, 3, 5, 6], [5, 3, 5, 3, 0, 1, 2, 6], [0, 1, 2, 3, 5], [5, 3, 5, 3, 0, 1, 2]])
+@pytest.mark.parametrize('iters', [0, 3])
+def test_static_chain_backward_equals_runtime_loop_program(ops, iters):
+    """chain_bwd_thread_static (operator list fixed at compile time: unrolled sweeps, parameter sums kept in
+    registers across the thread's pixels, one flush per thread) against the run-time-loop program on the same
+    inputs: identical image gradients (same per-pixel arithmetic), parameter gradients equal up to summation order.
+    Shapes with dead threads in the last workgroup and several pixels per thread."""
+    B, H, W = 2, 23, 19
+    img = synth.images(B, H, W, 61)
+    tgt = synth.images(B, H, W, 62)
+    params = torch.zeros(len(ops), B, 24)
+    for k, op in enumerate(ops):
+        n = cpu_ref.OP_NPARAM[op]
+        params[k, :, :n] = synth.op_params(op, B, 400 + k, 'mid')
+    o0, l0, g0, p0 = emul.fused(ops, img.numpy(), params.numpy(), tgt.numpy(), gloss=1.5, iters=iters, use_static=0)
+    o1, l1, g1, p1 = emul.fused(ops, img.numpy(), params.numpy(), tgt.numpy(), gloss=1.5, iters=iters, use_static=1)
+    assert np.array_equal(o0, o1) and l0 == l1
+    np.testing.assert_array_equal(g1, g0)
+    np.testing.assert_allclose(p1, p0, rtol=2e-5, atol=1e-6 * max(np.abs(p0).max(), 1e-6))
+
+
 def edge_image():
     """Exact ties the random suite never hits: black, white, greys, two equal maxima/minima,
     values on curve knots, flat saturated regions (sharpness output exactly 0 / 1)."""
