@@ -848,6 +848,49 @@ struct StaticChain {
 };
 T2O_HD constexpr int chain_nred(int op) { return op == OP_COLOR ? 24 : op == OP_TONE ? 8 : op == OP_WHITE ? 0 : 1; }
 
+// forward for a compile-time operator list: the operator loop unrolled (no `for k`, no `switch`), V pixels per
+// thread-iteration as the run-time-loop program
+template <int V, bool L1, class SEQ>
+T2O_HD float chain_fwd_thread_static(const ChainArgs& a, int b, int blk, int tid, const float* tab) {
+  constexpr int K = SEQ::K;
+  const unsigned hw = (unsigned)a.H * (unsigned)a.W;
+  const unsigned groups = hw / V;
+  const size_t sb = (size_t)b * 3 * hw;
+  const float* xin = a.img + sb;
+  float* o = a.out + sb;
+  float l1 = 0.0f;
+  for (int it = 0; it < a.iters; ++it) {
+    const unsigned g = ((unsigned)blk * a.iters + it) * kThreads + tid;
+    if (g >= groups) break;
+    const unsigned px = g * V;
+    float x[3][V];
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) load_vec<V>(xin + c * hw + px, x[c]);
+    T2O_UNROLL
+    for (int k = 0; k < K; ++k) {
+      T2O_UNROLL
+      for (int i = 0; i < V; ++i) {
+        Rgb xi = {{x[0][i], x[1][i], x[2][i]}};
+        const Rgb r = chain_op_fwd(SEQ::ops[k], xi, tab + k * kTabStride);
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) x[c][i] = clamp01(r.c[c]);
+      }
+    }
+    T2O_UNROLL
+    for (int c = 0; c < 3; ++c) store_vec<V>(o + c * hw + px, x[c]);
+    if (L1) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        float t[V];
+        load_vec<V>(a.target + sb + c * hw + px, t);
+        T2O_UNROLL
+        for (int i = 0; i < V; ++i) l1 += fabsf(x[c][i] - t[i]);
+      }
+    }
+  }
+  return l1;
+}
+
 template <bool L1, class SEQ, bool SV_LDS, class ACC>
 T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* svl, ACC& acc) {
   constexpr int K = SEQ::K;

@@ -390,6 +390,17 @@ __global__ __launch_bounds__(kThreads) void k_chain_fwd(ChainArgs a) {
   if (L1) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk);
 }
 
+template <int V, bool L1, class SEQ>
+__global__ __launch_bounds__(kThreads) void k_chain_fwd_static(ChainArgs a) {
+  __shared__ float tab[kMaxChain * kTabStride];
+  int b, blk;
+  wg_coords(a.nblk, b, blk);
+  if ((int)threadIdx.x < SEQ::K) chain_build_table(a, b, threadIdx.x, tab);
+  __syncthreads();
+  const float l1 = chain_fwd_thread_static<V, L1, SEQ>(a, b, blk, threadIdx.x, tab);
+  if (L1) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk);
+}
+
 template <int V, bool L1>
 __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [accumulator cells: NB rows of kAccStride][save area]
@@ -1137,12 +1148,6 @@ int t2o_fused_sequence_buffers(const int* ops, int K) {
   return ns < 0 ? -1 : ns - 1;
 }
 
-static int fused_chain_launch_fwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
-  const unsigned grid = (unsigned)a.B * a.nblk;
-  if (vec == 2) { if (l1) k_chain_fwd<2, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<2, false><<<grid, kThreads, 0, st>>>(a); }
-  else          { if (l1) k_chain_fwd<1, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<1, false><<<grid, kThreads, 0, st>>>(a); }
-  return 0;
-}
 }  // extern "C" (templates need C++ linkage)
 
 // operator lists with a compile-time instantiation of the backward: the benchmark / planner sequences
@@ -1165,6 +1170,13 @@ static void launch_static_bwd(ChainArgs& a, bool l1, hipStream_t st) {
   else k_chain_bwd_static<false, SEQ, SV_LDS, MINW><<<grid, kThreads, lds, st>>>(a);
 }
 template <class SEQ>
+static void launch_static_fwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
+  const unsigned grid = (unsigned)a.B * a.nblk;
+  if (vec == 2) { if (l1) k_chain_fwd_static<2, true, SEQ><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd_static<2, false, SEQ><<<grid, kThreads, 0, st>>>(a); }
+  else          { if (l1) k_chain_fwd_static<1, true, SEQ><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd_static<1, false, SEQ><<<grid, kThreads, 0, st>>>(a); }
+}
+
+template <class SEQ>
 static void launch_static_bwd_variant(ChainArgs& a, int variant, bool l1, hipStream_t st) {
   switch (variant) {
     case 2: launch_static_bwd<SEQ, true, 1>(a, l1, st); break;       // operator inputs saved in LDS: no faster (106.9 vs 104.2 us)
@@ -1180,6 +1192,17 @@ static int chain_static_variant() {
 }
 static bool chain_has_static_bwd(const ChainArgs& a, int vec) {
   return vec == 1 && chain_static_variant() && (chain_is<SeqCfg2>(a) || chain_is<SeqCfg5>(a));
+}
+
+static int fused_chain_launch_fwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
+  if (chain_static_variant()) {
+    if (chain_is<SeqCfg2>(a)) { launch_static_fwd<SeqCfg2>(a, vec, l1, st); return 0; }
+    if (chain_is<SeqCfg5>(a)) { launch_static_fwd<SeqCfg5>(a, vec, l1, st); return 0; }
+  }
+  const unsigned grid = (unsigned)a.B * a.nblk;
+  if (vec == 2) { if (l1) k_chain_fwd<2, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<2, false><<<grid, kThreads, 0, st>>>(a); }
+  else          { if (l1) k_chain_fwd<1, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<1, false><<<grid, kThreads, 0, st>>>(a); }
+  return 0;
 }
 
 static int fused_chain_launch_bwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
