@@ -55,13 +55,66 @@ def parse_action_record(record, op_max_len=OP_MAX_LEN):
     return op_seq, params, trunc_len
 
 
+def resize_linear_u8(img, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h)) for a uint8 (H,W,C) image with the default interpolation -- what the
+    reference's loaders call (utils/visual_utils.py:9,24,42).  cv2 is absent from this image, so this restates
+    OpenCV's published INTER_LINEAR algorithm for 8-bit images (imgproc/resize.cpp): half-pixel centres, NO
+    antialiasing when shrinking, 11-bit fixed-point coefficients (cvRound), horizontal pass in int32, vertical pass
+    ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2; and OpenCV's special case: an exact 2x shrink in both
+    directions is the rounded mean of each 2x2 block (INTER_LINEAR is replaced by the fast INTER_AREA path there).
+    Parity with cv2 itself is unpinned (nothing to run it against here); tests/test_data_cpu.py holds it to the
+    algorithm's own properties and to float bilinear within one grey level."""
+    img = np.ascontiguousarray(img)
+    H, W = img.shape[:2]
+    if (out_h, out_w) == (H, W):
+        return img.copy()
+    if H == 2 * out_h and W == 2 * out_w:
+        s = img.astype(np.int32)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+    def taps(n_src, n_dst):
+        f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        f = f - i0
+        lo = i0 < 0
+        f[lo], i0[lo] = 0.0, 0
+        hi = i0 >= n_src - 1
+        f[hi], i0[hi] = 0.0, n_src - 1
+        i1 = np.minimum(i0 + 1, n_src - 1)
+        c1 = np.rint(f * 2048.0).astype(np.int32)                  # cvRound: round half to even
+        c0 = np.rint((1.0 - f) * 2048.0).astype(np.int32)
+        return i0, i1, c0, c1
+    x0, x1, a0, a1 = taps(W, out_w)
+    y0, y1, b0, b1 = taps(H, out_h)
+    src = img.astype(np.int32)
+    shape = (1, out_w) + (1,) * (img.ndim - 2)
+    rows = src[:, x0] * a0.reshape(shape) + src[:, x1] * a1.reshape(shape)          # (H, out_w, C) int32
+    S0, S1 = rows[y0], rows[y1]
+    vb = (out_h, 1) + (1,) * (img.ndim - 2)
+    out = (((b0.reshape(vb) * (S0 >> 4)) >> 16) + ((b1.reshape(vb) * (S1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def load_image(path, size=None):
-    """RGB float tensor (3,H,W) in [0,1]; `size` -> square resize (training), None -> as is."""
+    """RGB float tensor (3,H,W) in [0,1] as the reference's loaders produce it (utils/visual_utils.py:6-31:
+    cv2.imread -> cv2.resize -> BGR->RGB -> /255).  `size`: None (as is), an int (square, training:
+    load_train_img) or (h, w).  Decoding is PIL's (libjpeg, like cv2's); the resize is resize_linear_u8."""
     from PIL import Image
-    img = Image.open(path).convert('RGB')
+    img = np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8)
     if size is not None:
-        img = img.resize((size, size), Image.BILINEAR)
-    return torch.from_numpy(np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0)
+        h, w = (size, size) if isinstance(size, int) else size
+        img = resize_linear_u8(img, h, w)
+    return torch.from_numpy(img.astype(np.float32).transpose(2, 0, 1) / 255.0)
+
+
+def load_image_short_side(path, short_size=600):
+    """utils/visual_utils.py:34-47 (full-resolution inference): the short side scaled to `short_size`."""
+    from PIL import Image
+    img = np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8)
+    h, w = img.shape[:2]
+    ratio = short_size / min(h, w)
+    img = resize_linear_u8(img, int(np.round(h * ratio)), int(np.round(w * ratio)))
+    return torch.from_numpy(img.astype(np.float32).transpose(2, 0, 1) / 255.0)
 
 
 class FiveKAct(Dataset):

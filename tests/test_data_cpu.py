@@ -41,3 +41,38 @@ def test_synthetic_dataset_shapes():
     loader = torch.utils.data.DataLoader(ds, batch_size=2)
     batch = next(iter(loader))
     assert batch[1].shape == (2, 6, 3, 32, 32)
+
+
+def test_resize_restates_cv2_inter_linear_properties(tmp_path):
+    """data.resize_linear_u8 = OpenCV's 8-bit INTER_LINEAR as published (cv2 itself is absent: unpinned against it).
+    Held to the algorithm's own properties and to float bilinear without antialiasing within one grey level, on a
+    JPEG written and decoded here."""
+    import io
+    import torch
+    from PIL import Image
+    from t2onet_amd import data
+    rng = np.random.default_rng(3)
+    base = (rng.random((37, 53, 3)) * 255).astype(np.uint8)
+    smooth = np.asarray(Image.fromarray(base).resize((212, 148), Image.BICUBIC))       # a natural-ish image
+    buf = io.BytesIO()
+    Image.fromarray(smooth).save(buf, format='JPEG', quality=92)
+    path = tmp_path / 'x.jpg'
+    path.write_bytes(buf.getvalue())
+    img = np.asarray(Image.open(str(path)).convert('RGB'))
+    H, W = img.shape[:2]
+    assert np.array_equal(data.resize_linear_u8(img, H, W), img)                       # same size: untouched
+    const = np.full((20, 30, 3), 77, np.uint8)
+    assert np.all(data.resize_linear_u8(const, 13, 17) == 77) and np.all(data.resize_linear_u8(const, 41, 64) == 77)
+    half = data.resize_linear_u8(img, H // 2, W // 2)                                  # exact 2x: rounded 2x2 block mean
+    s = img.astype(np.int32)
+    assert np.array_equal(half, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    for oh, ow in ((128, 128), (64, 100), (200, 300), (31, 17)):
+        got = data.resize_linear_u8(img, oh, ow).astype(np.float32)
+        t = torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None]
+        ref = torch.nn.functional.interpolate(t, size=(oh, ow), mode='bilinear', align_corners=False, antialias=False)[0]
+        assert np.abs(got - ref.permute(1, 2, 0).numpy()).max() <= 1.0 + 1e-3, (oh, ow)
+    x = data.load_image(str(path), 128)
+    assert tuple(x.shape) == (3, 128, 128) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+    np.testing.assert_array_equal((x * 255).round().numpy().astype(np.uint8), data.resize_linear_u8(img, 128, 128).transpose(2, 0, 1))
+    y = data.load_image_short_side(str(path), 100)
+    assert min(y.shape[1:]) == 100 and tuple(y.shape[1:]) == (100, int(np.round(W * 100 / H)))
