@@ -14,10 +14,10 @@ from . import functional as T
 
 
 _FUSED = os.environ.get('T2O_FUSED_BN', '1') != '0'      # 0: PyTorch's batch norm everywhere (A/B timing)
-# 1: the hand-written MFMA weight gradient (t2o_conv3x3_wgrad_nhwc) for the 3x3 stride-1 convolutions in channels-last
-# mode.  Deterministic (fixed-order split-K; the library's kernel adds atomically) but 5-15 % slower than the library's
-# on MI355X -- both sit at ~70 % matrix-pipe occupancy (profiles/r02_wgrad_*.txt) -- so it is opt-in.
-_OWN_WGRAD = os.environ.get('T2O_OWN_WGRAD', '0') != '0'
+# The hand-written MFMA weight gradient (t2o_conv3x3_wgrad_nhwc) for the 3x3 stride-1 convolutions in channels-last
+# mode: deterministic (fixed-order split-K; the library's kernel adds atomically) and 1.0-1.25x the library's speed
+# on MI355X (profiles/r02_wgrad_*.txt); the train step 65.2 -> 62.5 ms.  0: the library's weight gradient (A/B).
+_OWN_WGRAD = os.environ.get('T2O_OWN_WGRAD', '1') != '0'
 
 
 def _conv(conv, x):

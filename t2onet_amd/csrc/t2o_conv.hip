@@ -10,15 +10,15 @@
 // WEIGHT GRADIENT   dw[co][tap][ci] = sum_p dy[p][co] * x[p + shift(tap)][ci]      (p over all N*H*W pixels)
 //   One GEMM per tap: M = Co, N = Ci, K = pixels.  Both operands are stored pixel-major with the channel
 //   contiguous, which IS the MFMA operand order (lane l supplies A[m = l % 32][k = l / 32]: for one pixel k the 32
-//   lanes read 32 consecutive channels), so tiles go global -> LDS as plain 16-byte row copies and fragments are
-//   conflict-free ds_read_b32 -- no transposes anywhere.
-//   Workgroup = 256 threads = 2 x 2 waves, tile TM x TN channels (128 x 128: 2 x 2 MFMA blocks per wave, 64
-//   accumulator registers; 64 x 64 for the 64-channel stage), K consumed in stages of 32 pixels through two LDS
-//   buffers (the next stage's global loads are issued before the current stage's MFMAs).
-//   K is split across workgroups (a stage-aligned pixel range each); every workgroup writes its TM x TN tile of
-//   its own partial (split, Co, 9, Ci) array and a second kernel adds the partials in split order: deterministic,
-//   no float atomics.  Workgroups of one pixel range (9 taps x channel tiles: they re-read the same dy / x rows) get
-//   block indices congruent mod 8, i.e. land on the same XCD and share its L2.
+//   lanes read 32 consecutive channels), so tiles go global -> LDS as plain 16-byte row copies (LDS-DMA) and
+//   fragments are conflict-free ds_read_b32 -- no transposes anywhere.
+//   Workgroup = 256 threads = 2 x 2 waves = one kernel ROW (3 taps) of a TM x TN channel tile (128 x 64: 2 x 1 MFMA
+//   blocks per wave and tap, 96 accumulator registers), K consumed in stages of 32 pixels through two LDS buffers.
+//   K is split across workgroups (a stage-aligned pixel range each); every workgroup writes its tiles into its own
+//   partial (split, Co, 9, Ci) array and a second kernel adds the partials in a fixed order: deterministic, no
+//   float atomics.  The 3 kernel rows of one (pixel range, tile) get block indices congruent mod 8, i.e. land on the
+//   same XCD and share its L2.
+//   What the loop looks like, and why, is written at the kernel (measurements: tools/diag/*.hip, profiles/r02_*).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -42,32 +42,96 @@ struct WgradArgs {
   int N, H, W, Ci, Co;
   int tiles_m, tiles_n;       // channel tiles
   int splits, stages_per_split, total_stages;
+  const float* zero;            // >= 16 bytes of zeros: the LDS-DMA source of padding pixels and of the tail
   unsigned long long* stamps;   // diagnostic builds only (tools/diag/wgrad_clock.hip): per-workgroup clock stamps; null in the product
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int TM, int TN, int kStagePix, int kMinWaves>
+// Instructions beside an fp32 MFMA stream (tools/diag/valu_beside_mfma.hip, two waves per SIMD, the other one
+// streaming v_mfma_f32_32x32x2_f32): a VECTOR-ALU instruction of this wave takes 58 cycles when the partner's MFMAs
+// are interleaved with LDS reads and 300-400 beside a bare stream (11 alone); a SCALAR instruction 15-18 (10 alone);
+// LDS reads and LDS-DMA issue are not affected.  The loop below is therefore written with no vector-ALU
+// instructions at all outside the MFMAs: addresses are scalar bases plus loop-invariant lane offsets (LDS-DMA in
+// its saddr form, ds_read with immediate offsets), padding is decided per 1 KiB piece in scalar registers, and the
+// two edge masks of an image row are applied under a scalar branch only in the k-pairs that hold a row end.
+
+// One LDS-DMA wave-instruction (global_load_lds_dwordx4, saddr form): lane l's 16 bytes at sbase + voff[l] go to
+// LDS byte address lds_dst + 16 * l (lds_dst wave-uniform, in M0).  Inline assembly: through the builtin the
+// compiler cannot tell the DMA's LDS destination from the buffer the following ds_reads use and waits vmcnt(0) in
+// front of them; completion is waited for explicitly (glds_wait) before the barrier that publishes the tile.
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+#if defined(T2O_DIAG_GLDS) && T2O_DIAG_GLDS == 0       // diagnostic: no DMA at all (results are wrong, timing only)
+  return;
+#elif defined(T2O_DIAG_GLDS) && T2O_DIAG_GLDS == 1     // diagnostic: M0 not restored
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  return;
+#elif defined(T2O_DIAG_GLDS) && T2O_DIAG_GLDS == 2     // diagnostic: a plain load instead of the DMA (data dropped)
+  float4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return;
+#endif
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// ds_read_b32 with a compile-time byte offset: one loop-invariant address register per operand, no address arithmetic
+template <int kOff>
+__device__ __forceinline__ float lds_read(unsigned base) {
+  static_assert(kOff >= 0 && kOff < 65536, "ds_read immediate offset");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(kOff));
+  return v;
+}
+template <int kFirst, int kLast, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (kFirst < kLast) {
+    f(std::integral_constant<int, kFirst>{});
+    static_for<kFirst + 1, kLast>(f);
+  }
+}
+
+constexpr int kStagePix = 32;        // pixels (K of the GEMM) per LDS stage
+constexpr int kHalo = 4;             // x tile rows before the stage's first pixel (1 needed; 4 keeps 1 KiB pieces inside an image row)
+
+// One workgroup = one kernel ROW (kh fixed, kw = 0, 1, 2) of a TM x TN channel tile over a range of pixels.  The three
+// taps of a row read the same dy tile and the same x rows shifted by one pixel, so the x tile is staged once with a
+// halo (row r of Bs = pixel p0 - 4 + r of the image row h + dh) and every dy fragment feeds three MFMAs.
+// Requires W % 4 == 0: a 1 KiB DMA piece (2 or 4 pixels, aligned) then never crosses an image row, so a piece is
+// either a run of real pixels or all padding (row h + dh outside the image, or beyond the last pixel) and reads the
+// zero region instead -- a scalar select of the base address.  A pixel whose horizontal neighbour lies outside its
+// image row (w == 0 for kw = 0, w == W-1 for kw = 2) has that fragment element zeroed in registers.
+template <int TM, int TN, int kMinWaves>
 __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(WgradArgs a) {
   constexpr int BM = TM / 64, BN = TN / 64;          // MFMA blocks per wave along m / n (wave tile = TM/2 x TN/2)
-  constexpr int RA = TM / 4, RB = TN / 4;            // float4 per tile row
-  constexpr int PA = kStagePix * RA / kConvThreads;  // float4 loads per thread per stage (dy / x)
-  constexpr int PB = kStagePix * RB / kConvThreads;
+  constexpr int RWA = 256 / TM, RWB = 256 / TN;            // tile rows per 1 KiB DMA piece
+  constexpr int NPA = kStagePix / RWA;                     // dy pieces per stage
+  constexpr int PB0 = (kHalo - 1) / RWB;                   // first x piece holding a row that is read (rows kHalo-1 .. kHalo+kStagePix)
+  constexpr int NA = NPA / 4, NB = ((kHalo + kStagePix) / RWB + 1 - PB0 + 3) / 4;      // pieces per wave
+  constexpr int BROWS = (PB0 + 4 * NB) * RWB;              // x tile rows: every wave loads NB pieces (the last ones past the rows that are read)
   __shared__ __attribute__((aligned(16))) float As[2][kStagePix][TM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kStagePix][TN];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BROWS][TN];
 
-  // block index -> (split, channel tile, tap).  The 9 taps of one (split, tile) re-read the same dy / x tile rows:
-  // they get block indices congruent mod 8 (same XCD, shared L2) and adjacent in dispatch order; consecutive
-  // (split, tile) units go to consecutive XCDs, so every XCD gets the same number of workgroups.
+  // block index -> (split, channel tile, kernel row).  The 3 kernel rows of one (split, tile) re-read the same dy
+  // tile and neighbouring x rows: they get block indices congruent mod 8 (same XCD, shared L2) and adjacent in
+  // dispatch order; consecutive (split, tile) units go to consecutive XCDs, so every XCD gets the same number of
+  // workgroups.
   const int units = a.splits * a.tiles_m * a.tiles_n;
   const int b = blockIdx.x;
-  const int unit = (b / 72) * 8 + b % 8;
-  const int tap = (b % 72) / 8;
+  const int unit = (b / 24) * 8 + b % 8;
+  const int kh = (b % 24) / 8;
   if (unit >= units) return;
   const int tiles = a.tiles_m * a.tiles_n;
-  const int split = unit / tiles, tile = unit % tiles;
-  const int m0 = (tile / a.tiles_n) * TM, n0 = (tile % a.tiles_n) * TN;
-  const int dh = tap / 3 - 1, dw = tap % 3 - 1;
+  // (integer division by a run-time value is done in vector registers even for wave-uniform operands: the results
+  // go back to scalar registers here, once, so that everything derived from them stays scalar)
+  const int split = __builtin_amdgcn_readfirstlane(unit / tiles), tile = unit - split * tiles;
+  const int tile_m = __builtin_amdgcn_readfirstlane(tile / a.tiles_n), tile_n = tile - tile_m * a.tiles_n;
+  const int m0 = tile_m * TM, n0 = tile_n * TN;
+  const int dh = kh - 1;
 
   unsigned long long t0 = 0, r0 = 0;
   if (a.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -76,163 +140,220 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
   int s1 = s0 + a.stages_per_split;
   if (s1 > a.total_stages) s1 = a.total_stages;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lk = lane >> 5;
 
-  f32x16 acc[BM][BN];
+  f32x16 acc[3][BM][BN];
 #pragma unroll
-  for (int i = 0; i < BM; ++i)
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int jn = 0; jn < BN; ++jn)
+    for (int i = 0; i < BM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+      for (int jn = 0; jn < BN; ++jn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][jn][r] = 0.0f;
 
-  float4 ra[2][PA], rb[2][PB];                     // two register sets: the global loads run TWO stages ahead
-  // per load slot: the pixel's (h, w), advanced by one stage (32 pixels) at a time -- no division in the loop
-  int ph[PB], pw[PB];
-  {
-    const int pbase = s0 * kStagePix;
+  // ---- global -> LDS by LDS-DMA.  One wave-instruction writes 1 KiB of consecutive LDS = RW whole tile rows; lane l
+  // supplies the 16 bytes at column 4 * (l % (T/4)) of row l / (T/4): a loop-invariant byte offset from the piece's
+  // scalar base address.
+  const unsigned lane_a = (unsigned)((lane / (TM / 4)) * a.Co + (lane % (TM / 4)) * 4) * 4u;
+  const unsigned lane_b = (unsigned)((lane / (TN / 4)) * a.Ci + (lane % (TN / 4)) * 4) * 4u;
+  // (a.zero is read from the kernel arguments where it is used: as a local captured by the lambdas below, 'ok ? p :
+  // zero' becomes a load through a selected ADDRESS of two captures, which keeps all captures in scratch memory)
+  int pbase = s0 * kStagePix;                              // first pixel of the stage the next dma_stage() loads
+  // 64-bit scalar bases of that stage's first dy / x piece of this wave
+  const char* a_ptr = (const char*)(a.dy + m0) + ((long long)pbase + wave * RWA) * a.Co * 4;
+  const char* b_ptr = (const char*)(a.x + n0) + ((long long)pbase - kHalo + (PB0 + wave) * RWB + (long long)dh * a.W) * a.Ci * 4;
+  const long long step_a = (long long)4 * RWA * a.Co * 4, step_b = (long long)4 * RWB * a.Ci * 4;      // to this wave's next piece
+  const long long stage_a = (long long)kStagePix * a.Co * 4, stage_b = (long long)kStagePix * a.Ci * 4;
+  // A piece of x is padding iff its image row h + dh lies outside the image: with m = (pixel index) mod (H * W)
+  // that is m < W for dh = -1 and m >= (H - 1) * W for dh = +1, i.e. valid iff lo <= m < lo + span.  m is tracked
+  // per piece, advanced by one stage with an add and a conditional subtract.
+  const int HW = a.H * a.W;
+  const int m_lo = dh < 0 ? a.W : 0, m_span = dh == 0 ? HW : HW - a.W;
+  const int adv_m = __builtin_amdgcn_readfirstlane(kStagePix % HW);
+  int mrow[NB];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int p = pbase + (tid + i * kConvThreads) / RB;
-      pw[i] = p % a.W;
-      ph[i] = (p / a.W) % a.H;
+  for (int i = 0; i < NB; ++i)
+    mrow[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(pbase - kHalo + (PB0 + wave + 4 * i) * RWB + HW) % (unsigned)HW));    // (+HW: >= 0)
+  const unsigned lds_a = lds_addr(&As[0][0][0]), lds_b = lds_addr(&Bs[0][0][0]);
+  // The DMA of a stage is NA + NB pieces per wave, all scalar work: select the base address (the zero region for
+  // padding, for the tail and when there is no next stage), issue, advance m.
+  bool more = true;                                        // there is a stage to load
+  auto dma_piece = [&](auto jc, int buf) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < NA) {
+      const int piece = wave + 4 * j;
+      const bool ok = more && pbase + piece * RWA < P;     // P % 4 == 0: a piece is all inside or all beyond the tail
+      glds16(lane_a, ok ? a_ptr + j * step_a : (const char*)a.zero, lds_a + (unsigned)(buf * kStagePix * TM * 4 + piece * 1024));
+    } else {
+      constexpr int i = j - NA;
+      const int piece = PB0 + wave + 4 * i;
+      const int q0 = pbase - kHalo + piece * RWB;          // the pixel whose centre tap reads the piece's first row
+      const bool ok = more && (unsigned)q0 < (unsigned)P && (unsigned)(mrow[i] - m_lo) < (unsigned)m_span;
+      glds16(lane_b, ok ? b_ptr + i * step_b : (const char*)a.zero, lds_b + (unsigned)(buf * BROWS * TN * 4 + piece * 1024));
+      mrow[i] += adv_m;
+      mrow[i] -= mrow[i] >= HW ? HW : 0;
     }
-  }
-  const int adv_w = kStagePix % a.W, adv_h = kStagePix / a.W;
-  auto load_stage = [&](int st, int set) {
-    const int pbase = st * kStagePix;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int idx = tid + i * kConvThreads;
-      const int row = idx / RA, c4 = idx % RA;
-      const int p = pbase + row;
-      ra[set][i] = p < P ? ldg4(a.dy + (size_t)p * a.Co + m0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int idx = tid + i * kConvThreads;
-      const int row = idx / RB, c4 = idx % RB;
-      const int p = pbase + row;
-      const bool ok = p < P && (unsigned)(ph[i] + dh) < (unsigned)a.H && (unsigned)(pw[i] + dw) < (unsigned)a.W;
-      rb[set][i] = ok ? ldg4(a.x + (size_t)(p + dh * a.W + dw) * a.Ci + n0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pw[i] += adv_w;                                   // -> the same slot's pixel of the next stage
-      const int carry = pw[i] >= a.W ? 1 : 0;
-      pw[i] -= carry * a.W;
-      ph[i] += adv_h + carry;
-      while (ph[i] >= a.H) ph[i] -= a.H;
+    if constexpr (j == NA + NB - 1) {                      // the stage's last piece: on to the next stage
+      pbase += kStagePix;
+      a_ptr += stage_a;
+      b_ptr += stage_b;
     }
   };
-  auto store_stage = [&](int buf, int set) {
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int idx = tid + i * kConvThreads;
-      *reinterpret_cast<float4*>(&As[buf][idx / RA][(idx % RA) * 4]) = ra[set][i];
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int idx = tid + i * kConvThreads;
-      *reinterpret_cast<float4*>(&Bs[buf][idx / RB][(idx % RB) * 4]) = rb[set][i];
-    }
+  auto dma_stage = [&](int buf) {                          // a whole stage at once (the prologue)
+    static_for<0, NA + NB>([&](auto jc) { dma_piece(jc, buf); });
   };
 
-  // One continuous MFMA stream across stages, global loads two stages ahead.  Stage st (LDS buffer q = parity of
-  // st - s0, kStagePix / 2 k-pairs, 4 MFMAs of 64 cycles each per pair):
-  //   k-pair 0        the loads of stage st+2 are issued into register set q (its previous content, stage st, went to
-  //                   LDS during stage st-1): they have a whole stage (~10k cycles) to land, HBM latency never shows
-  //   k-pairs kS..    one 16-byte LDS store per k-pair of stage st+1 (register set q^1, loaded during stage st-1)
-  //                   into the OTHER buffer
-  //   k-pair  last-1  barrier: every wave's stores are done -- it does not have to wait for anybody's reads of the
-  //                   current buffer, and the matrix pipe still holds 256 cycles of this wave's MFMAs to cover the skew
-  //   k-pair  last    its fragment prefetch already reads k-pair 0 of stage st+1, so the first MFMAs after the stage
-  //                   boundary find their operands in registers: no bubble at the boundary
+  // ---- fragments: lane l reads channel (l % 32) of pixel 2 * kk + l / 32 -- conflict-free ds_read_b32 from one
+  // loop-invariant address per operand plus compile-time offsets
   constexpr int KP = kStagePix / 2;                       // k-pairs per stage
-  constexpr int NST = PA + PB;                            // LDS stores per thread per stage
-  constexpr int kS = 1;                                   // first k-pair that carries a store
-  static_assert(kS + NST <= KP - 1, "stage too short for its stores");
-  float fa[2][BM], fb[2][BN];
-  auto read_frags = [&](int buf, int kk, int slot) {
-    const int k = kk * 2 + lk;
-#pragma unroll
-    for (int i = 0; i < BM; ++i) fa[slot][i] = As[buf][k][wm * (TM / 2) + i * 32 + lr];
-#pragma unroll
-    for (int jn = 0; jn < BN; ++jn) fb[slot][jn] = Bs[buf][k][wn * (TN / 2) + jn * 32 + lr];
+  const unsigned fa_base = lds_a + (unsigned)((lk * TM + wm * (TM / 2) + lr) * 4);
+  const unsigned fb_base = lds_b + (unsigned)((lk * TN + wn * (TN / 2) + lr) * 4);
+  float fa[2][BM], fb[2][3][BN];
+  auto read_frags = [&](auto Qc, auto kkc, auto slotc) {
+    constexpr int Q = decltype(Qc)::value, kk = decltype(kkc)::value, slot = decltype(slotc)::value;
+    static_for<0, BM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      fa[slot][i] = lds_read<(Q * kStagePix + 2 * kk) * TM * 4 + i * 128>(fa_base);
+    });
+    static_for<0, 3>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      static_for<0, BN>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        fb[slot][t][jn] = lds_read<(Q * BROWS + 2 * kk + kHalo - 1 + t) * TN * 4 + jn * 128>(fb_base);
+      });
+    });
   };
-  // one stage; Q (compile time) = LDS buffer and register-set parity of this stage
+  // column of the image row that the k-pair being CONSUMED starts at (even: W % 4 == 0 and stages start at multiples of 32)
+  int wk = __builtin_amdgcn_readfirstlane((int)((unsigned)(s0 * kStagePix) % (unsigned)a.W));
+
+#ifdef T2O_CONV_DIAG
+  unsigned kp_cycles[KP] = {}, dma_cycles = 0;
+#endif
+  // One continuous MFMA stream across stages.  Stage st (LDS buffer Q = parity of st - s0), KP k-pairs of
+  // 3 * BM * BN MFMAs (64 cycles each):
+  //   before k-pair 0  the LDS-DMA of stage st+1 is issued into the OTHER buffer (nobody reads it any more: its last
+  //                    reads were before the previous stage's barrier) and flies under the whole stage
+  //   k-pair  last-1   barrier (after this wave's DMA has landed): every wave's part of the next tile is there; the
+  //                    matrix pipe still holds this wave's MFMAs to cover the skew
+  //   k-pair  last     its fragment prefetch already reads k-pair 0 of stage st+1: no bubble at the stage boundary
+  constexpr int NM = 3 * BM * BN;                         // MFMAs per k-pair
+  constexpr int kSaluPerGap = (24 + NM - 1) / NM;         // ~24 scalar instructions per piece
+  static_assert(NA + NB <= KP - 3, "one DMA piece per k-pair, all issued well before the barrier");
   auto stage = [&](auto Qc, int st) {
     constexpr int Q = decltype(Qc)::value;
     const bool has_next = st + 1 < s1;
-    if (st + 2 < s1) load_stage(st + 2, Q);
+    more = has_next;
+#ifdef T2O_CONV_DIAG
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();       // diagnostic build: cycles per k-pair position, summed over stages
+#endif
+    static_for<0, KP>([&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      constexpr int cur = kk & 1, nxt = cur ^ 1;
+      lds_wait();                                         // the fragments of this k-pair (read one k-pair ago)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kk + 1 < KP) read_frags(Qc, std::integral_constant<int, kk + 1>{}, std::integral_constant<int, nxt>{});
+      else if (has_next) read_frags(std::integral_constant<int, Q ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
+      // image-row ends inside this k-pair (scalar conditions; one k-pair in W/2 has either)
+      // (volatile asm inside the branches: as plain selects the compiler turns them into 6 unconditional v_cndmask per k-pair)
+      if (wk == 0) {                                      // lanes of pixel 2kk sit at w == 0: kw = 0 reads pixel w-1, outside
 #pragma unroll
-    for (int kk = 0; kk < KP; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < KP) read_frags(Q, kk + 1, nxt);
-      else if (has_next) read_frags(Q ^ 1, 0, nxt);       // (after the barrier of k-pair KP-2)
-      if (has_next && kk >= kS && kk < kS + NST) {
-        const int i = kk - kS;
-        if (i < PA) {
-          const int idx = tid + i * kConvThreads;
-          *reinterpret_cast<float4*>(&As[Q ^ 1][idx / RA][(idx % RA) * 4]) = ra[Q ^ 1][i < PA ? i : 0];
-        } else {
-          const int idx = tid + (i - PA) * kConvThreads;
-          *reinterpret_cast<float4*>(&Bs[Q ^ 1][idx / RB][(idx % RB) * 4]) = rb[Q ^ 1][i >= PA ? i - PA : 0];
+        for (int jn = 0; jn < BN; ++jn) asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(fb[cur][0][jn]) : "s"(0x00000000ffffffffull));
+      }
+      wk += 2;
+      if (wk == a.W) {                                    // lanes of pixel 2kk+1 sit at w == W-1: kw = 2 reads pixel w+1, outside
+        wk = 0;
+#pragma unroll
+        for (int jn = 0; jn < BN; ++jn) asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(fb[cur][2][jn]) : "s"(0xffffffff00000000ull));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the k-pair's MFMAs, and DMA piece kk of stage st+1 (into the OTHER buffer): ~20 scalar instructions that the
+      // scheduler is told to deal out two per MFMA (in the shadow of the MFMA just issued) instead of in one block
+      if constexpr (kk < NA + NB) dma_piece(kkc, Q ^ 1);
+      static_for<0, NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int t = m / (BM * BN), i = (m / BN) % BM, jn = m % BN;
+        acc[t][i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][t][jn], acc[t][i][jn], 0, 0, 0);
+      });
+      if constexpr (kk < NA + NB) {
+#pragma unroll
+        for (int g = 0; g < NM; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x004, kSaluPerGap, 0);      // scalar instructions of the piece
         }
       }
-      __builtin_amdgcn_sched_barrier(0);                  // keep reads / stores above the MFMAs (the scheduler sinks them)
-#pragma unroll
-      for (int i = 0; i < BM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < BN; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][jn], acc[i][jn], 0, 0, 0);
-      if (kk == KP - 2) __syncthreads();
+      if constexpr (kk == KP - 2) { glds_wait(); __syncthreads(); }
       __builtin_amdgcn_sched_barrier(0);
-    }
+#ifdef T2O_CONV_DIAG
+      { const unsigned long long tn = __builtin_amdgcn_s_memtime(); kp_cycles[kk] += (unsigned)(tn - tprev); tprev = tn; }
+#endif
+    });
   };
 
-  if (s0 < s1) {
-    load_stage(s0, 0);
-    store_stage(0, 0);
-    if (s0 + 1 < s1) load_stage(s0 + 1, 1);
-  }
+  if (s0 < s1) dma_stage(0);
+  glds_wait();
   __syncthreads();
-  if (s0 < s1) read_frags(0, 0, 0);
+  if (s0 < s1) read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   for (int st = s0; st < s1; st += 2) {
     stage(std::integral_constant<int, 0>{}, st);
     if (st + 1 < s1) stage(std::integral_constant<int, 1>{}, st + 1);
   }
+  lds_wait();
 
   if (a.stamps && threadIdx.x == 0) {
     a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
     a.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+#ifdef T2O_CONV_DIAG
+    for (int kk = 0; kk < KP; ++kk) a.stamps[2 * gridDim.x + (size_t)blockIdx.x * (KP + 2) + kk] = kp_cycles[kk];
+    a.stamps[2 * gridDim.x + (size_t)blockIdx.x * (KP + 2) + KP] = (unsigned long long)(s1 - s0);
+    a.stamps[2 * gridDim.x + (size_t)blockIdx.x * (KP + 2) + KP + 1] = dma_cycles;
+#endif
   }
   // C/D layout: column (n) = lane % 32, row (m) = (reg % 4) + 8 * (reg / 4) + 4 * (lane / 32)
   float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
 #pragma unroll
-  for (int i = 0; i < BM; ++i)
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int jn = 0; jn < BN; ++jn)
+    for (int i = 0; i < BM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int n = n0 + wn * (TN / 2) + jn * 32 + lr;
-        out[((size_t)m * 9 + tap) * a.Ci + n] = acc[i][jn][r];
-      }
+      for (int jn = 0; jn < BN; ++jn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int n = n0 + wn * (TN / 2) + jn * 32 + lr;
+          out[((size_t)m * 9 + (kh * 3 + t)) * a.Ci + n] = acc[t][i][jn][r];
+        }
 }
 
-// dw[i] = sum over splits of partial[s][i], in split order; 4 floats per thread
+// dw[i] = sum over splits of partial[s][i], in a fixed order.  A workgroup takes 32 consecutive float4 of the
+// output; its 8 thread rows each add every 8th split (in split order), then the 8 partial sums are added in row
+// order through LDS: deterministic, and 8 x as many loads in flight as one thread per output (with 168 splits of
+// a 64-channel layer that serial loop took 50 us for 25 MB).
 __global__ __launch_bounds__(kConvThreads) void k_conv_wgrad_reduce(const float* partial, float* dw, size_t n4, int splits, size_t stride) {
-  const size_t i = (size_t)blockIdx.x * kConvThreads + threadIdx.x;
-  if (i >= n4) return;
-  float4 s = ldg4(partial + 4 * i);
-  for (int k = 1; k < splits; ++k) {
-    const float4 v = ldg4(partial + (size_t)k * stride + 4 * i);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  __shared__ float4 part[8][32];
+  const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + col;
+  float4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (i < n4)
+    for (int k = row; k < splits; k += 8) {
+      const float4 v = ldg4(partial + (size_t)k * stride + 4 * i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  part[row][col] = s;
+  __syncthreads();
+  if (row == 0 && i < n4) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const float4 v = part[r][col];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dw + 4 * i) = s;
   }
-  *reinterpret_cast<float4*>(dw + 4 * i) = s;
 }
 
-struct WgradPlan { int tm, tn, tiles_m, tiles_n, splits, stages_per_split, total_stages, stage_pix; };
+struct WgradPlan { int tm, tn, tiles_m, tiles_n, splits, stages_per_split, total_stages; size_t zero_bytes; };
 
 int conv_env(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -240,27 +361,27 @@ int conv_env(const char* name, int dflt) {
 }
 
 bool wgrad_supported(int N, int H, int W, int Ci, int Co) {
-  return N > 0 && H > 0 && W > 0 && Ci >= 64 && Co >= 64 && Ci % 64 == 0 && Co % 64 == 0 &&
-         (size_t)N * H * W < ((size_t)1 << 30);
+  return N > 0 && H > 0 && W >= 4 && W % 4 == 0 && Ci >= 64 && Co >= 64 && Ci % 64 == 0 && Co % 64 == 0 &&
+         (size_t)N * H * W + (size_t)H * W + 64 < ((size_t)1 << 31);               // pixel indices are ints
 }
 
 WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co) {
   WgradPlan p;
-  p.tm = (Co % 128 == 0) ? 128 : 64;
-  p.tn = (Ci % 128 == 0) ? 128 : 64;
+  static const int tile_n = conv_env("T2O_WGRAD_TILE_N", 64);            // 128: 128 x 128 tiles -- twice the split-K partial bytes per workgroup
+  static const int tile_m = conv_env("T2O_WGRAD_TILE_M", 128);
+  p.tm = (Co % 128 == 0 && tile_m == 128) ? 128 : 64;
+  p.tn = (Ci % 128 == 0 && tile_n == 128) ? 128 : 64;
   p.tiles_m = Co / p.tm;
   p.tiles_n = Ci / p.tn;
   const int P = N * H * W;
-  static const int stage_pix = conv_env("T2O_WGRAD_STAGE", 32);          // 16: three workgroups per CU (A/B runs)
-  p.stage_pix = stage_pix == 16 ? 16 : 32;
-  p.total_stages = (P + p.stage_pix - 1) / p.stage_pix;
-  const int group = 9 * p.tiles_m * p.tiles_n;
-  // ONE round of workgroups: 2 are resident per CU (LDS), 64 slots per XCD; a second, partly filled round would
-  // cost a whole round's time.  (split, tile) units are dealt to the 8 XCDs in turn, 9 workgroups (taps) each:
-  // 7 units per XCD = 63 slots.  At least 8 stages of K per workgroup.
+  p.total_stages = (P + kStagePix - 1) / kStagePix;
+  // zeros behind the lane offsets of one DMA piece (up to 4 pixel rows of the wider tensor)
+  p.zero_bytes = ((size_t)4 * (Ci > Co ? Ci : Co) * 4 + 1024 + 255) / 256 * 256;
+  // ONE round of workgroups: 2 are resident per CU, 64 slots per XCD; a second, partly filled round would cost a
+  // whole round's time.  (split, tile) units are dealt to the 8 XCDs in turn, 3 workgroups (kernel rows) each:
+  // 21 units per XCD = 63 slots.  At least 8 stages of K per workgroup.
   static const int units = conv_env("T2O_WGRAD_UNITS", 0);
-  int splits = (units > 0 ? units : p.stage_pix == 16 ? 80 : 56) / (p.tiles_m * p.tiles_n);
-  (void)group;
+  int splits = (units > 0 ? units : 168) / (p.tiles_m * p.tiles_n);      // 168 units x 3 kernel rows = 504 workgroups
   if (splits > p.total_stages / 8) splits = p.total_stages / 8;
   if (splits < 1) splits = 1;
   p.stages_per_split = (p.total_stages + splits - 1) / splits;
@@ -275,39 +396,37 @@ extern "C" {
 size_t t2o_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co) {
   if (!wgrad_supported(N, H, W, Ci, Co)) return 0;
   const WgradPlan p = wgrad_plan(N, H, W, Ci, Co);
-  return sizeof(float) * (size_t)p.splits * Co * 9 * Ci;
+  return p.zero_bytes + sizeof(float) * (size_t)p.splits * Co * 9 * Ci;      // [zero region][split-K partials]
 }
 
 int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream) {
   if (!x || !dy || !dw) return set_error(T2O_EINVAL, "conv3x3_wgrad: null pointer");
   if (!wgrad_supported(N, H, W, Ci, Co))
-    return set_error(T2O_EUNSUPPORTED, "conv3x3_wgrad: channel counts must be multiples of 64 (>= 64)");
+    return set_error(T2O_EUNSUPPORTED, "conv3x3_wgrad: channel counts must be multiples of 64 and the image width a multiple of 4");
   if (!workspace || workspace_bytes < t2o_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co))
     return set_error(T2O_EWORKSPACE, "conv3x3_wgrad: workspace too small");
   const WgradPlan p = wgrad_plan(N, H, W, Ci, Co);
   WgradArgs a;
-  a.x = x; a.dy = dy; a.partial = (float*)workspace;
+  a.x = x; a.dy = dy; a.partial = (float*)((char*)workspace + p.zero_bytes); a.zero = (const float*)workspace;
+  if (hipMemsetAsync(workspace, 0, p.zero_bytes, (hipStream_t)stream) != hipSuccess)
+    return set_error(T2O_ELAUNCH, "conv3x3_wgrad: clearing the zero region failed");
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n;
   a.splits = p.splits; a.stages_per_split = p.stages_per_split; a.total_stages = p.total_stages;
   a.stamps = nullptr;
   const int units = p.splits * p.tiles_m * p.tiles_n;
-  const unsigned grid = (unsigned)(((units + 7) / 8) * 72);
+  const unsigned grid = (unsigned)(((units + 7) / 8) * 24);
   hipStream_t st = (hipStream_t)stream;
-#define T2O_WGRAD_LAUNCH(TM_, TN_)                                                                     \
-  do {                                                                                                 \
-    if (p.stage_pix == 16) k_conv3x3_wgrad<TM_, TN_, 16, 3><<<grid, kConvThreads, 0, st>>>(a);           \
-    else k_conv3x3_wgrad<TM_, TN_, 32, 2><<<grid, kConvThreads, 0, st>>>(a);                              \
-  } while (0)
+#define T2O_WGRAD_LAUNCH(TM_, TN_) k_conv3x3_wgrad<TM_, TN_, 2><<<grid, kConvThreads, 0, st>>>(a)
   if (p.tm == 128 && p.tn == 128) T2O_WGRAD_LAUNCH(128, 128);
   else if (p.tm == 128) T2O_WGRAD_LAUNCH(128, 64);
   else if (p.tn == 128) T2O_WGRAD_LAUNCH(64, 128);
   else T2O_WGRAD_LAUNCH(64, 64);
 #undef T2O_WGRAD_LAUNCH
   const size_t n = (size_t)Co * 9 * Ci, n4 = n / 4;
-  k_conv_wgrad_reduce<<<(unsigned)((n4 + kConvThreads - 1) / kConvThreads), kConvThreads, 0, st>>>(
-      (const float*)workspace, dw, n4, p.splits, n);
+  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(
+      a.partial, dw, n4, p.splits, n);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3_wgrad launch failed");
 }
 

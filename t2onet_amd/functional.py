@@ -381,7 +381,7 @@ def conv3x3_wgrad(x, dy):
     lib = _lib.load()
     need = lib.t2o_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co)
     if need == 0:
-        raise RuntimeError('conv3x3_wgrad: unsupported shape (channels must be multiples of 64)')
+        raise RuntimeError('conv3x3_wgrad: unsupported shape (channels must be multiples of 64, the width a multiple of 4)')
     key = (x.device.index, _stream(x.device))
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -394,10 +394,11 @@ def conv3x3_wgrad(x, dy):
 
 def conv3x3_supported(x, weight, stride, padding):
     """Layers the matrix-core weight gradient takes: channels-last fp32 activations on the GPU, 3x3 / stride 1 /
-    padding 1, channel counts multiples of 64 (every BasicBlock convolution of the encoder except the strided ones)."""
+    padding 1, channel counts multiples of 64, image width a multiple of 4 (every BasicBlock convolution of the
+    encoder except the strided ones, for inputs of 32 pixels and more)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
             and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and weight.shape[0] % 64 == 0
-            and weight.shape[1] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+            and weight.shape[1] % 64 == 0 and x.shape[3] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
 class _Conv3x3Fn(torch.autograd.Function):

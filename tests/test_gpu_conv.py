@@ -17,9 +17,11 @@ def _ref_wgrad(x, dy, co, ci):
     return w.grad
 
 
-# (N, Ci, Co, H, W): every tile template, ragged pixel counts (stage tail), one-row and one-column images, deep split-K
-SHAPES = [(2, 64, 64, 8, 8), (3, 128, 128, 5, 7), (2, 64, 128, 6, 6), (2, 128, 64, 9, 4), (1, 256, 192, 4, 4),
-          (4, 64, 64, 1, 9), (2, 64, 64, 7, 1), (2, 128, 256, 16, 16), (3, 64, 64, 33, 20)]
+# (N, Ci, Co, H, W), W a multiple of 4: every tile template, ragged pixel counts (stage tail), one-row images, rows
+# shorter / longer than a 32-pixel stage and not dividing it, deep split-K
+SHAPES = [(2, 64, 64, 8, 8), (3, 128, 128, 5, 12), (2, 64, 128, 6, 4), (2, 128, 64, 9, 4), (1, 256, 192, 4, 4),
+          (4, 64, 64, 1, 8), (2, 64, 64, 7, 20), (2, 128, 256, 16, 16), (3, 64, 64, 33, 20), (1, 128, 128, 3, 40),
+          (2, 64, 64, 5, 64)]
 
 
 @pytest.mark.parametrize('shape', SHAPES)
@@ -40,13 +42,25 @@ def test_wgrad_matches_conv2d_fp64(shape):
     assert torch.equal(dw, T.conv3x3_wgrad(xg, dg))
 
 
+def test_wgrad_refuses_widths_it_does_not_take():
+    """W % 4 != 0 is not a shape of the kernel: the library says so and the autograd wrapper's predicate sends such
+    layers to the library convolution."""
+    import t2onet_amd.functional as T
+    dev = torch.device('cuda:0')
+    x = torch.zeros(1, 64, 6, 6, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(64, 64, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    assert not T.conv3x3_supported(x, w, (1, 1), (1, 1))
+    with pytest.raises(RuntimeError):
+        T.conv3x3_wgrad(x, x)
+
+
 def test_conv3x3_autograd_function_matches_library():
     """The autograd wrapper (library forward + data gradient, own weight gradient) vs plain F.conv2d autograd."""
     import t2onet_amd.functional as T
     dev = torch.device('cuda:0')
-    x = synth.uniform((2, 64, 12, 10), 711, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    x = synth.uniform((2, 64, 10, 12), 711, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
     w = synth.uniform((128, 64, 3, 3), 712, -0.1, 0.1).to(dev).contiguous(memory_format=torch.channels_last)
-    gy = synth.uniform((2, 128, 12, 10), 713, -1.0, 1.0).to(dev)
+    gy = synth.uniform((2, 128, 10, 12), 713, -1.0, 1.0).to(dev)
     x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     assert T.conv3x3_supported(x1, w1, (1, 1), (1, 1))

@@ -1,2 +1,2 @@
-bash tools/gpu_check.sh r03m
-bash tools/gpu_pmc.sh r03m_pmc
+export TMPDIR=/tmp
+T2O_OWN_WGRAD=1 timeout 1500 python -m pytest tests -m gpu -q --tb=short -x -k "actor or train or conv or golden" 2>&1 | tail -8
