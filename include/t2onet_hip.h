@@ -200,10 +200,25 @@ int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const 
  *   x  (N,H,W,Ci) and dy (N,H,W,Co): NHWC = torch.channels_last storage of (N,C,H,W) tensors
  *   dw (Co,3,3,Ci)                 = channels_last storage of a (Co,Ci,3,3) weight gradient
  *   dw[co][kh][kw][ci] = sum_{n,h,w} dy[n][h][w][co] * x[n][h+kh-1][w+kw-1][ci]   (zero padding)
- * Ci and Co must be multiples of 64.  Deterministic: split-K partial sums in `workspace`
+ * Ci and Co must be multiples of 64, W a multiple of 4.  Deterministic: split-K partial sums in `workspace`
  * (t2o_conv3x3_wgrad_workspace_bytes) are added in a fixed order. */
 size_t t2o_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                           int N, int H, int W, int Ci, int Co, void* stream);
+
+/* ---- the same convolutions, forward and data gradient (t2o_conv.hip: one implicit-GEMM kernel on the fp32 matrix
+ * cores; the data gradient runs it on dy with the transposed, tap-mirrored weight).  Replace F.conv2d(x, w, None, 1, 1)
+ * (models/actor_resnet.py:27-30 conv3x3) and torch.ops.aten.convolution_backward(..., output_mask [1,0,0]).
+ *   y[n][h][w][co]  = sum_{kh,kw,ci} x[n][h+kh-1][w+kw-1][ci] * w[co][kh][kw][ci]        (zero padding)
+ *   dx[n][h][w][ci] = sum_{kh,kw,co} dy[n][h-kh+1][w-kw+1][co] * w[co][kh][kw][ci]
+ * Tensors as above (NHWC activations, (Co,3,3,Ci) weight).  Forward: Ci % 32 == 0, Co % 64 == 0; data gradient:
+ * Co % 32 == 0, Ci % 64 == 0; both: W % 8 == 0.  `workspace` holds a zero region (padding source of the LDS-DMA)
+ * and, for the data gradient, the transformed weight; it is (re)written by every call. */
+size_t t2o_conv3x3_fwd_workspace_bytes(int N, int H, int W, int Ci, int Co);
+int t2o_conv3x3_fwd_nhwc(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes,
+                         int N, int H, int W, int Ci, int Co, void* stream);
+size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
+int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream);
 
 /* ---- operator parameter heads for a batch whose samples use different operators: models/operators.py:73-88

@@ -58,6 +58,10 @@ SIGNATURES = {
     't2o_adam_step': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
     't2o_conv3x3_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    't2o_conv3x3_fwd_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
+    't2o_conv3x3_fwd_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    't2o_conv3x3_dgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
+    't2o_conv3x3_dgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

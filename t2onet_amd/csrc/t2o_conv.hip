@@ -255,7 +255,10 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
       lds_wait();                                         // the fragments of this k-pair (read one k-pair ago)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kk + 1 < KP) read_frags(Qc, std::integral_constant<int, kk + 1>{}, std::integral_constant<int, nxt>{});
-      else if (has_next) read_frags(std::integral_constant<int, Q ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
+      else read_frags(std::integral_constant<int, Q ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
+      // (unconditional: after the last stage the values are not used.  Under 'if (has_next)' the compiler merges the two
+      // paths with register copies placed right behind the ds_reads -- it cannot know that an asm ds_read's result
+      // arrives later -- and the copies pick up whatever was in the registers before)
       // image-row ends inside this k-pair (scalar conditions; one k-pair in W/2 has either)
       // (volatile asm inside the branches: as plain selects the compiler turns them into 6 unconditional v_cndmask per k-pair)
       if (wk == 0) {                                      // lanes of pixel 2kk sit at w == 0: kw = 0 reads pixel w-1, outside
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
           __builtin_amdgcn_sched_group_barrier(0x004, kSaluPerGap, 0);      // scalar instructions of the piece
         }
       }
-      if constexpr (kk == KP - 2) { glds_wait(); __syncthreads(); }
+      if constexpr (kk == KP - 2) { __builtin_amdgcn_sched_barrier(0); glds_wait(); lds_wait(); __syncthreads(); }     // (pinned behind the k-pair's MFMAs)
+      if constexpr (kk == KP - 1) lds_wait();             // (see k_conv3x3_fwd: prefetched fragments must have arrived where the compiler may copy them)
       __builtin_amdgcn_sched_barrier(0);
 #ifdef T2O_CONV_DIAG
       { const unsigned long long tn = __builtin_amdgcn_s_memtime(); kp_cycles[kk] += (unsigned)(tn - tprev); tprev = tn; }
@@ -296,6 +300,8 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
   glds_wait();
   __syncthreads();
   if (s0 < s1) read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  lds_wait();
+  __builtin_amdgcn_sched_barrier(0);
   for (int st = s0; st < s1; st += 2) {
     stage(std::integral_constant<int, 0>{}, st);
     if (st + 1 < s1) stage(std::integral_constant<int, 1>{}, st + 1);
@@ -351,6 +357,241 @@ __global__ __launch_bounds__(kConvThreads) void k_conv_wgrad_reduce(const float*
     }
     *reinterpret_cast<float4*>(dw + 4 * i) = s;
   }
+}
+
+// ================================================================================================================
+// FORWARD / DATA GRADIENT   y[p][co] = sum_{kh,kw,ci} x[p + (kh-1) * W + (kw-1)][ci] * w[co][kh][kw][ci]   (zero padding)
+//   One implicit GEMM: M = pixels, N = Co, K = 9 * Ci.  The data gradient is the same sum over dy with the weight
+//   transposed and the taps mirrored (k_conv_flip_weight), so one kernel serves both.
+//   Workgroup = 512 threads = 8 waves (4 along pixels x 2 along channels), one per CU: 256 consecutive pixels x 64
+//   output channels; wave tile 64 x 32 (2 MFMA blocks, 32 accumulator registers).  The two waves of a SIMD belong
+//   to the same workgroup, i.e. have the same age: the matrix pipe alternates between them (two 256-thread
+//   workgroups per CU run one after the other instead -- the older wave wins every arbitration).
+//   K is consumed in stages (kh, 32 input channels): the x tile is 272 pixel rows of 128 bytes (the 256 pixels with
+//   a halo of 8 on both sides, for the image row h + kh - 1: the three kw taps read it shifted by one row), the w
+//   tile 3 x 64 rows of 128 bytes; both double-buffered (118 KiB).
+//   K runs along the 128-byte rows, and an MFMA wants a different row in every lane.  Rows are stored as 8 chunks
+//   of 16 bytes with chunk c of row r at position c ^ ((r >> 1) & 7): lane l of a fragment reads chunk 2G + l / 32
+//   of row l % 32 (+ tile offsets) with ONE conflict-free ds_read_b128 -- four k-steps of that lane (the reduction
+//   order inside a group of 8 channels is 0..3 for lanes 0-31 and 4..7 for lanes 32-63, on both operands).  The
+//   swizzle is applied on the global side of the LDS-DMA (which lane fetches which 16 bytes of a 128-byte line), so
+//   every DMA piece is still 8 full lines.
+//   Padding: a DMA piece (8 pixels, W % 8 == 0: inside one image row) whose input row lies outside the image reads
+//   the zero region (scalar select, as in the weight gradient); a lane whose pixel sits in the first / last column
+//   reads its kw = 0 / kw = 2 fragments from a zero row of the tile -- a loop-invariant address, no masking
+//   instructions.  The loop has no vector-ALU instructions besides the MFMAs.
+struct FwdArgs {
+  const float* x;       // (N,H,W,Ci)
+  const float* w;       // (Co,3,3,Ci)
+  float* y;             // (N,H,W,Co)
+  const float* zero;    // zero region (global), >= 8 * Ci * 4 bytes
+  int N, H, W, Ci, Co;
+  int tiles_p, tiles_n;
+  unsigned long long* stamps;   // diagnostic builds only
+};
+
+constexpr int kFwdThreads = 512;
+constexpr int kFwdPix = 256;          // output pixels per workgroup
+constexpr int kFwdCo = 64;            // output channels per workgroup
+constexpr int kFwdHalo = 8;           // tile rows before the first pixel (1 needed; 8 = one DMA piece)
+constexpr int kFwdXPieces = (kFwdPix + 2 * kFwdHalo) / 8;       // 34 pieces of 8 rows
+constexpr int kFwdXBuf = (kFwdXPieces + 1) * 1024;              // + one piece of zero rows
+constexpr int kFwdWBuf = 3 * kFwdCo * 128;                      // [kw][co][32 ci]
+constexpr int kFwdZeroRow = kFwdXPieces * 8;
+
+__global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char Xs[2][kFwdXBuf];
+  __shared__ __attribute__((aligned(16))) char Ws[2][kFwdWBuf];
+
+  // block -> (pixel tile, channel tile): the channel tiles of one pixel tile are neighbours inside one XCD (they
+  // re-read the same x rows from its L2)
+  const int b = blockIdx.x;
+  const int xcd = b % 8, k8 = b / 8;
+  const int pt = (k8 / a.tiles_n) * 8 + xcd, ct = k8 % a.tiles_n;
+  if (pt >= a.tiles_p) return;
+  const int P = a.N * a.H * a.W, HW = a.H * a.W;
+  const int p0 = pt * kFwdPix, co0 = ct * kFwdCo;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ln = lane & 31, lh = lane >> 5;
+
+  unsigned long long t0 = 0;
+  if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  // ---- LDS-DMA pieces of this wave: x pieces wave, wave + 8, ... (< 34), w pieces (kw = 0..2, co rows 8*wave..)
+  const unsigned lds_x = lds_addr(&Xs[0][0]), lds_w = lds_addr(&Ws[0][0]);
+  constexpr int NXW = (kFwdXPieces + 7) / 8;              // x pieces per wave (the last one only for waves 0, 1)
+  // lane l of a piece writes LDS bytes 16 l .. 16 l + 15 = (row l / 8, position l % 8) and fetches chunk
+  // position ^ swizzle(row); rows of this wave's pieces are 8 * (wave + 8 i) + l / 8: the swizzle does not depend on i
+  const int prow = lane >> 3, ppos = lane & 7;
+  const int pswz = ((wave * 8 + prow) >> 1) & 7;
+  const unsigned lane_x = (unsigned)(prow * a.Ci * 4 + ((ppos ^ pswz) << 4));
+  const unsigned lane_w = (unsigned)(prow * 9 * a.Ci * 4 + ((ppos ^ pswz) << 4));    // (w tile rows 64 kw + 8 wave + l / 8)
+  int mrow[NXW];                                          // (first pixel of the piece) mod (H * W): the image row it is in
+#pragma unroll
+  for (int i = 0; i < NXW; ++i)
+    mrow[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(p0 - kFwdHalo + (wave + 8 * i) * 8 + HW) % (unsigned)HW));
+  const long long xrow = (long long)a.Ci * 4;
+  const char* const x0 = (const char*)a.x + ((long long)p0 - kFwdHalo + wave * 8) * xrow;       // this wave's first piece, kh = 1, ci = 0
+  const char* const w0 = (const char*)a.w + (long long)(co0 + wave * 8) * 9 * xrow;            // its w rows, tap 0, ci = 0
+  const int chunks = a.Ci / 32, stages = 3 * chunks;
+  // stage st = kh * chunks + cc
+  auto dma_piece = [&](auto jc, int buf, int kh, int cc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < NXW) {
+      const int piece = wave + 8 * j;
+      if (piece < kFwdXPieces) {                           // wave-uniform
+        const int q0 = p0 - kFwdHalo + piece * 8;          // output pixel of the piece's first row
+        const int dh = kh - 1;
+        const int lo = dh < 0 ? a.W : 0, span = dh == 0 ? HW : HW - a.W;
+        const bool ok = (unsigned)q0 < (unsigned)P && (unsigned)(mrow[j] - lo) < (unsigned)span;
+        const char* src = x0 + ((long long)j * 64 + (long long)dh * a.W) * xrow + cc * 128;
+        glds16(lane_x, ok ? src : (const char*)a.zero, lds_x + (unsigned)(buf * kFwdXBuf + piece * 1024));
+      }
+    } else {
+      constexpr int kw = j - NXW;
+      const char* src = w0 + (long long)(kh * 3 + kw) * xrow + cc * 128;
+      glds16(lane_w, src, lds_w + (unsigned)(buf * kFwdWBuf + (kw * 8 + wave) * 1024));
+    }
+  };
+  constexpr int NPW = NXW + 3;                             // pieces per wave and stage
+
+  // ---- fragment addresses (loop-invariant byte offsets into Xs / Ws): A = x rows (pixels), B = w rows (channels)
+  unsigned xa[3][2][4], wb[4];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pl = wm * 64 + i * 32 + ln;                // pixel inside the tile
+      const int wcol = (int)((unsigned)(p0 + pl) % (unsigned)a.W);
+      const bool outside = (kw == 0 && wcol == 0) || (kw == 2 && wcol == a.W - 1);
+      const int row = outside ? kFwdZeroRow : kFwdHalo + pl + kw - 1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xa[kw][i][g] = (unsigned)(row * 128 + (((2 * g + lh) ^ ((row >> 1) & 7)) << 4));
+    }
+  {
+    const int row = wn * 32 + ln;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wb[g] = (unsigned)(row * 128 + (((2 * g + lh) ^ ((row >> 1) & 7)) << 4));
+  }
+
+  // the zero rows of both x buffers (never written again)
+  if (wave == 0) {
+    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kFwdXPieces * 1024));
+    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kFwdXBuf + kFwdXPieces * 1024));
+  }
+
+  float4 fa[2][3][2], fb[2][3];
+  auto read_frags = [&](auto Qc, auto gc, auto slotc) {
+    constexpr int Q = decltype(Qc)::value, g = decltype(gc)::value, slot = decltype(slotc)::value;
+    static_for<0, 3>([&](auto kwc) {
+      constexpr int kw = decltype(kwc)::value;
+      // (plain loads, not asm: these values live across the loop's back edge, where the compiler places register
+      // copies -- it has to know that a ds_read's result arrives later.  Address = loop-invariant register + immediate.)
+      fa[slot][kw][0] = *reinterpret_cast<const float4*>(&Xs[Q][0] + xa[kw][0][g]);
+      fa[slot][kw][1] = *reinterpret_cast<const float4*>(&Xs[Q][0] + xa[kw][1][g]);
+      fb[slot][kw] = *reinterpret_cast<const float4*>(&Ws[Q][0] + kw * kFwdCo * 128 + wb[g]);
+    });
+  };
+
+  // One continuous MFMA stream across stages: 4 groups of 8 input channels = 24 MFMAs each.  Groups 0 and 1 carry
+  // the DMA pieces of the next stage (scalar instructions dealt out between the MFMAs), after group 2 the barrier
+  // publishes them, group 3 already prefetches the next stage's first fragments.
+  auto stage = [&](auto Qc, int st) {
+    constexpr int Q = decltype(Qc)::value;
+    const bool has_next = st + 1 < stages;
+    const int nst = has_next ? st + 1 : st;                // (the last stage reloads itself into the idle buffer)
+    const int nkh = nst / chunks, ncc = nst - nkh * chunks;
+    static_for<0, 4>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int cur = g & 1, nxt = cur ^ 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g + 1 < 4) read_frags(Qc, std::integral_constant<int, g + 1>{}, std::integral_constant<int, nxt>{});
+      else read_frags(std::integral_constant<int, Q ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g < 2) {
+        static_for<0, (NPW + 1) / 2>([&](auto jc) {
+          constexpr int j = g * ((NPW + 1) / 2) + decltype(jc)::value;
+          if constexpr (j < NPW) dma_piece(std::integral_constant<int, j>{}, Q ^ 1, nkh, ncc);
+        });
+      }
+      static_for<0, 3>([&](auto kwc) {
+        constexpr int kw = decltype(kwc)::value;
+        static_for<0, 4>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][kw][0][s], fb[cur][kw][s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][kw][1][s], fb[cur][kw][s], acc[1], 0, 0, 0);
+        });
+      });
+      if constexpr (g < 2) {                              // deal the pieces' scalar instructions out between the MFMAs
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+        }
+      }
+      if constexpr (g == 2) { __builtin_amdgcn_sched_barrier(0); glds_wait(); __syncthreads(); }     // (pinned behind the group's MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  static_for<0, NPW>([&](auto jc) { dma_piece(jc, 0, 0, 0); });
+  glds_wait();
+  __syncthreads();
+  read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  for (int st = 0; st < stages; st += 2) {
+    stage(std::integral_constant<int, 0>{}, st);
+    if (st + 1 < stages) stage(std::integral_constant<int, 1>{}, st + 1);
+  }
+
+  if (a.stamps && tid == 0) a.stamps[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+  // C/D layout: column (n = channel) = lane % 32, row (m = pixel) = (reg % 4) + 8 * (reg / 4) + 4 * (lane / 32)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = p0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (p < P) a.y[(size_t)p * a.Co + co0 + wn * 32 + ln] = acc[i][r];
+    }
+}
+
+// wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]: the data gradient is the forward kernel on dy with these weights
+__global__ __launch_bounds__(kConvThreads) void k_conv_flip_weight(const float* w, float* wt, int Co, int Ci) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((size_t)(co0 + r) * 9 + tap) * Ci + ci0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * 9 + (8 - tap)) * Co + co0 + tx] = tile[tx][r];
+}
+
+bool fwd_supported(int N, int H, int W, int Ci, int Co) {
+  return N > 0 && H > 0 && W >= 8 && W % 8 == 0 && Ci >= 32 && Ci % 32 == 0 && Co >= 64 && Co % 64 == 0 &&
+         (size_t)N * H * W + (size_t)H * W + 1024 < ((size_t)1 << 31);
+}
+
+size_t fwd_zero_bytes(int Ci) { return ((size_t)8 * Ci * 4 + 1024 + 255) / 256 * 256; }
+
+int launch_fwd(const float* x, const float* w, float* y, const float* zero, int N, int H, int W, int Ci, int Co, hipStream_t st) {
+  FwdArgs a;
+  a.x = x; a.w = w; a.y = y; a.zero = zero;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  const int P = N * H * W;
+  a.tiles_p = (P + kFwdPix - 1) / kFwdPix;
+  a.tiles_n = Co / kFwdCo;
+  a.stamps = nullptr;
+  const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
+  k_conv3x3_fwd<<<grid, kFwdThreads, 0, st>>>(a);
+  return hipGetLastError() == hipSuccess ? T2O_OK : T2O_ELAUNCH;
 }
 
 struct WgradPlan { int tm, tn, tiles_m, tiles_n, splits, stages_per_split, total_stages; size_t zero_bytes; };
@@ -428,6 +669,45 @@ int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* wor
   k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(
       a.partial, dw, n4, p.splits, n);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3_wgrad launch failed");
+}
+
+size_t t2o_conv3x3_fwd_workspace_bytes(int N, int H, int W, int Ci, int Co) {
+  return fwd_supported(N, H, W, Ci, Co) ? fwd_zero_bytes(Ci) : 0;
+}
+
+int t2o_conv3x3_fwd_nhwc(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes,
+                         int N, int H, int W, int Ci, int Co, void* stream) {
+  if (!x || !w || !y) return set_error(T2O_EINVAL, "conv3x3_fwd: null pointer");
+  if (!fwd_supported(N, H, W, Ci, Co))
+    return set_error(T2O_EUNSUPPORTED, "conv3x3_fwd: Ci must be a multiple of 32, Co of 64, the image width of 8");
+  if (!workspace || workspace_bytes < fwd_zero_bytes(Ci)) return set_error(T2O_EWORKSPACE, "conv3x3_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, fwd_zero_bytes(Ci), st) != hipSuccess)
+    return set_error(T2O_ELAUNCH, "conv3x3_fwd: clearing the zero region failed");
+  const int rc = launch_fwd(x, w, y, (const float*)workspace, N, H, W, Ci, Co, st);
+  return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_fwd launch failed");
+}
+
+size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co) {
+  // the data gradient is a forward convolution of dy (Co channels) to dx (Ci channels)
+  return fwd_supported(N, H, W, Co, Ci) ? fwd_zero_bytes(Co) + sizeof(float) * (size_t)Co * 9 * Ci : 0;
+}
+
+int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                           int N, int H, int W, int Ci, int Co, void* stream) {
+  if (!dy || !w || !dx) return set_error(T2O_EINVAL, "conv3x3_dgrad: null pointer");
+  if (!fwd_supported(N, H, W, Co, Ci) || Co % 32 != 0 || Ci % 32 != 0)
+    return set_error(T2O_EUNSUPPORTED, "conv3x3_dgrad: Co must be a multiple of 32, Ci of 64, the image width of 8");
+  if (!workspace || workspace_bytes < t2o_conv3x3_dgrad_workspace_bytes(N, H, W, Ci, Co))
+    return set_error(T2O_EWORKSPACE, "conv3x3_dgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t zb = fwd_zero_bytes(Co);
+  if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess)
+    return set_error(T2O_ELAUNCH, "conv3x3_dgrad: clearing the zero region failed");
+  float* wt = (float*)((char*)workspace + zb);
+  k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci);
+  const int rc = launch_fwd(dy, wt, dx, (const float*)workspace, N, H, W, Co, Ci, st);
+  return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_dgrad launch failed");
 }
 
 }  // extern "C"

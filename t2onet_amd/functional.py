@@ -5,6 +5,8 @@ Every function requires CUDA(HIP) fp32 tensors and raises otherwise -- there is 
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -382,18 +384,61 @@ def conv3x3_wgrad(x, dy):
     need = lib.t2o_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co)
     if need == 0:
         raise RuntimeError('conv3x3_wgrad: unsupported shape (channels must be multiples of 64, the width a multiple of 4)')
-    key = (x.device.index, _stream(x.device))
-    ws = _conv_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _conv_ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ws = _conv_workspace(x.device, need)
     dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
     rc = lib.t2o_conv3x3_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(x.device))
     _lib.check(rc, 't2o_conv3x3_wgrad_nhwc')
     return dw
 
 
+def _conv_workspace(device, need):
+    key = (device.index, _stream(device))
+    ws = _conv_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _conv_ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
+
+
+def conv3x3_forward(x, weight):
+    """conv2d(x, weight, None, 1, 1) on the fp32 matrix cores (t2o_conv3x3_fwd_nhwc).  x (N,Ci,H,W) and weight
+    (Co,Ci,3,3) channels-last; returns y (N,Co,H,W) channels-last."""
+    _need_gpu(x, weight)
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    x = x.contiguous(memory_format=torch.channels_last)
+    weight = weight.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3_fwd_workspace_bytes(N, H, W, Ci, Co)
+    if need == 0:
+        raise RuntimeError('conv3x3_forward: unsupported shape (Ci % 32, Co % 64, W % 8 must be 0)')
+    ws = _conv_workspace(x.device, need)
+    y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    rc = lib.t2o_conv3x3_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(x.device))
+    _lib.check(rc, 't2o_conv3x3_fwd_nhwc')
+    return y
+
+
+def conv3x3_dgrad(dy, weight):
+    """Data gradient of conv2d(x, weight, None, 1, 1) (t2o_conv3x3_dgrad_nhwc).  dy (N,Co,H,W) and weight (Co,Ci,3,3)
+    channels-last; returns dx (N,Ci,H,W) channels-last."""
+    _need_gpu(dy, weight)
+    N, Co, H, W = dy.shape
+    Ci = weight.shape[1]
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    weight = weight.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3_dgrad_workspace_bytes(N, H, W, Ci, Co)
+    if need == 0:
+        raise RuntimeError('conv3x3_dgrad: unsupported shape (Co % 32, Ci % 64, W % 8 must be 0)')
+    ws = _conv_workspace(dy.device, need)
+    dx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=dy.device).contiguous(memory_format=torch.channels_last)
+    rc = lib.t2o_conv3x3_dgrad_nhwc(_ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(dy.device))
+    _lib.check(rc, 't2o_conv3x3_dgrad_nhwc')
+    return dx
+
+
 def conv3x3_supported(x, weight, stride, padding):
-    """Layers the matrix-core weight gradient takes: channels-last fp32 activations on the GPU, 3x3 / stride 1 /
+    """Layers the matrix-core convolution kernels take: channels-last fp32 activations on the GPU, 3x3 / stride 1 /
     padding 1, channel counts multiples of 64, image width a multiple of 4 (every BasicBlock convolution of the
     encoder except the strided ones, for inputs of 32 pixels and more)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
@@ -401,13 +446,26 @@ def conv3x3_supported(x, weight, stride, padding):
             and weight.shape[1] % 64 == 0 and x.shape[3] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
+# which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
+# 'w' weight gradient, 'f' forward, 'd' data gradient
+_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'w')
+
+
+def _own_direct(x):
+    """The forward / data-gradient kernel wants W % 8 == 0 and full 256-pixel tiles to fill the chip: layers with
+    fewer than 256 workgroups of work (the 8x8 stage at batch 64) stay with the library."""
+    N, _, H, W = x.shape
+    return W % 8 == 0
+
+
 class _Conv3x3Fn(torch.autograd.Function):
-    """conv2d(x, w, 3x3, stride 1, padding 1): forward and data gradient stay library calls (MIOpen), the weight
-    gradient is the hand-written MFMA kernel."""
+    """conv2d(x, w, 3x3, stride 1, padding 1) on the hand-written MFMA kernels (t2o_conv.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        if 'f' in _CONV_OWN and _own_direct(x):
+            return conv3x3_forward(x, weight)
         return torch.nn.functional.conv2d(x, weight, None, 1, 1)
 
     @staticmethod
@@ -416,9 +474,18 @@ class _Conv3x3Fn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
-        dw = conv3x3_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+            if 'd' in _CONV_OWN and _own_direct(x):
+                dx = conv3x3_dgrad(dy, weight)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if 'w' in _CONV_OWN:
+                dw = conv3x3_wgrad(x, dy)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return dx, dw
 
 

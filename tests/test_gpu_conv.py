@@ -1,5 +1,5 @@
-"""Hand-written fp32 MFMA weight gradient of the encoder's 3x3 stride-1 convolutions (t2o_conv.hip) against
-F.conv2d's weight gradient in fp64 (models/actor_resnet.py:27-44)."""
+"""Hand-written fp32 MFMA kernels of the encoder's 3x3 stride-1 convolutions (t2o_conv.hip: forward, data gradient,
+weight gradient) against F.conv2d and its gradients in fp64 (models/actor_resnet.py:27-44)."""
 import numpy as np
 import pytest
 import torch
@@ -42,6 +42,44 @@ def test_wgrad_matches_conv2d_fp64(shape):
     assert torch.equal(dw, T.conv3x3_wgrad(xg, dg))
 
 
+# (N, Ci, Co, H, W), W a multiple of 8: one and several channel tiles, ragged pixel counts (tile tail), one-row images,
+# tiles that start in the middle of an image row, rows longer than a tile, Ci = 32
+DIRECT_SHAPES = [(2, 64, 64, 8, 8), (3, 128, 64, 5, 16), (1, 64, 128, 3, 24), (5, 32, 64, 1, 8), (2, 64, 192, 40, 8),
+                 (1, 128, 128, 2, 264), (3, 64, 64, 9, 32), (2, 256, 64, 12, 16)]
+
+
+@pytest.mark.parametrize('shape', DIRECT_SHAPES)
+def test_forward_matches_conv2d_fp64(shape):
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    x = synth.uniform((N, Ci, H, W), 721, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 722, -1.0, 1.0)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    dev = torch.device('cuda:0')
+    y = T.conv3x3_forward(x.to(dev).contiguous(memory_format=torch.channels_last),
+                          w.to(dev).contiguous(memory_format=torch.channels_last))
+    assert y.shape == (N, Co, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize('shape', DIRECT_SHAPES)
+def test_dgrad_matches_conv2d_fp64(shape):
+    import t2onet_amd.functional as T
+    N, Co, Ci, H, W = shape                     # (the data gradient wants Co % 32 == 0 and Ci % 64 == 0)
+    dy = synth.uniform((N, Co, H, W), 731, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 732, -1.0, 1.0)
+    x64 = torch.zeros(N, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x64, w.double(), None, 1, 1).backward(dy.double())
+    ref = x64.grad
+    dev = torch.device('cuda:0')
+    dx = T.conv3x3_dgrad(dy.to(dev).contiguous(memory_format=torch.channels_last),
+                         w.to(dev).contiguous(memory_format=torch.channels_last))
+    assert dx.shape == (N, Ci, H, W) and dx.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(dx.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
 def test_wgrad_refuses_widths_it_does_not_take():
     """W % 4 != 0 is not a shape of the kernel: the library says so and the autograd wrapper's predicate sends such
     layers to the library convolution."""
@@ -58,9 +96,9 @@ def test_conv3x3_autograd_function_matches_library():
     """The autograd wrapper (library forward + data gradient, own weight gradient) vs plain F.conv2d autograd."""
     import t2onet_amd.functional as T
     dev = torch.device('cuda:0')
-    x = synth.uniform((2, 64, 10, 12), 711, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    x = synth.uniform((2, 64, 10, 16), 711, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
     w = synth.uniform((128, 64, 3, 3), 712, -0.1, 0.1).to(dev).contiguous(memory_format=torch.channels_last)
-    gy = synth.uniform((2, 128, 10, 12), 713, -1.0, 1.0).to(dev)
+    gy = synth.uniform((2, 128, 10, 16), 713, -1.0, 1.0).to(dev)
     x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     assert T.conv3x3_supported(x1, w1, (1, 1), (1, 1))
