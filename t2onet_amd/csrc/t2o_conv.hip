@@ -391,15 +391,18 @@ struct FwdArgs {
 };
 
 constexpr int kFwdThreads = 512;
-constexpr int kFwdPix = 256;          // output pixels per workgroup
 constexpr int kFwdCo = 64;            // output channels per workgroup
 constexpr int kFwdHalo = 8;           // tile rows before the first pixel (1 needed; 8 = one DMA piece)
-constexpr int kFwdXPieces = (kFwdPix + 2 * kFwdHalo) / 8;       // 34 pieces of 8 rows
-constexpr int kFwdXBuf = (kFwdXPieces + 1) * 1024;              // + one piece of zero rows
 constexpr int kFwdWBuf = 3 * kFwdCo * 128;                      // [kw][co][32 ci]
-constexpr int kFwdZeroRow = kFwdXPieces * 8;
 
+// kBM: MFMA blocks per wave along the pixels; the workgroup takes 128 * kBM consecutive pixels (2: the normal tile;
+// 1: layers whose 256-pixel tiles would leave CUs idle)
+template <int kBM>
 __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
+  constexpr int kFwdPix = 128 * kBM;                              // output pixels per workgroup
+  constexpr int kFwdXPieces = (kFwdPix + 2 * kFwdHalo) / 8;       // pieces of 8 rows (34 / 18)
+  constexpr int kFwdXBuf = (kFwdXPieces + 1) * 1024;              // + one piece of zero rows
+  constexpr int kFwdZeroRow = kFwdXPieces * 8;
   __shared__ __attribute__((aligned(16))) char Xs[2][kFwdXBuf];
   __shared__ __attribute__((aligned(16))) char Ws[2][kFwdWBuf];
 
@@ -419,9 +422,9 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   unsigned long long t0 = 0;
   if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
 
-  f32x16 acc[2];
+  f32x16 acc[kBM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kBM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
@@ -464,12 +467,12 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   constexpr int NPW = NXW + 3;                             // pieces per wave and stage
 
   // ---- fragment addresses (loop-invariant byte offsets into Xs / Ws): A = x rows (pixels), B = w rows (channels)
-  unsigned xa[3][2][4], wb[4];
+  unsigned xa[3][kBM][4], wb[4];
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pl = wm * 64 + i * 32 + ln;                // pixel inside the tile
+    for (int i = 0; i < kBM; ++i) {
+      const int pl = wm * 32 * kBM + i * 32 + ln;          // pixel inside the tile
       const int wcol = (int)((unsigned)(p0 + pl) % (unsigned)a.W);
       const bool outside = (kw == 0 && wcol == 0) || (kw == 2 && wcol == a.W - 1);
       const int row = outside ? kFwdZeroRow : kFwdHalo + pl + kw - 1;
@@ -488,15 +491,15 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
     glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kFwdXBuf + kFwdXPieces * 1024));
   }
 
-  float4 fa[2][3][2], fb[2][3];
+  float4 fa[2][3][kBM], fb[2][3];
   auto read_frags = [&](auto Qc, auto gc, auto slotc) {
     constexpr int Q = decltype(Qc)::value, g = decltype(gc)::value, slot = decltype(slotc)::value;
     static_for<0, 3>([&](auto kwc) {
       constexpr int kw = decltype(kwc)::value;
       // (plain loads, not asm: these values live across the loop's back edge, where the compiler places register
       // copies -- it has to know that a ds_read's result arrives later.  Address = loop-invariant register + immediate.)
-      fa[slot][kw][0] = *reinterpret_cast<const float4*>(&Xs[Q][0] + xa[kw][0][g]);
-      fa[slot][kw][1] = *reinterpret_cast<const float4*>(&Xs[Q][0] + xa[kw][1][g]);
+#pragma unroll
+      for (int i = 0; i < kBM; ++i) fa[slot][kw][i] = *reinterpret_cast<const float4*>(&Xs[Q][0] + xa[kw][i][g]);
       fb[slot][kw] = *reinterpret_cast<const float4*>(&Ws[Q][0] + kw * kFwdCo * 128 + wb[g]);
     });
   };
@@ -504,9 +507,16 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   // One continuous MFMA stream across stages: 4 groups of 8 input channels = 24 MFMAs each.  Groups 0 and 1 carry
   // the DMA pieces of the next stage (scalar instructions dealt out between the MFMAs), after group 2 the barrier
   // publishes them, group 3 already prefetches the next stage's first fragments.
+#ifdef T2O_CONV_DIAG
+  unsigned g_cycles[4] = {};
+  unsigned long long t_loop = 0;
+#endif
   auto stage = [&](auto Qc, int st) {
     constexpr int Q = decltype(Qc)::value;
     const bool has_next = st + 1 < stages;
+#ifdef T2O_CONV_DIAG
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     const int nst = has_next ? st + 1 : st;                // (the last stage reloads itself into the idle buffer)
     const int nkh = nst / chunks, ncc = nst - nkh * chunks;
     static_for<0, 4>([&](auto gc) {
@@ -526,19 +536,23 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
         constexpr int kw = decltype(kwc)::value;
         static_for<0, 4>([&](auto sc) {
           constexpr int s = decltype(sc)::value;
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][kw][0][s], fb[cur][kw][s], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][kw][1][s], fb[cur][kw][s], acc[1], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < kBM; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][kw][i][s], fb[cur][kw][s], acc[i], 0, 0, 0);
         });
       });
       if constexpr (g < 2) {                              // deal the pieces' scalar instructions out between the MFMAs
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
+        for (int q = 0; q < 12 * kBM; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
         }
       }
       if constexpr (g == 2) { __builtin_amdgcn_sched_barrier(0); glds_wait(); __syncthreads(); }     // (pinned behind the group's MFMAs)
       __builtin_amdgcn_sched_barrier(0);
+#ifdef T2O_CONV_DIAG
+      { const unsigned long long tn = __builtin_amdgcn_s_memtime(); g_cycles[g] += (unsigned)(tn - tprev); tprev = tn; }
+#endif
     });
   };
 
@@ -546,20 +560,33 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   glds_wait();
   __syncthreads();
   read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+#ifdef T2O_CONV_DIAG
+  t_loop = __builtin_amdgcn_s_memtime();
+#endif
   for (int st = 0; st < stages; st += 2) {
     stage(std::integral_constant<int, 0>{}, st);
     if (st + 1 < stages) stage(std::integral_constant<int, 1>{}, st + 1);
   }
+#ifdef T2O_CONV_DIAG
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+#endif
 
-  if (a.stamps && tid == 0) a.stamps[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
   // C/D layout: column (n = channel) = lane % 32, row (m = pixel) = (reg % 4) + 8 * (reg / 4) + 4 * (lane / 32)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kBM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int p = p0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int p = p0 + wm * 32 * kBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (p < P) a.y[(size_t)p * a.Co + co0 + wn * 32 + ln] = acc[i][r];
     }
+#ifdef T2O_CONV_DIAG
+  if (a.stamps && tid == 0) {          // [start, prologue, loop, g0..g3, epilogue issue] per workgroup
+    unsigned long long* q = a.stamps + (size_t)blockIdx.x * 8;
+    q[0] = t0; q[1] = t_loop - t0; q[2] = t_end - t_loop;
+    for (int g = 0; g < 4; ++g) q[3 + g] = g_cycles[g];
+    q[7] = __builtin_amdgcn_s_memtime() - t_end;
+  }
+#endif
 }
 
 // wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]: the data gradient is the forward kernel on dy with these weights
@@ -574,6 +601,11 @@ __global__ __launch_bounds__(kConvThreads) void k_conv_flip_weight(const float* 
   for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * 9 + (8 - tap)) * Co + co0 + tx] = tile[tx][r];
 }
 
+int conv_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 bool fwd_supported(int N, int H, int W, int Ci, int Co) {
   return N > 0 && H > 0 && W >= 8 && W % 8 == 0 && Ci >= 32 && Ci % 32 == 0 && Co >= 64 && Co % 64 == 0 &&
          (size_t)N * H * W + (size_t)H * W + 1024 < ((size_t)1 << 31);
@@ -586,20 +618,20 @@ int launch_fwd(const float* x, const float* w, float* y, const float* zero, int 
   a.x = x; a.w = w; a.y = y; a.zero = zero;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   const int P = N * H * W;
-  a.tiles_p = (P + kFwdPix - 1) / kFwdPix;
   a.tiles_n = Co / kFwdCo;
+  // 256-pixel tiles unless they would fill less than one round of workgroups (one per CU) that 128-pixel tiles fill better
+  static const int force_bm = conv_env("T2O_FWD_BM", 0);
+  const int wg256 = ((P + 255) / 256) * a.tiles_n;
+  const int bm = force_bm == 1 || force_bm == 2 ? force_bm : (wg256 < 256 ? 1 : 2);
+  a.tiles_p = (P + 128 * bm - 1) / (128 * bm);
   a.stamps = nullptr;
   const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
-  k_conv3x3_fwd<<<grid, kFwdThreads, 0, st>>>(a);
+  if (bm == 1) k_conv3x3_fwd<1><<<grid, kFwdThreads, 0, st>>>(a);
+  else k_conv3x3_fwd<2><<<grid, kFwdThreads, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : T2O_ELAUNCH;
 }
 
 struct WgradPlan { int tm, tn, tiles_m, tiles_n, splits, stages_per_split, total_stages; size_t zero_bytes; };
-
-int conv_env(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 
 bool wgrad_supported(int N, int H, int W, int Ci, int Co) {
   return N > 0 && H > 0 && W >= 4 && W % 4 == 0 && Ci >= 64 && Co >= 64 && Ci % 64 == 0 && Co % 64 == 0 &&

@@ -385,7 +385,7 @@ def conv3x3_wgrad(x, dy):
     if need == 0:
         raise RuntimeError('conv3x3_wgrad: unsupported shape (channels must be multiples of 64, the width a multiple of 4)')
     ws = _conv_workspace(x.device, need)
-    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     rc = lib.t2o_conv3x3_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(x.device))
     _lib.check(rc, 't2o_conv3x3_wgrad_nhwc')
     return dw
@@ -412,7 +412,7 @@ def conv3x3_forward(x, weight):
     if need == 0:
         raise RuntimeError('conv3x3_forward: unsupported shape (Ci % 32, Co % 64, W % 8 must be 0)')
     ws = _conv_workspace(x.device, need)
-    y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     rc = lib.t2o_conv3x3_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(x.device))
     _lib.check(rc, 't2o_conv3x3_fwd_nhwc')
     return y
@@ -431,7 +431,7 @@ def conv3x3_dgrad(dy, weight):
     if need == 0:
         raise RuntimeError('conv3x3_dgrad: unsupported shape (Co % 32, Ci % 64, W % 8 must be 0)')
     ws = _conv_workspace(dy.device, need)
-    dx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=dy.device).contiguous(memory_format=torch.channels_last)
+    dx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
     rc = lib.t2o_conv3x3_dgrad_nhwc(_ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(dy.device))
     _lib.check(rc, 't2o_conv3x3_dgrad_nhwc')
     return dx
@@ -448,14 +448,12 @@ def conv3x3_supported(x, weight, stride, padding):
 
 # which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
 # 'w' weight gradient, 'f' forward, 'd' data gradient
-_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'w')
+_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfd')
 
 
 def _own_direct(x):
-    """The forward / data-gradient kernel wants W % 8 == 0 and full 256-pixel tiles to fill the chip: layers with
-    fewer than 256 workgroups of work (the 8x8 stage at batch 64) stay with the library."""
-    N, _, H, W = x.shape
-    return W % 8 == 0
+    """The forward / data-gradient kernel wants W % 8 == 0 (a DMA piece of 8 pixels inside one image row)."""
+    return x.shape[3] % 8 == 0
 
 
 class _Conv3x3Fn(torch.autograd.Function):
