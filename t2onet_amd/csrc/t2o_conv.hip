@@ -419,8 +419,8 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int ln = lane & 31, lh = lane >> 5;
 
-  unsigned long long t0 = 0;
-  if (a.stamps) t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long t0 = 0, r0 = 0;
+  if (a.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
   f32x16 acc[kBM];
 #pragma unroll
@@ -465,6 +465,10 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
     }
   };
   constexpr int NPW = NXW + 3;                             // pieces per wave and stage
+#ifndef T2O_FWD_DMA_GROUPS
+#define T2O_FWD_DMA_GROUPS 2
+#endif
+  constexpr int kDmaGroups = T2O_FWD_DMA_GROUPS;           // the first groups of a stage carry the next stage's DMA
 
   // ---- fragment addresses (loop-invariant byte offsets into Xs / Ws): A = x rows (pixels), B = w rows (channels)
   unsigned xa[3][kBM][4], wb[4];
@@ -526,9 +530,9 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
       if constexpr (g + 1 < 4) read_frags(Qc, std::integral_constant<int, g + 1>{}, std::integral_constant<int, nxt>{});
       else read_frags(std::integral_constant<int, Q ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (g < 2) {
-        static_for<0, (NPW + 1) / 2>([&](auto jc) {
-          constexpr int j = g * ((NPW + 1) / 2) + decltype(jc)::value;
+      if constexpr (g < kDmaGroups) {
+        static_for<0, (NPW + kDmaGroups - 1) / kDmaGroups>([&](auto jc) {
+          constexpr int j = g * ((NPW + kDmaGroups - 1) / kDmaGroups) + decltype(jc)::value;
           if constexpr (j < NPW) dma_piece(std::integral_constant<int, j>{}, Q ^ 1, nkh, ncc);
         });
       }
@@ -541,11 +545,11 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][kw][i][s], fb[cur][kw][s], acc[i], 0, 0, 0);
         });
       });
-      if constexpr (g < 2) {                              // deal the pieces' scalar instructions out between the MFMAs
+      if constexpr (g < kDmaGroups) {                     // deal the pieces' scalar instructions out between the MFMAs
 #pragma unroll
         for (int q = 0; q < 12 * kBM; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, (NPW * 16 / kDmaGroups + 12 * kBM - 1) / (12 * kBM), 0);
         }
       }
       if constexpr (g == 2) { __builtin_amdgcn_sched_barrier(0); glds_wait(); __syncthreads(); }     // (pinned behind the group's MFMAs)
@@ -582,8 +586,9 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 #ifdef T2O_CONV_DIAG
   if (a.stamps && tid == 0) {          // [start, prologue, loop, g0..g3, epilogue issue] per workgroup
     unsigned long long* q = a.stamps + (size_t)blockIdx.x * 8;
-    q[0] = t0; q[1] = t_loop - t0; q[2] = t_end - t_loop;
-    for (int g = 0; g < 4; ++g) q[3 + g] = g_cycles[g];
+    q[0] = r0; q[1] = t_loop - t0; q[2] = t_end - t_loop;
+    for (int g = 0; g < 3; ++g) q[3 + g] = g_cycles[g];
+    q[6] = __builtin_amdgcn_s_memrealtime();             // (100 MHz, one counter for the chip)
     q[7] = __builtin_amdgcn_s_memtime() - t_end;
   }
 #endif

@@ -38,18 +38,23 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> s((size_t)grid * 8);
   hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
   unsigned long long tmin = ~0ull, tmax = 0;
-  std::vector<double> pro, loop, epi, g[4];
+  std::vector<double> pro, loop, epi, g[4], starts, ends;
   const int stages = 3 * C / 32;
   for (unsigned b = 0; b < grid; ++b) {
     const unsigned long long* q = &s[(size_t)b * 8];
     if (!q[2]) continue;
-    tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[0] + q[1] + q[2] + q[7]);
+    tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[6]); starts.push_back((double)q[0]); ends.push_back((double)q[6]);
     pro.push_back((double)q[1]); loop.push_back((double)q[2]); epi.push_back((double)q[7]);
-    for (int k = 0; k < 4; ++k) g[k].push_back((double)q[3 + k] / stages);
+    for (int k = 0; k < 3; ++k) g[k].push_back((double)q[3 + k] / stages);
+    g[3].push_back(0);
   }
   auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
   const double mfma_wave = (double)stages * 48 * bm * 64;
-  printf("C=%d %dx%d: kernel %.1f us, %u workgroups (%zu ran), %d stages; first start -> last end %llu cycles\n", C, H, W, ms * 1e3, grid, pro.size(), stages, tmax - tmin);
+  std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+  auto at = [&](std::vector<double>& v, double q) { return (v[(size_t)(q * (v.size() - 1))] - (double)tmin) * 0.01; };
+  printf("C=%d %dx%d: kernel %.1f us, %u workgroups (%zu ran), %d stages\n", C, H, W, ms * 1e3, grid, pro.size(), stages);
+  printf("  workgroup starts after the first one (us): 10%% %.1f  50%% %.1f  90%% %.1f  last %.1f;  ends: first %.1f  10%% %.1f  50%% %.1f  90%% %.1f  last %.1f\n",
+         at(starts, 0.1), at(starts, 0.5), at(starts, 0.9), at(starts, 1.0), at(ends, 0.0), at(ends, 0.1), at(ends, 0.5), at(ends, 0.9), at(ends, 1.0));
   printf("  per workgroup (median): prologue %.0f, main loop %.0f (MFMA cycles per wave %.0f: two waves per SIMD -> %.0f %% of the loop), epilogue issue %.0f cycles\n",
          med(pro), med(loop), mfma_wave, 100.0 * 2 * mfma_wave / med(loop), med(epi));
   printf("  cycles per group position (24 MFMAs = 1536 pipe cycles; x2 waves = 3072): %.0f %.0f %.0f %.0f\n", med(g[0]), med(g[1]), med(g[2]), med(g[3]));

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512, 1) void k(unsigned long long* out, int iters, 
     if constexpr (CLS == 3) { REP32(asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(z) : "v"(z));) }
     if constexpr (CLS == 4) { REP32(asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(r0) : "v"(x), "v"(y) : "vcc");) }
     if constexpr (CLS == 5) { REP32(asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(r0) : "v"(x));) }
-    if constexpr (CLS == 6) { REP32(asm volatile("s_add_u32 %0, %0, 1" : "+s"(r0));) }
+    if constexpr (CLS == 6) { REP32(asm volatile("s_add_u32 %0, %0, 1" : "+s"(r0) :: "scc");) }
     if constexpr (CLS == 7) { REP32(asm volatile("s_mul_i32 %0, %0, 3" : "+s"(r0));) }
     if constexpr (CLS == 8) { REP32(asm volatile("v_cmp_le_u32 vcc, %0, %1\n\ts_and_b64 %2, vcc, exec" :: "v"(x), "v"(y), "s"(0ull) : "vcc");) }
     if constexpr (CLS == 9) { REP32(asm volatile("v_rcp_iflag_f32 %0, %1" : "=v"(r0) : "v"(x));) }
