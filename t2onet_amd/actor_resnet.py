@@ -14,15 +14,16 @@ from . import functional as T
 
 
 _FUSED = os.environ.get('T2O_FUSED_BN', '1') != '0'      # 0: PyTorch's batch norm everywhere (A/B timing)
-# The hand-written MFMA weight gradient (t2o_conv3x3_wgrad_nhwc) for the 3x3 stride-1 convolutions in channels-last
-# mode: deterministic (fixed-order split-K; the library's kernel adds atomically) and 1.0-1.25x the library's speed
-# on MI355X (profiles/r02_wgrad_*.txt); the train step 65.2 -> 62.5 ms.  0: the library's weight gradient (A/B).
+# The hand-written MFMA kernels (t2o_conv.hip: forward, data gradient, weight gradient) for the 3x3 stride-1 convolutions
+# in channels-last mode: 1.06-1.25x the library's kernels on MI355X (profiles/r02d_conv_*.txt), the weight gradient
+# deterministic (fixed-order split-K; the library's adds atomically); the train step 65.2 -> 60.0 ms.
+# T2O_OWN_WGRAD=0: library calls for all three (A/B); T2O_OWN_CONV=w|f|d...: a subset (functional._CONV_OWN).
 _OWN_WGRAD = os.environ.get('T2O_OWN_WGRAD', '1') != '0'
 
 
 def _conv(conv, x):
     if _OWN_WGRAD and conv.bias is None and T.conv3x3_supported(x, conv.weight, conv.stride, conv.padding) \
-            and conv.weight.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled():
+            and conv.weight.is_contiguous(memory_format=torch.channels_last):
         return T.conv3x3(x, conv.weight)
     return conv(x)
 
