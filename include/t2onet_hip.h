@@ -221,6 +221,15 @@ size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream);
 
+/* ---- data gradient of the encoder's STRIDE-2 3x3 convolutions (the first convolution of each stage,
+ * models/actor_resnet.py:32-36 with stride 2; replaces torch.ops.aten.convolution_backward(..., output_mask [1,0,0])):
+ *   dx[n][i][j][ci] = sum_{kh,kw,co} dy[n][(i+1-kh)/2][(j+1-kw)/2][co] * w[co][kh][kw][ci]   over the taps for which
+ *   both quotients are integers inside the (Ho, Wo) grid.   dy (N,Ho,Wo,Co), w (Co,3,3,Ci), dx (N,2Ho,2Wo,Ci), NHWC.
+ * Co % 32 == 0, Ci % 64 == 0, Wo % 8 == 0.  `workspace`: zero region + the transposed weight, rewritten per call. */
+size_t t2o_conv3x3s2_dgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co);
+int t2o_conv3x3s2_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                             int N, int Ho, int Wo, int Ci, int Co, void* stream);
+
 /* ---- operator parameter heads for a batch whose samples use different operators: models/operators.py:73-88
  * (param = op_param_regressor(fc2(LeakyReLU_0.01(fc1(features))))) as called per operator group by
  * models/actor.py:244-255.  op_id (B) device int32: executor index of each sample, < 0 or 4 -> no head, zeros.

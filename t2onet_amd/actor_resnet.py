@@ -25,6 +25,9 @@ def _conv(conv, x):
     if _OWN_WGRAD and conv.bias is None and T.conv3x3_supported(x, conv.weight, conv.stride, conv.padding) \
             and conv.weight.is_contiguous(memory_format=torch.channels_last):
         return T.conv3x3(x, conv.weight)
+    if _OWN_WGRAD and conv.bias is None and T.conv3x3s2_supported(x, conv.weight, conv.stride, conv.padding) \
+            and conv.weight.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled() and x.requires_grad:
+        return T.conv3x3s2(x, conv.weight)
     return conv(x)
 
 

@@ -594,8 +594,9 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 #endif
 }
 
-// wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]: the data gradient is the forward kernel on dy with these weights
-__global__ __launch_bounds__(kConvThreads) void k_conv_flip_weight(const float* w, float* wt, int Co, int Ci) {
+// wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci] (flip: the stride-1 data gradient is the forward kernel on dy with these
+// weights) or wt[ci][kh][kw][co] = w[co][kh][kw][ci] (no flip: the stride-2 data gradient indexes taps itself)
+__global__ __launch_bounds__(kConvThreads) void k_conv_flip_weight(const float* w, float* wt, int Co, int Ci, int flip) {
   __shared__ float tile[32][33];
   const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
@@ -603,7 +604,188 @@ __global__ __launch_bounds__(kConvThreads) void k_conv_flip_weight(const float* 
   for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((size_t)(co0 + r) * 9 + tap) * Ci + ci0 + tx];
   __syncthreads();
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * 9 + (8 - tap)) * Co + co0 + tx] = tile[tx][r];
+  for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * 9 + (flip ? 8 - tap : tap)) * Co + co0 + tx] = tile[tx][r];
+}
+
+// ================================================================================================================
+// DATA GRADIENT OF THE STRIDE-2 CONVOLUTIONS (the first convolution of every encoder stage, models/actor_resnet.py:32-36)
+//   y[n][a][b][co] = sum x[n][2a+kh-1][2b+kw-1][ci] w[co][kh][kw][ci]   ==>   with i = 2 alpha + ph, j = 2 beta + pw:
+//   dx[n][i][j][ci] = sum over the taps with kh = ph + 1 (mod 2), kw = pw + 1 (mod 2) of
+//                     dy[n][alpha + (kh == 0)][beta + (kw == 0)][co] * w[co][kh][kw][ci]
+//   i.e. every pixel (alpha, beta) of the dy grid produces the 2 x 2 block of dx pixels above it from its own row
+//   and the next one, its own column and the next one: 1 + 2 + 2 + 4 = 9 taps for 4 outputs, no multiplications by
+//   inserted zeros.  Same machinery as k_conv3x3_fwd (x := dy, reduction over co, weights transposed to
+//   (Ci,3,3,Co)): a workgroup of 8 waves takes 128 consecutive dy pixels x 64 input channels and keeps FOUR
+//   accumulators per wave (one per output parity).  Stages alternate between the dy rows alpha (6 taps: kh = 1, 2)
+//   and alpha + 1 (3 taps: kh = 0) of a 32-channel chunk -- which is also the double buffering.
+struct Dgrad2Args {
+  const float* dy;      // (N,Ho,Wo,Co)
+  const float* wt;      // (Ci,3,3,Co)
+  float* dx;            // (N,2Ho,2Wo,Ci)
+  const float* zero;
+  int N, Ho, Wo, Ci, Co;
+  int tiles_p, tiles_n;
+};
+
+__global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a) {
+  constexpr int kPix = 128;
+  constexpr int kXPieces = (kPix + 2 * kFwdHalo) / 8;            // 18
+  constexpr int kXBuf = (kXPieces + 1) * 1024;                   // + zero rows
+  constexpr int kZeroRow = kXPieces * 8;
+  constexpr int kTapBytes = 64 * 128;                            // one tap of the w tile: 64 output channels x 32 reduction channels
+  __shared__ __attribute__((aligned(16))) char Xs[2][kXBuf];     // [0]: rows alpha (stage A), [1]: rows alpha + 1 (stage B)
+  __shared__ __attribute__((aligned(16))) char WsA[6 * kTapBytes];
+  __shared__ __attribute__((aligned(16))) char WsB[3 * kTapBytes];
+
+  const int b = blockIdx.x;
+  const int xcd = b % 8, k8 = b / 8;
+  const int pt = (k8 / a.tiles_n) * 8 + xcd, ct = k8 % a.tiles_n;
+  if (pt >= a.tiles_p) return;
+  const int P = a.N * a.Ho * a.Wo, HW = a.Ho * a.Wo;
+  const int p0 = pt * kPix, n0 = ct * 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ln = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];                                       // [ph][pw]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c >> 1][c & 1][r] = 0.0f;
+
+  const unsigned lds_x = lds_addr(&Xs[0][0]), lds_wa = lds_addr(&WsA[0]), lds_wb = lds_addr(&WsB[0]);
+  constexpr int NXW = (kXPieces + 7) / 8;                 // 3 (the last one only for waves 0, 1)
+  const int prow = lane >> 3, ppos = lane & 7;
+  const int pswz = ((wave * 8 + prow) >> 1) & 7;
+  const unsigned lane_x = (unsigned)(prow * a.Co * 4 + ((ppos ^ pswz) << 4));
+  const unsigned lane_w = (unsigned)(prow * 9 * a.Co * 4 + ((ppos ^ pswz) << 4));
+  int mrow[NXW];
+#pragma unroll
+  for (int i = 0; i < NXW; ++i)
+    mrow[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(p0 - kFwdHalo + (wave + 8 * i) * 8 + HW) % (unsigned)HW));
+  const long long xrow = (long long)a.Co * 4;
+  const char* const x0 = (const char*)a.dy + ((long long)p0 - kFwdHalo + wave * 8) * xrow;
+  const char* const w0 = (const char*)a.wt + (long long)(n0 + wave * 8) * 9 * xrow;
+  const int chunks = a.Co / 32;
+  // pieces of a stage's data: j < NXW: dy rows (dr = 0 for stage A, 1 for stage B); then its taps' weight rows
+  auto dma_piece = [&](auto typec, auto jc, int cc) {
+    constexpr int type = decltype(typec)::value, j = decltype(jc)::value;      // type 0 = A, 1 = B
+    if constexpr (j < NXW) {
+      const int piece = wave + 8 * j;
+      if (piece < kXPieces) {                              // wave-uniform
+        const int q0 = p0 - kFwdHalo + piece * 8;
+        const bool ok = (unsigned)q0 < (unsigned)P && (type == 0 || mrow[j] < HW - a.Wo);      // B: the row alpha + 1 exists
+        const char* src = x0 + ((long long)j * 64 + (long long)type * a.Wo) * xrow + cc * 128;
+        glds16(lane_x, ok ? src : (const char*)a.zero, lds_x + (unsigned)(type * kXBuf + piece * 1024));
+      }
+    } else {
+      constexpr int t = j - NXW;                           // A: taps (kh = 1 + t / 3, kw = t % 3); B: (kh = 0, kw = t)
+      constexpr int tap = type == 0 ? 3 + t : t;           // kh * 3 + kw
+      const char* src = w0 + (long long)tap * xrow + cc * 128;
+      glds16(lane_w, src, (type == 0 ? lds_wa : lds_wb) + (unsigned)((t * 8 + wave) * 1024));
+    }
+  };
+  constexpr int NPA = NXW + 6, NPB = NXW + 3;             // pieces per wave of a stage A / B
+
+  // fragment addresses: dy rows for the column shifts dc = 0, 1 (dc = 1 beyond the last column: zero row); w rows
+  unsigned xa[2][4], wb[4];
+  {
+    const int pl = wm * 32 + ln;
+    const int bcol = (int)((unsigned)(p0 + pl) % (unsigned)a.Wo);
+#pragma unroll
+    for (int dc = 0; dc < 2; ++dc) {
+      const int row = (dc == 1 && bcol == a.Wo - 1) ? kZeroRow : kFwdHalo + pl + dc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xa[dc][g] = (unsigned)(row * 128 + (((2 * g + lh) ^ ((row >> 1) & 7)) << 4));
+    }
+    const int row = wn * 32 + ln;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wb[g] = (unsigned)(row * 128 + (((2 * g + lh) ^ ((row >> 1) & 7)) << 4));
+  }
+  if (wave == 0) {
+    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kXPieces * 1024));
+    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kXBuf + kXPieces * 1024));
+  }
+
+  float4 fa[2][2], fb[2][6];
+  auto read_frags = [&](auto typec, auto gc, auto slotc) {
+    constexpr int type = decltype(typec)::value, g = decltype(gc)::value, slot = decltype(slotc)::value;
+    fa[slot][0] = *reinterpret_cast<const float4*>(&Xs[type][0] + xa[0][g]);
+    fa[slot][1] = *reinterpret_cast<const float4*>(&Xs[type][0] + xa[1][g]);
+    static_for<0, (type == 0 ? 6 : 3)>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      fb[slot][t] = *reinterpret_cast<const float4*>((type == 0 ? &WsA[0] : &WsB[0]) + t * kTapBytes + wb[g]);
+    });
+  };
+
+  // one stage = 4 groups of 8 reduction channels; the next stage's data is loaded during groups 0 and 1
+  auto stage = [&](auto typec, int cc, bool more) {
+    constexpr int type = decltype(typec)::value;
+    constexpr int NT = type == 0 ? 6 : 3;
+    constexpr int NPN = type == 0 ? NPB : NPA;             // pieces of the NEXT stage (the other type)
+    const int ncc = type == 0 ? cc : (more ? cc + 1 : cc);
+    static_for<0, 4>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int cur = g & 1, nxt = cur ^ 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g + 1 < 4) read_frags(typec, std::integral_constant<int, g + 1>{}, std::integral_constant<int, nxt>{});
+      else read_frags(std::integral_constant<int, type ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g < 2) {
+        static_for<0, (NPN + 1) / 2>([&](auto jc) {
+          constexpr int j = g * ((NPN + 1) / 2) + decltype(jc)::value;
+          if constexpr (j < NPN) dma_piece(std::integral_constant<int, type ^ 1>{}, std::integral_constant<int, j>{}, ncc);
+        });
+      }
+      static_for<0, 4>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        static_for<0, NT>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int kh = type == 0 ? 1 + t / 3 : 0, kw = t % 3;
+          constexpr int ph = kh != 1, pw = kw != 1, dc = kw == 0;
+          acc[ph][pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][dc][s], fb[cur][t][s], acc[ph][pw], 0, 0, 0);
+        });
+      });
+      if constexpr (g < 2) {
+#pragma unroll
+        for (int q = 0; q < 4 * NT; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, (NPN * 16 / 2 + 4 * NT - 1) / (4 * NT), 0);
+        }
+      }
+      if constexpr (g == 2) { __builtin_amdgcn_sched_barrier(0); glds_wait(); __syncthreads(); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  static_for<0, NPA>([&](auto jc) { dma_piece(std::integral_constant<int, 0>{}, jc, 0); });
+  glds_wait();
+  __syncthreads();
+  read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  for (int cc = 0; cc < chunks; ++cc) {
+    stage(std::integral_constant<int, 0>{}, cc, true);
+    stage(std::integral_constant<int, 1>{}, cc, cc + 1 < chunks);
+  }
+
+  // dx pixel of dy pixel p = (t, beta), t = p / Wo = n * Ho + alpha:  (2 t + ph) * 2 Wo + 2 beta + pw
+  //                                                                 = 2 p + 2 Wo (t + ph) + pw
+  const int pbase = p0 + wm * 32 + 4 * lh;
+  const int tbase = (int)((unsigned)pbase / (unsigned)a.Wo), bbase = pbase - tbase * a.Wo;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int off = (r & 3) + 8 * (r >> 2);
+    const int p = pbase + off, bb = bbase + off;
+    const int t = tbase + (bb >= a.Wo) + (bb >= 2 * a.Wo) + (bb >= 3 * a.Wo) + (bb >= 4 * a.Wo);      // off <= 27, Wo >= 8
+    if (p < P) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ph = c >> 1, pw = c & 1;
+        const size_t o = (size_t)2 * p + (size_t)2 * a.Wo * (t + ph) + pw;
+        a.dx[o * a.Ci + n0 + wn * 32 + ln] = acc[ph][pw][r];
+      }
+    }
+  }
 }
 
 int conv_env(const char* name, int dflt) {
@@ -742,9 +924,36 @@ int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* wor
   if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess)
     return set_error(T2O_ELAUNCH, "conv3x3_dgrad: clearing the zero region failed");
   float* wt = (float*)((char*)workspace + zb);
-  k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci);
+  k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci, 1);
   const int rc = launch_fwd(dy, wt, dx, (const float*)workspace, N, H, W, Co, Ci, st);
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_dgrad launch failed");
+}
+
+size_t t2o_conv3x3s2_dgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {
+  return fwd_supported(N, Ho, Wo, Co, Ci) ? fwd_zero_bytes(Co) + sizeof(float) * (size_t)Co * 9 * Ci : 0;
+}
+
+int t2o_conv3x3s2_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                             int N, int Ho, int Wo, int Ci, int Co, void* stream) {
+  if (!dy || !w || !dx) return set_error(T2O_EINVAL, "conv3x3s2_dgrad: null pointer");
+  if (!fwd_supported(N, Ho, Wo, Co, Ci) || (size_t)N * Ho * Wo * 4 + 1024 >= ((size_t)1 << 31))
+    return set_error(T2O_EUNSUPPORTED, "conv3x3s2_dgrad: Co must be a multiple of 32, Ci of 64, the output-gradient width of 8");
+  if (!workspace || workspace_bytes < t2o_conv3x3s2_dgrad_workspace_bytes(N, Ho, Wo, Ci, Co))
+    return set_error(T2O_EWORKSPACE, "conv3x3s2_dgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t zb = fwd_zero_bytes(Co);
+  if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess)
+    return set_error(T2O_ELAUNCH, "conv3x3s2_dgrad: clearing the zero region failed");
+  float* wt = (float*)((char*)workspace + zb);
+  k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci, 0);
+  Dgrad2Args a;
+  a.dy = dy; a.wt = wt; a.dx = dx; a.zero = (const float*)workspace;
+  a.N = N; a.Ho = Ho; a.Wo = Wo; a.Ci = Ci; a.Co = Co;
+  const int P = N * Ho * Wo;
+  a.tiles_p = (P + 127) / 128; a.tiles_n = Ci / 64;
+  const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
+  k_conv3x3s2_dgrad<<<grid, kFwdThreads, 0, st>>>(a);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3s2_dgrad launch failed");
 }
 
 }  // extern "C"

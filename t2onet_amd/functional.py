@@ -437,6 +437,61 @@ def conv3x3_dgrad(dy, weight):
     return dx
 
 
+def conv3x3s2_dgrad(dy, weight):
+    """Data gradient of conv2d(x, weight, None, stride 2, padding 1) for an even-sized x (t2o_conv3x3s2_dgrad_nhwc).
+    dy (N,Co,Ho,Wo) and weight (Co,Ci,3,3) channels-last; returns dx (N,Ci,2Ho,2Wo) channels-last."""
+    _need_gpu(dy, weight)
+    N, Co, Ho, Wo = dy.shape
+    Ci = weight.shape[1]
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    weight = weight.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3s2_dgrad_workspace_bytes(N, Ho, Wo, Ci, Co)
+    if need == 0:
+        raise RuntimeError('conv3x3s2_dgrad: unsupported shape (Co % 32, Ci % 64, Wo % 8 must be 0)')
+    ws = _conv_workspace(dy.device, need)
+    dx = torch.empty((N, Ci, 2 * Ho, 2 * Wo), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    rc = lib.t2o_conv3x3s2_dgrad_nhwc(_ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), ws.numel(), N, Ho, Wo, Ci, Co, _stream(dy.device))
+    _lib.check(rc, 't2o_conv3x3s2_dgrad_nhwc')
+    return dx
+
+
+def conv3x3s2_supported(x, weight, stride, padding):
+    """The stride-2 layers whose data gradient runs on the own kernel: channels-last fp32 on the GPU, 3x3 / stride 2 /
+    padding 1, even image size with an output width that is a multiple of 8, Ci a multiple of 64, Co of 32."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and weight.shape[0] % 32 == 0
+            and weight.shape[1] % 64 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 16 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _Conv3x3S2Fn(torch.autograd.Function):
+    """conv2d(x, w, 3x3, stride 2, padding 1): forward and weight gradient are library calls, the data gradient the
+    hand-written kernel ('s' in T2O_OWN_CONV)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight, None, 2, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        own = ctx.needs_input_grad[0] and 's' in _CONV_OWN
+        mask = [ctx.needs_input_grad[0] and not own, ctx.needs_input_grad[1], False]
+        dx = dw = None
+        if mask[0] or mask[1]:
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, mask)
+        if own:
+            dx = conv3x3s2_dgrad(dy, weight)
+        return dx, dw
+
+
+def conv3x3s2(x, weight):
+    return _Conv3x3S2Fn.apply(x, weight)
+
+
 def conv3x3_supported(x, weight, stride, padding):
     """Layers the matrix-core convolution kernels take: channels-last fp32 activations on the GPU, 3x3 / stride 1 /
     padding 1, channel counts multiples of 64, image width a multiple of 4 (every BasicBlock convolution of the
@@ -447,8 +502,8 @@ def conv3x3_supported(x, weight, stride, padding):
 
 
 # which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
-# 'w' weight gradient, 'f' forward, 'd' data gradient
-_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfd')
+# 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 's' data gradient of the stride-2 layers
+_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfds')
 
 
 def _own_direct(x):

@@ -113,6 +113,42 @@ def test_encoder_layer_shapes_at_batch_64_match_the_library(layer):
     assert torch.equal(dw, T.conv3x3_wgrad(x, dy))
 
 
+# (N, Ci, Co, Ho, Wo) of the stride-2 layers: dx is (N, Ci, 2Ho, 2Wo)
+S2_SHAPES = [(2, 64, 64, 8, 8), (3, 64, 128, 5, 16), (1, 128, 64, 3, 24), (2, 64, 32, 1, 8), (2, 128, 256, 20, 8), (1, 64, 64, 2, 136)]
+
+
+@pytest.mark.parametrize('shape', S2_SHAPES)
+def test_stride2_dgrad_matches_conv2d_fp64(shape):
+    import t2onet_amd.functional as T
+    N, Ci, Co, Ho, Wo = shape
+    dy = synth.uniform((N, Co, Ho, Wo), 751, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 752, -1.0, 1.0)
+    x64 = torch.zeros(N, Ci, 2 * Ho, 2 * Wo, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x64, w.double(), None, 2, 1).backward(dy.double())
+    ref = x64.grad
+    dev = torch.device('cuda:0')
+    dx = T.conv3x3s2_dgrad(dy.to(dev).contiguous(memory_format=torch.channels_last),
+                           w.to(dev).contiguous(memory_format=torch.channels_last))
+    assert dx.shape == (N, Ci, 2 * Ho, 2 * Wo) and dx.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(dx.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_stride2_autograd_function_matches_library():
+    import t2onet_amd.functional as T
+    dev = torch.device('cuda:0')
+    x = synth.uniform((2, 64, 12, 32), 761, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    w = synth.uniform((128, 64, 3, 3), 762, -0.1, 0.1).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = synth.uniform((2, 128, 6, 16), 763, -1.0, 1.0).to(dev)
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    assert T.conv3x3s2_supported(x1, w1, (2, 2), (1, 1))
+    T.conv3x3s2(x1, w1).backward(gy)
+    torch.nn.functional.conv2d(x2, w2, None, 2, 1).backward(gy)
+    np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(w1.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(w2.grad.abs().max()))
+
+
 def test_wgrad_refuses_widths_it_does_not_take():
     """W % 4 != 0 is not a shape of the kernel: the library says so and the autograd wrapper's predicate sends such
     layers to the library convolution."""

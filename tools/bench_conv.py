@@ -1,5 +1,6 @@
 """Own MFMA convolution kernels vs MIOpen's for the encoder's 3x3 stride-1 layers (bs=64, 256x256 input):
-forward, data gradient, weight gradient.  usage: tools/bench_conv.py [batch] [directions, e.g. fd]"""
+forward, data gradient, weight gradient (f, d, w), and the data gradient of the stride-2 layers (s).
+usage: tools/bench_conv.py [batch] [directions, e.g. fd]"""
 import os
 import sys
 import torch
@@ -8,7 +9,7 @@ import t2onet_amd.functional as T  # noqa: E402
 
 dev = torch.device('cuda')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-DIRS = sys.argv[2] if len(sys.argv) > 2 else 'fdw'
+DIRS = sys.argv[2] if len(sys.argv) > 2 else 'fdws'
 
 
 def timeit(fn, n=20):
@@ -39,9 +40,26 @@ for name, c, h in (('l1.s1', 64, 64), ('l2.s1', 128, 32), ('l3.s1', 256, 16), ('
         'w': ('wgrad', lambda: lib_bwd(gy, x, w, [False, True, False])[1], lambda: T.conv3x3_wgrad(x, gy)),
     }
     for d in DIRS:
+        if d not in cases:
+            continue
         label, lib, own = cases[d]
         t_lib, t_own = timeit(lib), timeit(own)
         ref = lib()
         err = ((own() - ref).abs().max() / ref.abs().max()).item()
         print('%-6s %s %6.2f GFLOP  MIOpen %.3f ms (%6.1f TF/s)   own %.3f ms (%6.1f TF/s)   x%.2f   rel err vs MIOpen %.1e' % (
             name, label, gf, t_lib, gf / t_lib, t_own, gf / t_own, t_lib / t_own, err), flush=True)
+
+if 's' in DIRS:
+    # the stride-2 layers (first convolution of each stage): data gradient
+    for name, ci, co, ho in (('l1.s2', 64, 64, 64), ('l2.s2', 64, 128, 32), ('l3.s2', 128, 256, 16), ('l4.s2', 256, 512, 8)):
+        x = torch.randn(B, ci, 2 * ho, 2 * ho, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(co, ci, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(B, co, ho, ho, device=dev).contiguous(memory_format=torch.channels_last)
+        gf = 2.0 * B * ho * ho * ci * co * 9 / 1e9
+        lib = lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        own = lambda: T.conv3x3s2_dgrad(gy, w)
+        t_lib, t_own = timeit(lib), timeit(own)
+        ref = lib()
+        err = ((own() - ref).abs().max() / ref.abs().max()).item()
+        print('%-6s dgrad %6.2f GFLOP  MIOpen %.3f ms (%6.1f TF/s)   own %.3f ms (%6.1f TF/s)   x%.2f   rel err vs MIOpen %.1e' % (
+            name, gf, t_lib, gf / t_lib, t_own, gf / t_own, t_lib / t_own, err), flush=True)
