@@ -103,7 +103,7 @@ class ResNet(nn.Module):
             # num_batches_tracked of all 21 batch norms: one multi-tensor launch instead of 21 one-element kernels
             torch._foreach_add_(self._batch_counters(), 1)
             counted = True
-        x = _bn_relu(self.bn1, self.conv1(x), None, counted)
+        x = _bn_relu(self.bn1, _conv(self.conv1, x), None, counted)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for block in layer:
                 x = block(x, counted)

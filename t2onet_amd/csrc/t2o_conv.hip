@@ -48,6 +48,13 @@ struct WgradArgs {
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// the zero region of a workspace (a multiple of 256 bytes).  A kernel, not hipMemsetAsync: inside a captured hipGraph
+// the memset node was seen to run out of order with the kernels around it (replays read a stale region)
+__global__ __launch_bounds__(256) void k_conv_zero(float4* p, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 // Instructions beside an fp32 MFMA stream (tools/diag/valu_beside_mfma.hip, two waves per SIMD, the other one
 // streaming v_mfma_f32_32x32x2_f32): a VECTOR-ALU instruction of this wave takes 58 cycles when the partner's MFMAs
 // are interleaved with LDS reads and 300-400 beside a bare stream (11 alone); a SCALAR instruction 15-18 (10 alone);
@@ -788,6 +795,74 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a
   }
 }
 
+// ================================================================================================================
+// DATA GRADIENT OF THE STEM CONVOLUTION (3 -> Co channels, 3x3, stride 2: models/actor_resnet.py:87, needed whenever
+// the encoder's input image carries a gradient -- every episode step after the first)
+//   3 output channels are no matrix-core shape (the library's kernel for it runs at 9 TFLOP/s: 0.40 ms for 3.6 GFLOP);
+//   it is a streaming kernel: read dy (N,Ho,Wo,Co) once, 27 FMAs per (pixel, co), write dx (N,2Ho,2Wo,3).
+//   One thread per dy-grid pixel (alpha, beta) produces the 2 x 2 block of dx pixels above it (see
+//   k_conv3x3s2_dgrad for the index algebra) from dy at (alpha + {0,1}, beta + {0,1}).  A workgroup stages a
+//   9 x 33 pixel tile of dy in LDS, 32 channels at a time, with coalesced 16-byte loads, stored channel-quad-major
+//   ([co/4][pixel][4]: the threads of a wave read consecutive 16-byte slots, no bank conflicts); weights are
+//   wave-uniform scalar loads and enter the FMAs as scalar operands.
+constexpr int kStemTH = 8, kStemTW = 32;                 // dy-grid tile of a workgroup (256 threads)
+constexpr int kStemPix = (kStemTH + 1) * (kStemTW + 1);  // with the +1 row / column the taps kh = 0 / kw = 0 read
+
+template <int kCo>
+__global__ __launch_bounds__(256) void k_stem_dgrad(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                    int N, int Ho, int Wo) {
+  constexpr int kPass = 32;                              // channels staged per pass: 38 KB of LDS, 4 workgroups per CU
+  constexpr int CQ = kPass / 4;
+  __shared__ float4 tile[CQ][kStemPix + 1];              // (+1: plane stride 298 * 16 B, co-prime with the 16 bank groups of a b128 access)
+  const int tiles_w = (Wo + kStemTW - 1) / kStemTW, tiles_h = (Ho + kStemTH - 1) / kStemTH;
+  const int tb = blockIdx.x;
+  const int n = tb / (tiles_h * tiles_w), th = (tb / tiles_w) % tiles_h, tw = tb % tiles_w;
+  const int a0 = th * kStemTH, b0 = tw * kStemTW;
+  const int ta = threadIdx.x / kStemTW, tbeta = threadIdx.x % kStemTW;
+  const int al = a0 + ta, be = b0 + tbeta;
+  const int p00 = ta * (kStemTW + 1) + tbeta;            // (alpha, beta); +1: beta + 1; + kStemTW + 1: alpha + 1
+  float acc[2][2][3] = {};
+  for (int c0 = 0; c0 < kCo; c0 += kPass) {
+    if (c0) __syncthreads();
+    // stage dy[n][a0 .. a0+8][b0 .. b0+32][c0 .. c0+32): 8 consecutive threads read one pixel's 128 bytes
+    for (int f = threadIdx.x; f < kStemPix * CQ; f += 256) {
+      const int px = f / CQ, cq = f % CQ;
+      const int sa = a0 + px / (kStemTW + 1), sb = b0 + px % (kStemTW + 1);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (sa < Ho && sb < Wo) v = ldg4(dy + (((size_t)n * Ho + sa) * Wo + sb) * kCo + c0 + 4 * cq);
+      tile[cq][px] = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int cq = 0; cq < CQ; ++cq) {
+      const float4 d00 = tile[cq][p00], d01 = tile[cq][p00 + 1], d10 = tile[cq][p00 + kStemTW + 1], d11 = tile[cq][p00 + kStemTW + 2];
+      const float v00[4] = {d00.x, d00.y, d00.z, d00.w}, v01[4] = {d01.x, d01.y, d01.z, d01.w};
+      const float v10[4] = {d10.x, d10.y, d10.z, d10.w}, v11[4] = {d11.x, d11.y, d11.z, d11.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* wc = w + (size_t)(c0 + cq * 4 + k) * 27;   // w[co][kh][kw][c]: wave-uniform -> scalar loads
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int ph = kh != 1, pw = kw != 1;
+            const float d = kh == 0 ? (kw == 0 ? v11[k] : v10[k]) : (kw == 0 ? v01[k] : v00[k]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[ph][pw][c] = fmaf(d, wc[(kh * 3 + kw) * 3 + c], acc[ph][pw][c]);
+          }
+      }
+    }
+  }
+  if (al < Ho && be < Wo) {
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      float* o = dx + ((((size_t)n * 2 * Ho + 2 * al + ph) * 2 * Wo) + 2 * be) * 3;      // 6 consecutive floats (pw = 0, 1)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) o[q] = acc[ph][q / 3][q % 3];
+    }
+  }
+}
+
 int conv_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -816,6 +891,11 @@ int launch_fwd(const float* x, const float* w, float* y, const float* zero, int 
   if (bm == 1) k_conv3x3_fwd<1><<<grid, kFwdThreads, 0, st>>>(a);
   else k_conv3x3_fwd<2><<<grid, kFwdThreads, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : T2O_ELAUNCH;
+}
+
+void clear_zero_region(void* p, size_t bytes, hipStream_t st) {
+  const size_t n16 = bytes / 16;
+  k_conv_zero<<<(unsigned)((n16 + 255) / 256), 256, 0, st>>>((float4*)p, n16);
 }
 
 struct WgradPlan { int tm, tn, tiles_m, tiles_n, splits, stages_per_split, total_stages; size_t zero_bytes; };
@@ -869,8 +949,7 @@ int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* wor
   const WgradPlan p = wgrad_plan(N, H, W, Ci, Co);
   WgradArgs a;
   a.x = x; a.dy = dy; a.partial = (float*)((char*)workspace + p.zero_bytes); a.zero = (const float*)workspace;
-  if (hipMemsetAsync(workspace, 0, p.zero_bytes, (hipStream_t)stream) != hipSuccess)
-    return set_error(T2O_ELAUNCH, "conv3x3_wgrad: clearing the zero region failed");
+  clear_zero_region(workspace, p.zero_bytes, (hipStream_t)stream);
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n;
   a.splits = p.splits; a.stages_per_split = p.stages_per_split; a.total_stages = p.total_stages;
@@ -901,8 +980,7 @@ int t2o_conv3x3_fwd_nhwc(const float* x, const float* w, float* y, void* workspa
     return set_error(T2O_EUNSUPPORTED, "conv3x3_fwd: Ci must be a multiple of 32, Co of 64, the image width of 8");
   if (!workspace || workspace_bytes < fwd_zero_bytes(Ci)) return set_error(T2O_EWORKSPACE, "conv3x3_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, fwd_zero_bytes(Ci), st) != hipSuccess)
-    return set_error(T2O_ELAUNCH, "conv3x3_fwd: clearing the zero region failed");
+  clear_zero_region(workspace, fwd_zero_bytes(Ci), st);
   const int rc = launch_fwd(x, w, y, (const float*)workspace, N, H, W, Ci, Co, st);
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_fwd launch failed");
 }
@@ -921,29 +999,38 @@ int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* wor
     return set_error(T2O_EWORKSPACE, "conv3x3_dgrad: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const size_t zb = fwd_zero_bytes(Co);
-  if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess)
-    return set_error(T2O_ELAUNCH, "conv3x3_dgrad: clearing the zero region failed");
+  clear_zero_region(workspace, zb, st);
   float* wt = (float*)((char*)workspace + zb);
   k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci, 1);
   const int rc = launch_fwd(dy, wt, dx, (const float*)workspace, N, H, W, Co, Ci, st);
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_dgrad launch failed");
 }
 
+bool stem_dgrad_supported(int N, int Ho, int Wo, int Ci, int Co) {
+  return N > 0 && Ho > 0 && Wo > 0 && Ci == 3 && (Co == 64 || Co == 32) && (size_t)N * Ho * Wo * 4 < ((size_t)1 << 31);
+}
+
 size_t t2o_conv3x3s2_dgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {
+  if (stem_dgrad_supported(N, Ho, Wo, Ci, Co)) return 16;            // (none needed; a non-zero size says "supported")
   return fwd_supported(N, Ho, Wo, Co, Ci) ? fwd_zero_bytes(Co) + sizeof(float) * (size_t)Co * 9 * Ci : 0;
 }
 
 int t2o_conv3x3s2_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                              int N, int Ho, int Wo, int Ci, int Co, void* stream) {
   if (!dy || !w || !dx) return set_error(T2O_EINVAL, "conv3x3s2_dgrad: null pointer");
+  if (stem_dgrad_supported(N, Ho, Wo, Ci, Co)) {                     // the 3-channel stem: streaming kernel, no workspace
+    const unsigned grid = (unsigned)(N * ((Ho + kStemTH - 1) / kStemTH) * ((Wo + kStemTW - 1) / kStemTW));
+    if (Co == 64) k_stem_dgrad<64><<<grid, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, Ho, Wo);
+    else k_stem_dgrad<32><<<grid, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, Ho, Wo);
+    return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3s2_dgrad (stem) launch failed");
+  }
   if (!fwd_supported(N, Ho, Wo, Co, Ci) || (size_t)N * Ho * Wo * 4 + 1024 >= ((size_t)1 << 31))
-    return set_error(T2O_EUNSUPPORTED, "conv3x3s2_dgrad: Co must be a multiple of 32, Ci of 64, the output-gradient width of 8");
+    return set_error(T2O_EUNSUPPORTED, "conv3x3s2_dgrad: Co must be a multiple of 32, Ci of 64 and the output-gradient width of 8 -- or Ci = 3 with Co = 32 / 64");
   if (!workspace || workspace_bytes < t2o_conv3x3s2_dgrad_workspace_bytes(N, Ho, Wo, Ci, Co))
     return set_error(T2O_EWORKSPACE, "conv3x3s2_dgrad: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const size_t zb = fwd_zero_bytes(Co);
-  if (hipMemsetAsync(workspace, 0, zb, st) != hipSuccess)
-    return set_error(T2O_ELAUNCH, "conv3x3s2_dgrad: clearing the zero region failed");
+  clear_zero_region(workspace, zb, st);
   float* wt = (float*)((char*)workspace + zb);
   k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci, 0);
   Dgrad2Args a;

@@ -989,6 +989,13 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
 }  // namespace
 
 // ==================================================================== C ABI
+namespace {
+__global__ __launch_bounds__(256) void k_zero_floats(float* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.0f;
+}
+}  // namespace
+
 extern "C" {
 
 int t2o_abi_version(void) { return 3; }
@@ -1281,7 +1288,10 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
   hipStream_t st = (hipStream_t)stream;
   bool has_identity = false;                     // identity rows are written by no kernel
   for (int k = 0; k < K; ++k) has_identity = has_identity || ops[k] == OP_IDENTITY;
-  if (has_identity) hipMemsetAsync(gparams, 0, sizeof(float) * (size_t)K * B * kMaxParam, st);
+  if (has_identity) {   // (a kernel, not hipMemsetAsync: a memset node inside a captured hipGraph was seen to run out of order, t2o_conv.hip)
+    const size_t n = (size_t)K * B * kMaxParam;
+    k_zero_floats<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(gparams, n);
+  }
   const float* gcur = nullptr;
   for (int s = ns - 1; s >= 0; --s) {
     const float* in = s == 0 ? img : seg_bufs + (size_t)(s - 1) * img_floats;

@@ -395,6 +395,7 @@ def _conv_workspace(device, need):
     key = (device.index, _stream(device))
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() < need:
+        need = max(need, int(os.environ.get('T2O_CONV_WS_MB', '0')) << 20)
         ws = _conv_ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return ws
 
@@ -448,7 +449,7 @@ def conv3x3s2_dgrad(dy, weight):
     lib = _lib.load()
     need = lib.t2o_conv3x3s2_dgrad_workspace_bytes(N, Ho, Wo, Ci, Co)
     if need == 0:
-        raise RuntimeError('conv3x3s2_dgrad: unsupported shape (Co % 32, Ci % 64, Wo % 8 must be 0)')
+        raise RuntimeError('conv3x3s2_dgrad: unsupported shape (Co % 32, Ci % 64, Wo % 8 must be 0 -- or Ci = 3, Co = 32 / 64)')
     ws = _conv_workspace(dy.device, need)
     dx = torch.empty((N, Ci, 2 * Ho, 2 * Wo), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
     rc = lib.t2o_conv3x3s2_dgrad_nhwc(_ptr(dy), _ptr(weight), _ptr(dx), _ptr(ws), ws.numel(), N, Ho, Wo, Ci, Co, _stream(dy.device))
@@ -457,12 +458,16 @@ def conv3x3s2_dgrad(dy, weight):
 
 
 def conv3x3s2_supported(x, weight, stride, padding):
-    """The stride-2 layers whose data gradient runs on the own kernel: channels-last fp32 on the GPU, 3x3 / stride 2 /
-    padding 1, even image size with an output width that is a multiple of 8, Ci a multiple of 64, Co of 32."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
-            and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and weight.shape[0] % 32 == 0
-            and weight.shape[1] % 64 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 16 == 0
-            and x.is_contiguous(memory_format=torch.channels_last))
+    """The stride-2 layers whose data gradient runs on the own kernels: channels-last fp32 on the GPU, 3x3 / stride 2 /
+    padding 1, even image size; either Ci a multiple of 64, Co of 32 and an output width that is a multiple of 8
+    (matrix cores), or the 3-channel stem with 32 / 64 output channels."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
+            and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    if weight.shape[1] == 3:                                   # the stem: a streaming kernel (no matrix-core shape)
+        return weight.shape[0] in (32, 64)
+    return weight.shape[0] % 32 == 0 and weight.shape[1] % 64 == 0 and x.shape[3] % 16 == 0
 
 
 class _Conv3x3S2Fn(torch.autograd.Function):

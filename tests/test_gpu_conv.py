@@ -114,7 +114,8 @@ def test_encoder_layer_shapes_at_batch_64_match_the_library(layer):
 
 
 # (N, Ci, Co, Ho, Wo) of the stride-2 layers: dx is (N, Ci, 2Ho, 2Wo)
-S2_SHAPES = [(2, 64, 64, 8, 8), (3, 64, 128, 5, 16), (1, 128, 64, 3, 24), (2, 64, 32, 1, 8), (2, 128, 256, 20, 8), (1, 64, 64, 2, 136)]
+S2_SHAPES = [(2, 64, 64, 8, 8), (3, 64, 128, 5, 16), (1, 128, 64, 3, 24), (2, 64, 32, 1, 8), (2, 128, 256, 20, 8), (1, 64, 64, 2, 136),
+             (2, 3, 64, 16, 16), (3, 3, 64, 9, 37), (1, 3, 32, 1, 1), (2, 3, 64, 8, 64)]      # (the last four: the 3-channel stem)
 
 
 @pytest.mark.parametrize('shape', S2_SHAPES)
@@ -147,6 +148,53 @@ def test_stride2_autograd_function_matches_library():
     torch.nn.functional.conv2d(x2, w2, None, 2, 1).backward(gy)
     np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(w1.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(w2.grad.abs().max()))
+
+
+def test_kernels_inside_replayed_graphs():
+    """The train step runs these kernels inside hipGraph replays (t2onet_amd/graphs.py).  Captured one graph per
+    direction from one memory pool (a later capture re-uses memory an earlier one freed, as the encoder's graphs do),
+    replayed with new inputs and with the allocator's free memory poisoned in between: every replay must match the
+    library.  (With hipMemsetAsync clearing the workspaces' zero regions this failed from the second or third replay
+    on -- the memset node ran out of order with the kernels around it; a kernel clears them now.)"""
+    import t2onet_amd.functional as T
+    dev = torch.device('cuda:0')
+    c, h = 256, 16
+    g = torch.Generator(device='cpu').manual_seed(771)
+    x = torch.randn(16, c, h, h, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(16, c, h, h, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gy2 = torch.randn(16, c, h // 2, h // 2, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    fns = {'fwd': lambda: T.conv3x3_forward(x, w), 'dgrad': lambda: T.conv3x3_dgrad(gy, w),
+           'wgrad': lambda: T.conv3x3_wgrad(x, gy), 's2': lambda: T.conv3x3s2_dgrad(gy2, w)}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for f in fns.values():
+            f()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    pool = torch.cuda.graph_pool_handle()
+    graphs, outs = {}, {}
+    for name, f in fns.items():
+        graphs[name] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graphs[name], pool=pool, capture_error_mode='thread_local'):
+            outs[name] = f()
+
+    def lib_bwd(dy, stride, mask):
+        return torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1, mask)
+
+    for trial in range(6):
+        x.normal_(), gy.normal_(), gy2.normal_(), w.normal_().mul_(0.05)
+        junk = torch.full((32 << 20,), float('inf'), device=dev)
+        del junk
+        for name in fns:
+            graphs[name].replay()
+        torch.cuda.synchronize()
+        ref = {'fwd': torch.nn.functional.conv2d(x, w, None, 1, 1), 'dgrad': lib_bwd(gy, 1, [True, False, False])[0],
+               'wgrad': lib_bwd(gy, 1, [False, True, False])[1], 's2': lib_bwd(gy2, 2, [True, False, False])[0]}
+        for name in fns:
+            err = float((outs[name] - ref[name]).abs().max() / ref[name].abs().max())
+            assert err < 2e-5, (trial, name, err)
 
 
 def test_wgrad_refuses_widths_it_does_not_take():

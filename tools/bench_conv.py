@@ -51,7 +51,7 @@ for name, c, h in (('l1.s1', 64, 64), ('l2.s1', 128, 32), ('l3.s1', 256, 16), ('
 
 if 's' in DIRS:
     # the stride-2 layers (first convolution of each stage): data gradient
-    for name, ci, co, ho in (('l1.s2', 64, 64, 64), ('l2.s2', 64, 128, 32), ('l3.s2', 128, 256, 16), ('l4.s2', 256, 512, 8)):
+    for name, ci, co, ho in (('stem', 3, 64, 128), ('l1.s2', 64, 64, 64), ('l2.s2', 64, 128, 32), ('l3.s2', 128, 256, 16), ('l4.s2', 256, 512, 8)):
         x = torch.randn(B, ci, 2 * ho, 2 * ho, device=dev).contiguous(memory_format=torch.channels_last)
         w = (torch.randn(co, ci, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
         gy = torch.randn(B, co, ho, ho, device=dev).contiguous(memory_format=torch.channels_last)
