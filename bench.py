@@ -584,9 +584,12 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
     dt = ctx['max_over_ranks'](time.perf_counter() - t0)
     flop = TRAIN_FLOP_PER_IMAGE * (H * W) / (256.0 * 256.0) * B
     tf = flop / (dt / steps) / 1e12                        # per GPU
+    finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())   # (a step that produced inf/nan gradients is no measurement)
+    if not finite:
+        raise RuntimeError('train leg: non-finite parameters after %d steps' % (warmup + steps))
     return {'images_per_sec': round(world * B * steps / dt, 1), 'ms_per_step': round(dt / steps * 1e3, 3),
             'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 2),
-            'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()),
+            'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()), 'parameters_finite': finite,
             'encoder_hipgraphs': bool(tr.graph_encoder and '_graphed_encoders' in model.__dict__),
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,

@@ -221,6 +221,12 @@ size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream);
 
+/* Optional: register `bytes` of device memory on `device` that hold zeros and that nobody writes while convolutions
+ * run (NULL unregisters).  The t2o_conv3x3* calls then read their padding from it instead of clearing the zero
+ * region at the start of their workspace on every call (it must be at least that large, 20 KiB covers the
+ * encoder; smaller: ignored).  Process-wide state, set before the calls it should affect. */
+int t2o_conv_set_zero_region(int device, const void* zeros, size_t bytes);
+
 /* ---- data gradient of the encoder's STRIDE-2 3x3 convolutions (the first convolution of each stage,
  * models/actor_resnet.py:32-36 with stride 2; replaces torch.ops.aten.convolution_backward(..., output_mask [1,0,0])):
  *   dx[n][i][j][ci] = sum_{kh,kw,co} dy[n][(i+1-kh)/2][(j+1-kw)/2][co] * w[co][kh][kw][ci]   over the taps for which

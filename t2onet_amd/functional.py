@@ -391,7 +391,16 @@ def conv3x3_wgrad(x, dy):
     return dw
 
 
+_conv_zeros = {}
+
+
 def _conv_workspace(device, need):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _conv_zeros and not torch.cuda.is_current_stream_capturing():
+        # a block of zeros the kernels read their padding from (never written): saves clearing a region per call
+        z = _conv_zeros[idx] = torch.zeros(64 << 10, dtype=torch.uint8, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        _lib.check(_lib.load().t2o_conv_set_zero_region(idx, _ptr(z), z.numel()), 't2o_conv_set_zero_region')
     key = (device.index, _stream(device))
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() < need:
