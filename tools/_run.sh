@@ -1,3 +1,2 @@
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -x 2>&1 | tail -4
-bash tools/ab_train.sh "T2O_OWN_CONV=wfds" "T2O_OWN_WGRAD=0" "T2O_OWN_CONV=wfds"
+python tools/bench_conv.py 64 fdws 2>&1 | grep -v amdgpu.ids
