@@ -391,3 +391,38 @@ def test_flat_adam_matches_torch_adam():
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
     x = torch.randn(2, 4, 5, 5, device=dev)
     assert torch.isfinite(net(x)).all()                                  # the module still runs on its re-homed parameters
+
+
+@pytest.mark.gpu
+def test_graphed_training_stays_on_the_eager_trajectory():
+    """Several episode train steps at the encoder's real stage sizes (256x256 images: every own convolution kernel
+    is in the captured graphs), hipGraph replays against eager execution from the same weights and seeds.  One
+    replay matching is not enough: a memset node that ran out of order inside the replayed graphs (fixed, see
+    t2o_conv.hip k_conv_zero) left the first step intact and produced garbage gradients from the second on."""
+    import copy
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    opt = t2onet_amd.default_options()
+    opt.input_dropout_p = opt.dropout_p = 0.0
+    torch.manual_seed(21)
+    base = Actor(opt).to(dev).train()
+    base.use_channels_last()
+    B, H, W = 8, 256, 256
+    img = synth.images(B, H, W, 91).to(dev)
+    tgt = synth.images(B, H, W, 92).to(dev)
+    x = synth.requests(B, 17, 93).to(dev)
+    lengths = (x != 0).sum(1).cpu()
+    runs = {}
+    for graph in (False, True):
+        model = copy.deepcopy(base)
+        tr = Trainer(model, opt, graph_encoder=graph)
+        torch.manual_seed(22)
+        losses = [float(tr.episode_step(x, img, tgt, lengths=lengths)) for _ in range(5)]
+        assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), (graph, losses)
+        if graph:
+            assert '_graphed_encoders' in model.__dict__ and tr.graph_encoder
+        runs[graph] = losses
+    np.testing.assert_allclose(runs[True], runs[False], rtol=0, atol=5e-3)
+    assert runs[False][-1] < runs[False][0]                    # (and it trains)
