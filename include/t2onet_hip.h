@@ -221,6 +221,14 @@ size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream);
 
+/* ---- weight gradient of the same stride-2 convolutions (t2o_conv.hip, the stride-1 kernel with a two-plane x tile):
+ *   dw[co][kh][kw][ci] = sum_{n,a,b} dy[n][a][b][co] * x[n][2a+kh-1][2b+kw-1][ci]   (zero padding)
+ *   x (N,2Ho,2Wo,Ci), dy (N,Ho,Wo,Co), dw (Co,3,3,Ci).  Ci, Co multiples of 64, Wo a multiple of 4.  Deterministic
+ *   (fixed-order split-K), replaces convolution_backward(..., stride 2, output_mask [0,1,0]). */
+size_t t2o_conv3x3s2_wgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co);
+int t2o_conv3x3s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                             int N, int Ho, int Wo, int Ci, int Co, void* stream);
+
 /* Optional: register `bytes` of device memory on `device` that hold zeros and that nobody writes while convolutions
  * run (NULL unregisters).  The t2o_conv3x3* calls then read their padding from it instead of clearing the zero
  * region at the start of their workspace on every call (it must be at least that large, 20 KiB covers the
@@ -254,6 +262,12 @@ int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* 
                         const float* gparam, float* gctx, float* dpre, float* const* gw1, float* const* gb1,
                         float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
                         float sharpness_range, int B, int D, void* stream);
+
+/* Rewrites a captured, not yet instantiated hipGraph (hipGraph_t) in place: every memset node becomes a kernel node
+ * doing the same fill, with the same dependencies and dependents; *replaced = how many.  Memset nodes were seen to
+ * run out of order with neighbouring kernel nodes on replay (ROCm 7.2 / gfx950): t2onet_amd/graphs.py calls this on
+ * the encoder's graphs before instantiating them (library calls inside them may enqueue hipMemsetAsync). */
+int t2o_graph_memsets_to_kernels(void* graph, int* replaced);
 
 /* ---- Adam over one flat fp32 buffer: experiments/t2onet/train_seq2seqL1.py:169 (torch.optim.Adam, default betas and
  * eps, no weight decay) -- param, grad, exp_avg, exp_avg_sq: n floats each, 16-byte aligned; `step` = 1 for the first

@@ -112,7 +112,11 @@ constexpr int kHalo = 4;             // x tile rows before the stage's first pix
 // either a run of real pixels or all padding (row h + dh outside the image, or beyond the last pixel) and reads the
 // zero region instead -- a scalar select of the base address.  A pixel whose horizontal neighbour lies outside its
 // image row (w == 0 for kw = 0, w == W-1 for kw = 2) has that fragment element zeroed in registers.
-template <int TM, int TN, int kMinWaves>
+// kS = 2: the weight gradient of a STRIDE-2 convolution.  a.H, a.W are then the dy grid (x is 2H x 2W) and the tap
+// (kh, kw) of dy pixel (alpha, beta) reads x at (2 alpha + kh - 1, 2 beta + kw - 1): the x tile is two planes, the
+// even columns 2 beta (kw = 1) and the odd columns 2 beta + 1 (kw = 2, and kw = 0 one pixel to the left), each
+// gathered by the LDS-DMA with a lane stride of two pixels.
+template <int TM, int TN, int kMinWaves, int kS = 1>
 __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(WgradArgs a) {
   constexpr int BM = TM / 64, BN = TN / 64;          // MFMA blocks per wave along m / n (wave tile = TM/2 x TN/2)
   constexpr int RWA = 256 / TM, RWB = 256 / TN;            // tile rows per 1 KiB DMA piece
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
   constexpr int NA = NPA / 4, NB = ((kHalo + kStagePix) / RWB + 1 - PB0 + 3) / 4;      // pieces per wave
   constexpr int BROWS = (PB0 + 4 * NB) * RWB;              // x tile rows: every wave loads NB pieces (the last ones past the rows that are read)
   __shared__ __attribute__((aligned(16))) float As[2][kStagePix][TM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BROWS][TN];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kS][BROWS][TN];
 
   // block index -> (split, channel tile, kernel row).  The 3 kernel rows of one (split, tile) re-read the same dy
   // tile and neighbouring x rows: they get block indices congruent mod 8 (same XCD, shared L2) and adjacent in
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
   // supplies the 16 bytes at column 4 * (l % (T/4)) of row l / (T/4): a loop-invariant byte offset from the piece's
   // scalar base address.
   const unsigned lane_a = (unsigned)((lane / (TM / 4)) * a.Co + (lane % (TM / 4)) * 4) * 4u;
-  const unsigned lane_b = (unsigned)((lane / (TN / 4)) * a.Ci + (lane % (TN / 4)) * 4) * 4u;
+  const unsigned lane_b = (unsigned)((lane / (TN / 4)) * kS * a.Ci + (lane % (TN / 4)) * 4) * 4u;
   // (a.zero is read from the kernel arguments where it is used: as a local captured by the lambdas below, 'ok ? p :
   // zero' becomes a load through a selected ADDRESS of two captures, which keeps all captures in scratch memory)
   int pbase = s0 * kStagePix;                              // first pixel of the stage the next dma_stage() loads
@@ -178,12 +182,21 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
   // that is m < W for dh = -1 and m >= (H - 1) * W for dh = +1, i.e. valid iff lo <= m < lo + span.  m is tracked
   // per piece, advanced by one stage with an add and a conditional subtract.
   const int HW = a.H * a.W;
-  const int m_lo = dh < 0 ? a.W : 0, m_span = dh == 0 ? HW : HW - a.W;
+  const int m_lo = dh < 0 ? a.W : 0, m_span = (dh == 0 || (kS == 2 && dh > 0)) ? HW : HW - a.W;    // (stride 2: row 2 alpha + 1 always exists)
   const int adv_m = __builtin_amdgcn_readfirstlane(kStagePix % HW);
   int mrow[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
     mrow[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(pbase - kHalo + (PB0 + wave + 4 * i) * RWB + HW) % (unsigned)HW));    // (+HW: >= 0)
+  // stride 2: the column beta of each piece's first pixel (x pixel index of dy pixel q: 4 q - 2 beta + (kh-1) 2 W + plane)
+  const int adv_b = __builtin_amdgcn_readfirstlane(kStagePix % a.W);
+  int bcol[kS == 2 ? NB : 1];
+  if constexpr (kS == 2) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      bcol[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(pbase - kHalo + (PB0 + wave + 4 * i) * RWB + HW) % (unsigned)a.W));
+  }
+  const char* const x_tile = (const char*)(a.x + n0);
   const unsigned lds_a = lds_addr(&As[0][0][0]), lds_b = lds_addr(&Bs[0][0][0]);
   // The DMA of a stage is NA + NB pieces per wave, all scalar work: select the base address (the zero region for
   // padding, for the tail and when there is no next stage), issue, advance m.
@@ -195,22 +208,31 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
       const bool ok = more && pbase + piece * RWA < P;     // P % 4 == 0: a piece is all inside or all beyond the tail
       glds16(lane_a, ok ? a_ptr + j * step_a : (const char*)a.zero, lds_a + (unsigned)(buf * kStagePix * TM * 4 + piece * 1024));
     } else {
-      constexpr int i = j - NA;
+      constexpr int i = (j - NA) % NB, plane = (j - NA) / NB;
       const int piece = PB0 + wave + 4 * i;
       const int q0 = pbase - kHalo + piece * RWB;          // the pixel whose centre tap reads the piece's first row
       const bool ok = more && (unsigned)q0 < (unsigned)P && (unsigned)(mrow[i] - m_lo) < (unsigned)m_span;
-      glds16(lane_b, ok ? b_ptr + i * step_b : (const char*)a.zero, lds_b + (unsigned)(buf * BROWS * TN * 4 + piece * 1024));
-      mrow[i] += adv_m;
-      mrow[i] -= mrow[i] >= HW ? HW : 0;
+      const char* src;
+      if constexpr (kS == 1) src = b_ptr + i * step_b;
+      else src = x_tile + ((long long)4 * q0 - 2 * bcol[i] + (long long)dh * 2 * a.W + plane) * a.Ci * 4;
+      glds16(lane_b, ok ? src : (const char*)a.zero, lds_b + (unsigned)(((buf * kS + plane) * BROWS) * TN * 4 + piece * 1024));
+      if constexpr (plane == kS - 1) {                     // (after the piece's last plane)
+        mrow[i] += adv_m;
+        mrow[i] -= mrow[i] >= HW ? HW : 0;
+        if constexpr (kS == 2) {
+          bcol[i] += adv_b;
+          bcol[i] -= bcol[i] >= a.W ? a.W : 0;
+        }
+      }
     }
-    if constexpr (j == NA + NB - 1) {                      // the stage's last piece: on to the next stage
+    if constexpr (j == NA + kS * NB - 1) {                 // the stage's last piece: on to the next stage
       pbase += kStagePix;
       a_ptr += stage_a;
       b_ptr += stage_b;
     }
   };
   auto dma_stage = [&](int buf) {                          // a whole stage at once (the prologue)
-    static_for<0, NA + NB>([&](auto jc) { dma_piece(jc, buf); });
+    static_for<0, NA + kS * NB>([&](auto jc) { dma_piece(jc, buf); });
   };
 
   // ---- fragments: lane l reads channel (l % 32) of pixel 2 * kk + l / 32 -- conflict-free ds_read_b32 from one
@@ -229,7 +251,9 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
       constexpr int t = decltype(tc)::value;
       static_for<0, BN>([&](auto jc) {
         constexpr int jn = decltype(jc)::value;
-        fb[slot][t][jn] = lds_read<(Q * BROWS + 2 * kk + kHalo - 1 + t) * TN * 4 + jn * 128>(fb_base);
+        // stride 1: row of pixel + (kw - 1); stride 2: kw = 0 -> odd plane one pixel to the left, 1 -> even plane, 2 -> odd plane
+        constexpr int plane = kS == 1 ? 0 : (t == 1 ? 0 : 1), row = kS == 1 ? kHalo - 1 + t : (t == 0 ? kHalo - 1 : kHalo);
+        fb[slot][t][jn] = lds_read<((Q * kS + plane) * BROWS + 2 * kk + row) * TN * 4 + jn * 128>(fb_base);
       });
     });
   };
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
   //   k-pair  last     its fragment prefetch already reads k-pair 0 of stage st+1: no bubble at the stage boundary
   constexpr int NM = 3 * BM * BN;                         // MFMAs per k-pair
   constexpr int kSaluPerGap = (24 + NM - 1) / NM;         // ~24 scalar instructions per piece
-  static_assert(NA + NB <= KP - 3, "one DMA piece per k-pair, all issued well before the barrier");
+  static_assert(NA + kS * NB <= KP - 3, "one DMA piece per k-pair, all issued well before the barrier");
   auto stage = [&](auto Qc, int st) {
     constexpr int Q = decltype(Qc)::value;
     const bool has_next = st + 1 < s1;
@@ -274,20 +298,22 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
       }
       wk += 2;
       if (wk == a.W) {                                    // lanes of pixel 2kk+1 sit at w == W-1: kw = 2 reads pixel w+1, outside
-        wk = 0;
+        wk = 0;                                           // (stride 2: column 2 beta + 1 always exists)
+        if constexpr (kS == 1) {
 #pragma unroll
-        for (int jn = 0; jn < BN; ++jn) asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(fb[cur][2][jn]) : "s"(0xffffffff00000000ull));
+          for (int jn = 0; jn < BN; ++jn) asm volatile("v_cndmask_b32_e64 %0, %0, 0, %1" : "+v"(fb[cur][2][jn]) : "s"(0xffffffff00000000ull));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // the k-pair's MFMAs, and DMA piece kk of stage st+1 (into the OTHER buffer): ~20 scalar instructions that the
       // scheduler is told to deal out two per MFMA (in the shadow of the MFMA just issued) instead of in one block
-      if constexpr (kk < NA + NB) dma_piece(kkc, Q ^ 1);
+      if constexpr (kk < NA + kS * NB) dma_piece(kkc, Q ^ 1);
       static_for<0, NM>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int t = m / (BM * BN), i = (m / BN) % BM, jn = m % BN;
         acc[t][i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][t][jn], acc[t][i][jn], 0, 0, 0);
       });
-      if constexpr (kk < NA + NB) {
+      if constexpr (kk < NA + kS * NB) {
 #pragma unroll
         for (int g = 0; g < NM; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
@@ -916,18 +942,18 @@ bool wgrad_supported(int N, int H, int W, int Ci, int Co) {
          (size_t)N * H * W + (size_t)H * W + 64 < ((size_t)1 << 31);               // pixel indices are ints
 }
 
-WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co) {
+WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int stride = 1) {
   WgradPlan p;
   static const int tile_n = conv_env("T2O_WGRAD_TILE_N", 64);            // 128: 128 x 128 tiles -- twice the split-K partial bytes per workgroup
   static const int tile_m = conv_env("T2O_WGRAD_TILE_M", 128);
   p.tm = (Co % 128 == 0 && tile_m == 128) ? 128 : 64;
-  p.tn = (Ci % 128 == 0 && tile_n == 128) ? 128 : 64;
+  p.tn = (Ci % 128 == 0 && tile_n == 128 && stride == 1) ? 128 : 64;      // (stride 2: two x planes per tile, 64 wide)
   p.tiles_m = Co / p.tm;
   p.tiles_n = Ci / p.tn;
   const int P = N * H * W;
   p.total_stages = (P + kStagePix - 1) / kStagePix;
   // zeros behind the lane offsets of one DMA piece (up to 4 pixel rows of the wider tensor)
-  p.zero_bytes = ((size_t)4 * (Ci > Co ? Ci : Co) * 4 + 1024 + 255) / 256 * 256;
+  p.zero_bytes = ((size_t)4 * stride * (Ci > Co ? Ci : Co) * 4 + 1024 + 255) / 256 * 256;
   // ONE round of workgroups: 2 are resident per CU, 64 slots per XCD; a second, partly filled round would cost a
   // whole round's time.  (split, tile) units are dealt to the 8 XCDs in turn, 3 workgroups (kernel rows) each:
   // 21 units per XCD = 63 slots.  At least 8 stages of K per workgroup.
@@ -938,6 +964,31 @@ WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co) {
   p.stages_per_split = (p.total_stages + splits - 1) / splits;
   p.splits = (p.total_stages + p.stages_per_split - 1) / p.stages_per_split;
   return p;
+}
+
+// (N, H, W): the dy grid (= the x grid for stride 1; x is 2H x 2W for stride 2)
+int launch_wgrad(const float* x, const float* dy, float* dw, void* workspace, int N, int H, int W, int Ci, int Co, int stride,
+                 hipStream_t st) {
+  const WgradPlan p = wgrad_plan(N, H, W, Ci, Co, stride);
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.partial = (float*)((char*)workspace + p.zero_bytes);
+  a.zero = zero_region(workspace, p.zero_bytes, st);
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n;
+  a.splits = p.splits; a.stages_per_split = p.stages_per_split; a.total_stages = p.total_stages;
+  a.stamps = nullptr;
+  const int units = p.splits * p.tiles_m * p.tiles_n;
+  const unsigned grid = (unsigned)(((units + 7) / 8) * 24);
+#define T2O_WGRAD_LAUNCH(TM_, TN_, S_) k_conv3x3_wgrad<TM_, TN_, 2, S_><<<grid, kConvThreads, 0, st>>>(a)
+  if (stride == 2) { if (p.tm == 128) T2O_WGRAD_LAUNCH(128, 64, 2); else T2O_WGRAD_LAUNCH(64, 64, 2); }
+  else if (p.tm == 128 && p.tn == 128) T2O_WGRAD_LAUNCH(128, 128, 1);
+  else if (p.tm == 128) T2O_WGRAD_LAUNCH(128, 64, 1);
+  else if (p.tn == 128) T2O_WGRAD_LAUNCH(64, 128, 1);
+  else T2O_WGRAD_LAUNCH(64, 64, 1);
+#undef T2O_WGRAD_LAUNCH
+  const size_t n = (size_t)Co * 9 * Ci, n4 = n / 4;
+  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(a.partial, dw, n4, p.splits, n);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3 weight-gradient launch failed");
 }
 
 }  // namespace
@@ -957,27 +1008,23 @@ int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* wor
     return set_error(T2O_EUNSUPPORTED, "conv3x3_wgrad: channel counts must be multiples of 64 and the image width a multiple of 4");
   if (!workspace || workspace_bytes < t2o_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co))
     return set_error(T2O_EWORKSPACE, "conv3x3_wgrad: workspace too small");
-  const WgradPlan p = wgrad_plan(N, H, W, Ci, Co);
-  WgradArgs a;
-  a.x = x; a.dy = dy; a.partial = (float*)((char*)workspace + p.zero_bytes);
-  a.zero = zero_region(workspace, p.zero_bytes, (hipStream_t)stream);
-  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
-  a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n;
-  a.splits = p.splits; a.stages_per_split = p.stages_per_split; a.total_stages = p.total_stages;
-  a.stamps = nullptr;
-  const int units = p.splits * p.tiles_m * p.tiles_n;
-  const unsigned grid = (unsigned)(((units + 7) / 8) * 24);
-  hipStream_t st = (hipStream_t)stream;
-#define T2O_WGRAD_LAUNCH(TM_, TN_) k_conv3x3_wgrad<TM_, TN_, 2><<<grid, kConvThreads, 0, st>>>(a)
-  if (p.tm == 128 && p.tn == 128) T2O_WGRAD_LAUNCH(128, 128);
-  else if (p.tm == 128) T2O_WGRAD_LAUNCH(128, 64);
-  else if (p.tn == 128) T2O_WGRAD_LAUNCH(64, 128);
-  else T2O_WGRAD_LAUNCH(64, 64);
-#undef T2O_WGRAD_LAUNCH
-  const size_t n = (size_t)Co * 9 * Ci, n4 = n / 4;
-  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(
-      a.partial, dw, n4, p.splits, n);
-  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3_wgrad launch failed");
+  return launch_wgrad(x, dy, dw, workspace, N, H, W, Ci, Co, 1, (hipStream_t)stream);
+}
+
+size_t t2o_conv3x3s2_wgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {
+  if (!wgrad_supported(N, Ho, Wo, Ci, Co) || (size_t)N * Ho * Wo * 4 + 64 >= ((size_t)1 << 31)) return 0;
+  const WgradPlan p = wgrad_plan(N, Ho, Wo, Ci, Co, 2);
+  return p.zero_bytes + sizeof(float) * (size_t)p.splits * Co * 9 * Ci;
+}
+
+int t2o_conv3x3s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                             int N, int Ho, int Wo, int Ci, int Co, void* stream) {
+  if (!x || !dy || !dw) return set_error(T2O_EINVAL, "conv3x3s2_wgrad: null pointer");
+  const size_t need = t2o_conv3x3s2_wgrad_workspace_bytes(N, Ho, Wo, Ci, Co);
+  if (need == 0)
+    return set_error(T2O_EUNSUPPORTED, "conv3x3s2_wgrad: channel counts must be multiples of 64 and the output-gradient width a multiple of 4");
+  if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "conv3x3s2_wgrad: workspace too small");
+  return launch_wgrad(x, dy, dw, workspace, N, Ho, Wo, Ci, Co, 2, (hipStream_t)stream);
 }
 
 size_t t2o_conv3x3_fwd_workspace_bytes(int N, int H, int W, int Ci, int Co) {

@@ -369,7 +369,6 @@ def param_heads(features, op_ids, heads, consts):
     return _ParamHeadsFn.apply(features, op_ids, tuple(float(v) for v in consts), *flat)
 
 
-_conv_ws = {}
 
 
 def conv3x3_wgrad(x, dy):
@@ -401,12 +400,10 @@ def _conv_workspace(device, need):
         z = _conv_zeros[idx] = torch.zeros(64 << 10, dtype=torch.uint8, device=device)
         torch.cuda.current_stream(device).synchronize()
         _lib.check(_lib.load().t2o_conv_set_zero_region(idx, _ptr(z), z.numel()), 't2o_conv_set_zero_region')
-    key = (device.index, _stream(device))
-    ws = _conv_ws.get(key)
-    if ws is None or ws.numel() < need:
-        need = max(need, int(os.environ.get('T2O_CONV_WS_MB', '0')) << 20)
-        ws = _conv_ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
-    return ws
+    # a fresh allocation per call (the caching allocator makes it cheap; inside a captured graph it costs nothing at
+    # replay).  A workspace cached per stream and grown on demand was baked into captured graphs and then freed by a
+    # later, larger request on the same stream handle -- graphs of another trainer kept replaying into freed memory.
+    return torch.empty(need, dtype=torch.uint8, device=device)
 
 
 def conv3x3_forward(x, weight):
@@ -466,6 +463,27 @@ def conv3x3s2_dgrad(dy, weight):
     return dx
 
 
+def conv3x3s2_wgrad(x, dy):
+    """Weight gradient of conv2d(x, w, None, stride 2, padding 1) (t2o_conv3x3s2_wgrad_nhwc).  x (N,Ci,2Ho,2Wo),
+    dy (N,Co,Ho,Wo), both channels-last; returns dw (Co,Ci,3,3) channels-last."""
+    _need_gpu(x, dy)
+    N, Co, Ho, Wo = dy.shape
+    Ci = x.shape[1]
+    if tuple(x.shape) != (N, Ci, 2 * Ho, 2 * Wo):
+        raise ValueError('conv3x3s2_wgrad: x must be (N, Ci, 2 Ho, 2 Wo)')
+    x = x.contiguous(memory_format=torch.channels_last)
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3s2_wgrad_workspace_bytes(N, Ho, Wo, Ci, Co)
+    if need == 0:
+        raise RuntimeError('conv3x3s2_wgrad: unsupported shape (channels must be multiples of 64, Wo a multiple of 4)')
+    ws = _conv_workspace(x.device, need)
+    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    rc = lib.t2o_conv3x3s2_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), N, Ho, Wo, Ci, Co, _stream(x.device))
+    _lib.check(rc, 't2o_conv3x3s2_wgrad_nhwc')
+    return dw
+
+
 def conv3x3s2_supported(x, weight, stride, padding):
     """The stride-2 layers whose data gradient runs on the own kernels: channels-last fp32 on the GPU, 3x3 / stride 2 /
     padding 1, even image size; either Ci a multiple of 64, Co of 32 and an output width that is a multiple of 8
@@ -493,12 +511,16 @@ class _Conv3x3S2Fn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         own = ctx.needs_input_grad[0] and 's' in _CONV_OWN
-        mask = [ctx.needs_input_grad[0] and not own, ctx.needs_input_grad[1], False]
+        own_w = (ctx.needs_input_grad[1] and 'S' in _CONV_OWN and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
+                 and dy.shape[3] % 4 == 0)
+        mask = [ctx.needs_input_grad[0] and not own, ctx.needs_input_grad[1] and not own_w, False]
         dx = dw = None
         if mask[0] or mask[1]:
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, mask)
         if own:
             dx = conv3x3s2_dgrad(dy, weight)
+        if own_w:
+            dw = conv3x3s2_wgrad(x, dy)
         return dx, dw
 
 
@@ -516,8 +538,9 @@ def conv3x3_supported(x, weight, stride, padding):
 
 
 # which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
-# 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 's' data gradient of the stride-2 layers
-_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfds')
+# 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 's' data gradient, 'S' weight gradient of the
+# stride-2 layers
+_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdsS')
 
 
 def _own_direct(x):

@@ -10,9 +10,17 @@ Different from torch.cuda.make_graphed_callables, by design:
     parameters, so the ~310 AccumulateGrad add launches per step (5 calls x 62 tensors) disappear;
   * capture runs in `thread_local` error mode: a process group's watchdog thread polling events does not
     invalidate the capture, so the data-parallel run (N > 1) keeps the graphs;
-  * batch-norm running statistics touched by the warm-up iterations are restored even when capture fails.
+  * batch-norm running statistics touched by the warm-up iterations are restored even when capture fails;
+  * every captured graph is rewritten before it is instantiated: its memset nodes become kernel nodes
+    (t2o_graph_memsets_to_kernels).  On this stack a memset node ran out of order with the kernels around it on
+    replay; the library's atomic weight-gradient solvers clear their output with hipMemsetAsync, so, depending on
+    which solver its find step picked on a box, the stem's gradients came out as garbage from the second step on.
 """
+import ctypes
+
 import torch
+
+from . import _lib
 
 
 class _Slot:
@@ -35,6 +43,15 @@ class _Replay(torch.autograd.Function):
         return (slot.static_gin.detach() if slot.needs_gin else None), None, None
 
 
+def _harden(graph):
+    """Memset nodes -> kernel nodes in the captured hipGraph, then instantiate it.  Returns the number replaced."""
+    n = ctypes.c_int(0)
+    rc = _lib.load().t2o_graph_memsets_to_kernels(ctypes.c_void_p(graph.raw_cuda_graph()), ctypes.byref(n))
+    _lib.check(rc, 't2o_graph_memsets_to_kernels')
+    graph.instantiate()                                # (keep_graph=True: not instantiated by capture_end)
+    return n.value
+
+
 class GraphedEncoder:
     """module(img) for call index k in [0, calls) as hipGraph replays.  Training mode, fixed input shape; the
     parameters' .grad tensors must exist (and stay the same tensors) -- Trainer's FlatGradients provides that."""
@@ -49,6 +66,7 @@ class GraphedEncoder:
         self._grad_ptrs = (self.grads[0].data_ptr(), self.grads[-1].data_ptr())
         # a grad-requiring scalar keeps the replay node in the autograd graph when the image itself needs no gradient
         self.anchor = torch.zeros((), device=sample_img.device, requires_grad=True)
+        self.memsets_replaced = 0                      # memset nodes of the captured graphs turned into kernel nodes
         buffers = list(module.buffers())
         saved = [t.clone() for t in buffers]
         try:
@@ -77,13 +95,14 @@ class GraphedEncoder:
             s = _Slot()
             s.needs_gin = k > 0                        # call 0 sees the input image: no gradient needed
             s.static_in = sample_img.detach().clone().requires_grad_(True)
-            s.fwd = torch.cuda.CUDAGraph()
+            s.fwd = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(s.fwd, pool=pool, capture_error_mode='thread_local'):
                 s.static_out = module(s.static_in)
+            self.memsets_replaced += _harden(s.fwd)
             slots.append(s)
         for s in reversed(slots):
             s.static_gout = torch.zeros_like(s.static_out)
-            s.bwd = torch.cuda.CUDAGraph()
+            s.bwd = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(s.bwd, pool=pool, capture_error_mode='thread_local'):
                 wrt = ([s.static_in] if s.needs_gin else []) + params
                 g = torch.autograd.grad((s.static_out,), wrt, (s.static_gout,), allow_unused=True)
@@ -93,6 +112,7 @@ class GraphedEncoder:
                     s.static_gin = None
                 have = [(acc, gi) for acc, gi in zip(self.grads, g) if gi is not None]
                 torch._foreach_add_([a for a, _ in have], [b for _, b in have])
+            self.memsets_replaced += _harden(s.bwd)
         for s in slots:
             # keep the buffers, drop the autograd graph: it holds the parameters' AccumulateGrad nodes, which were
             # created on the capture stream -- an eager encoder call reusing them would add into .grad on THAT

@@ -419,10 +419,48 @@ def test_graphed_training_stays_on_the_eager_trajectory():
         model = copy.deepcopy(base)
         tr = Trainer(model, opt, graph_encoder=graph)
         torch.manual_seed(22)
-        losses = [float(tr.episode_step(x, img, tgt, lengths=lengths)) for _ in range(5)]
+        losses = []
+        for step in range(5):
+            losses.append(float(tr.episode_step(x, img, tgt, lengths=lengths)))
+            bad = [n for n, p in model.named_parameters() if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
+            assert not bad, (graph, step, losses, bad[:6], len(bad))
         assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), (graph, losses)
         if graph:
             assert '_graphed_encoders' in model.__dict__ and tr.graph_encoder
         runs[graph] = losses
-    np.testing.assert_allclose(runs[True], runs[False], rtol=0, atol=5e-3)
-    assert runs[False][-1] < runs[False][0]                    # (and it trains)
+    # the library's remaining atomic kernels make two EAGER runs differ by ~4e-4 at step 2 and (sampled operators flip)
+    # by ~1e-2 from step 3 on: two steps are held tightly, the rest to the trajectory's own spread
+    np.testing.assert_allclose(runs[True][:2], runs[False][:2], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(runs[True], runs[False], rtol=0, atol=4e-2)
+    assert runs[False][-1] < runs[False][0] and runs[True][-1] < runs[True][0]      # (and it trains)
+
+
+@pytest.mark.gpu
+def test_graph_memset_nodes_become_kernel_nodes():
+    """t2o_graph_memsets_to_kernels on a captured graph: kernel -> hipMemsetAsync (part of the buffer) -> kernel.  The
+    rewritten graph has no memset node left, keeps the order (the fill runs between the two kernels) and the values
+    (1-, 2- and 4-byte patterns)."""
+    import ctypes
+    from t2onet_amd import graphs
+    dev = torch.device('cuda:0')
+    hip = ctypes.CDLL('libamdhip64.so')
+    buf = torch.zeros(4096, dtype=torch.int32, device=dev)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        buf.fill_(7)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        assert hip.hipMemsetAsync(ctypes.c_void_p(buf.data_ptr() + 4 * 1024), 0xAB, ctypes.c_size_t(4 * 1024), st) == 0
+        assert hip.hipMemsetD32Async(ctypes.c_void_p(buf.data_ptr() + 4 * 3072), 5, ctypes.c_size_t(512), st) == 0
+        buf.add_(1)
+    assert graphs._harden(g) == 2
+    assert graphs._harden.__doc__
+    for _ in range(3):
+        buf.fill_(-1)
+        junk = torch.full((1 << 20,), 3, device=dev)
+        del junk
+        g.replay()
+        torch.cuda.synchronize()
+        expect = torch.full((4096,), 8, dtype=torch.int32)
+        expect[1024:2048] = int(np.array([0xABABABAB], dtype=np.uint32).view(np.int32)[0]) + 1
+        expect[3072:3584] = 6
+        assert torch.equal(buf.cpu(), expect)

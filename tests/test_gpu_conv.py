@@ -135,6 +135,25 @@ def test_stride2_dgrad_matches_conv2d_fp64(shape):
     np.testing.assert_allclose(dx.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 64, 8, 8), (3, 64, 128, 5, 12), (1, 128, 64, 3, 4), (2, 64, 64, 33, 20), (1, 128, 256, 2, 40), (2, 64, 64, 5, 64)])
+def test_stride2_wgrad_matches_conv2d_fp64(shape):
+    import t2onet_amd.functional as T
+    N, Ci, Co, Ho, Wo = shape
+    x = synth.uniform((N, Ci, 2 * Ho, 2 * Wo), 771, -1.0, 1.0)
+    dy = synth.uniform((N, Co, Ho, Wo), 772, -1.0, 1.0)
+    w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(x.double(), w64, None, 2, 1) * dy.double()).sum().backward()
+    ref = w64.grad
+    dev = torch.device('cuda:0')
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    dg = dy.to(dev).contiguous(memory_format=torch.channels_last)
+    dw = T.conv3x3s2_wgrad(xg, dg)
+    assert dw.shape == (Co, Ci, 3, 3) and dw.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+    assert torch.equal(dw, T.conv3x3s2_wgrad(xg, dg))
+
+
 def test_stride2_autograd_function_matches_library():
     import t2onet_amd.functional as T
     dev = torch.device('cuda:0')
@@ -165,7 +184,8 @@ def test_kernels_inside_replayed_graphs():
     gy = torch.randn(16, c, h, h, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     gy2 = torch.randn(16, c, h // 2, h // 2, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     fns = {'fwd': lambda: T.conv3x3_forward(x, w), 'dgrad': lambda: T.conv3x3_dgrad(gy, w),
-           'wgrad': lambda: T.conv3x3_wgrad(x, gy), 's2': lambda: T.conv3x3s2_dgrad(gy2, w)}
+           'wgrad': lambda: T.conv3x3_wgrad(x, gy), 's2': lambda: T.conv3x3s2_dgrad(gy2, w),
+           's2w': lambda: T.conv3x3s2_wgrad(x, gy2)}
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -191,7 +211,8 @@ def test_kernels_inside_replayed_graphs():
             graphs[name].replay()
         torch.cuda.synchronize()
         ref = {'fwd': torch.nn.functional.conv2d(x, w, None, 1, 1), 'dgrad': lib_bwd(gy, 1, [True, False, False])[0],
-               'wgrad': lib_bwd(gy, 1, [False, True, False])[1], 's2': lib_bwd(gy2, 2, [True, False, False])[0]}
+               'wgrad': lib_bwd(gy, 1, [False, True, False])[1], 's2': lib_bwd(gy2, 2, [True, False, False])[0],
+               's2w': lib_bwd(gy2, 2, [False, True, False])[1]}
         for name in fns:
             err = float((outs[name] - ref[name]).abs().max() / ref[name].abs().max())
             assert err < 2e-5, (trial, name, err)

@@ -32,9 +32,9 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 200; ++rep) {                       // ~40 ms of back-to-back launches before the reading that counts
     if (rep == 199) hipEventRecord(e0);
-    if (p.tm == 128 && p.tn == 128) k_conv3x3_wgrad<128, 128, 2><<<grid, kConvThreads>>>(a);
-    else if (p.tm == 128) k_conv3x3_wgrad<128, 64, 2><<<grid, kConvThreads>>>(a);
-    else k_conv3x3_wgrad<64, 64, 2><<<grid, kConvThreads>>>(a);
+    if (p.tm == 128 && p.tn == 128) k_conv3x3_wgrad<128, 128, 2, 1><<<grid, kConvThreads>>>(a);
+    else if (p.tm == 128) k_conv3x3_wgrad<128, 64, 2, 1><<<grid, kConvThreads>>>(a);
+    else k_conv3x3_wgrad<64, 64, 2, 1><<<grid, kConvThreads>>>(a);
     if (rep == 199) hipEventRecord(e1);
   }
   hipEventSynchronize(e1);
