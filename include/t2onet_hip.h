@@ -221,6 +221,13 @@ size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream);
 
+/* ---- forward of the stride-2 3x3 convolutions (F.conv2d(x, w, None, 2, 1), models/actor_resnet.py:32-36 with stride 2):
+ *   y[n][a][b][co] = sum_{kh,kw,ci} x[n][2a+kh-1][2b+kw-1][ci] * w[co][kh][kw][ci]      (zero padding)
+ *   x (N,2Ho,2Wo,Ci), w (Co,3,3,Ci), y (N,Ho,Wo,Co).  Ci % 32 == 0, Co % 64 == 0, Wo % 8 == 0. */
+size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co);
+int t2o_conv3x3s2_fwd_nhwc(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes,
+                           int N, int Ho, int Wo, int Ci, int Co, void* stream);
+
 /* ---- weight gradient of the same stride-2 convolutions (t2o_conv.hip, the stride-1 kernel with a two-plane x tile):
  *   dw[co][kh][kw][ci] = sum_{n,a,b} dy[n][a][b][co] * x[n][2a+kh-1][2b+kw-1][ci]   (zero padding)
  *   x (N,2Ho,2Wo,Ci), dy (N,Ho,Wo,Co), dw (Co,3,3,Ci).  Ci, Co multiples of 64, Wo a multiple of 4.  Deterministic

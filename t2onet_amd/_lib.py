@@ -64,6 +64,8 @@ SIGNATURES = {
     't2o_conv3x3_dgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3_dgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv_set_zero_region': (_I, [_I, _P, _Z]),
+    't2o_conv3x3s2_fwd_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
+    't2o_conv3x3s2_fwd_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3s2_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_dgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),

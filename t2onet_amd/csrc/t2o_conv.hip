@@ -430,12 +430,16 @@ constexpr int kFwdWBuf = 3 * kFwdCo * 128;                      // [kw][co][32 c
 
 // kBM: MFMA blocks per wave along the pixels; the workgroup takes 128 * kBM consecutive pixels (2: the normal tile;
 // 1: layers whose 256-pixel tiles would leave CUs idle)
-template <int kBM>
+// kS = 2: the forward of a STRIDE-2 convolution.  a.H, a.W are then the OUTPUT grid (x is 2H x 2W) and the x tile is
+// two planes, as in the stride-2 weight gradient: the even input columns 2 beta (kw = 1) and the odd ones 2 beta + 1
+// (kw = 2, and kw = 0 one output pixel to the left).
+template <int kBM, int kS = 1>
 __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   constexpr int kFwdPix = 128 * kBM;                              // output pixels per workgroup
   constexpr int kFwdXPieces = (kFwdPix + 2 * kFwdHalo) / 8;       // pieces of 8 rows (34 / 18)
-  constexpr int kFwdXBuf = (kFwdXPieces + 1) * 1024;              // + one piece of zero rows
-  constexpr int kFwdZeroRow = kFwdXPieces * 8;
+  constexpr int kFwdPlane = kFwdXPieces * 1024;                   // one plane of the x tile
+  constexpr int kFwdXBuf = (kS * kFwdXPieces + 1) * 1024;         // kS planes + one piece of zero rows
+  constexpr int kFwdZeroRow = kS * kFwdXPieces * 8;
   __shared__ __attribute__((aligned(16))) char Xs[2][kFwdXBuf];
   __shared__ __attribute__((aligned(16))) char Ws[2][kFwdWBuf];
 
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   // position ^ swizzle(row); rows of this wave's pieces are 8 * (wave + 8 i) + l / 8: the swizzle does not depend on i
   const int prow = lane >> 3, ppos = lane & 7;
   const int pswz = ((wave * 8 + prow) >> 1) & 7;
-  const unsigned lane_x = (unsigned)(prow * a.Ci * 4 + ((ppos ^ pswz) << 4));
+  const unsigned lane_x = (unsigned)(prow * kS * a.Ci * 4 + ((ppos ^ pswz) << 4));      // (stride 2: consecutive tile rows are two input pixels apart)
   const unsigned lane_w = (unsigned)(prow * 9 * a.Ci * 4 + ((ppos ^ pswz) << 4));    // (w tile rows 64 kw + 8 wave + l / 8)
   int mrow[NXW];                                          // (first pixel of the piece) mod (H * W): the image row it is in
 #pragma unroll
@@ -476,28 +480,38 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
     mrow[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(p0 - kFwdHalo + (wave + 8 * i) * 8 + HW) % (unsigned)HW));
   const long long xrow = (long long)a.Ci * 4;
   const char* const x0 = (const char*)a.x + ((long long)p0 - kFwdHalo + wave * 8) * xrow;       // this wave's first piece, kh = 1, ci = 0
+  // stride 2: input pixel index of output pixel q = (t, beta): 4 q - 2 beta + (kh - 1) 2 W + plane
+  int bcol[kS == 2 ? NXW : 1];
+  if constexpr (kS == 2) {
+#pragma unroll
+    for (int i = 0; i < NXW; ++i)
+      bcol[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(p0 - kFwdHalo + (wave + 8 * i) * 8 + HW) % (unsigned)a.W));
+  }
   const char* const w0 = (const char*)a.w + (long long)(co0 + wave * 8) * 9 * xrow;            // its w rows, tap 0, ci = 0
   const int chunks = a.Ci / 32, stages = 3 * chunks;
   // stage st = kh * chunks + cc
   auto dma_piece = [&](auto jc, int buf, int kh, int cc) {
     constexpr int j = decltype(jc)::value;
-    if constexpr (j < NXW) {
-      const int piece = wave + 8 * j;
+    if constexpr (j < kS * NXW) {
+      constexpr int jx = j % NXW, plane = j / NXW;
+      const int piece = wave + 8 * jx;
       if (piece < kFwdXPieces) {                           // wave-uniform
         const int q0 = p0 - kFwdHalo + piece * 8;          // output pixel of the piece's first row
         const int dh = kh - 1;
-        const int lo = dh < 0 ? a.W : 0, span = dh == 0 ? HW : HW - a.W;
-        const bool ok = (unsigned)q0 < (unsigned)P && (unsigned)(mrow[j] - lo) < (unsigned)span;
-        const char* src = x0 + ((long long)j * 64 + (long long)dh * a.W) * xrow + cc * 128;
-        glds16(lane_x, ok ? src : (const char*)a.zero, lds_x + (unsigned)(buf * kFwdXBuf + piece * 1024));
+        const int lo = dh < 0 ? a.W : 0, span = (dh == 0 || (kS == 2 && dh > 0)) ? HW : HW - a.W;     // (stride 2: row 2 alpha + 1 always exists)
+        const bool ok = (unsigned)q0 < (unsigned)P && (unsigned)(mrow[jx] - lo) < (unsigned)span;
+        const char* src;
+        if constexpr (kS == 1) src = x0 + ((long long)jx * 64 + (long long)dh * a.W) * xrow + cc * 128;
+        else src = (const char*)a.x + ((long long)4 * q0 - 2 * bcol[jx] + (long long)dh * 2 * a.W + plane) * xrow + cc * 128;
+        glds16(lane_x, ok ? src : (const char*)a.zero, lds_x + (unsigned)(buf * kFwdXBuf + plane * kFwdPlane + piece * 1024));
       }
     } else {
-      constexpr int kw = j - NXW;
+      constexpr int kw = j - kS * NXW;
       const char* src = w0 + (long long)(kh * 3 + kw) * xrow + cc * 128;
       glds16(lane_w, src, lds_w + (unsigned)(buf * kFwdWBuf + (kw * 8 + wave) * 1024));
     }
   };
-  constexpr int NPW = NXW + 3;                             // pieces per wave and stage
+  constexpr int NPW = kS * NXW + 3;                        // pieces per wave and stage
 #ifndef T2O_FWD_DMA_GROUPS
 #define T2O_FWD_DMA_GROUPS 2
 #endif
@@ -511,8 +525,10 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
     for (int i = 0; i < kBM; ++i) {
       const int pl = wm * 32 * kBM + i * 32 + ln;          // pixel inside the tile
       const int wcol = (int)((unsigned)(p0 + pl) % (unsigned)a.W);
-      const bool outside = (kw == 0 && wcol == 0) || (kw == 2 && wcol == a.W - 1);
-      const int row = outside ? kFwdZeroRow : kFwdHalo + pl + kw - 1;
+      // stride 1: row of pixel + (kw - 1); stride 2: kw = 0 -> odd plane one pixel to the left, 1 -> even plane, 2 -> odd plane
+      const bool outside = (kw == 0 && wcol == 0) || (kS == 1 && kw == 2 && wcol == a.W - 1);
+      const int inrow = kS == 1 ? kFwdHalo + pl + kw - 1 : (kw == 1 ? 0 : kFwdXPieces * 8) + kFwdHalo + pl - (kw == 0 ? 1 : 0);
+      const int row = outside ? kFwdZeroRow : inrow;
 #pragma unroll
       for (int g = 0; g < 4; ++g) xa[kw][i][g] = (unsigned)(row * 128 + (((2 * g + lh) ^ ((row >> 1) & 7)) << 4));
     }
@@ -524,8 +540,8 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 
   // the zero rows of both x buffers (never written again)
   if (wave == 0) {
-    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kFwdXPieces * 1024));
-    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kFwdXBuf + kFwdXPieces * 1024));
+    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kS * kFwdPlane));
+    glds16((unsigned)(lane * 16), a.zero, lds_x + (unsigned)(kFwdXBuf + kS * kFwdPlane));
   }
 
   float4 fa[2][3][kBM], fb[2][3];
@@ -901,7 +917,8 @@ bool fwd_supported(int N, int H, int W, int Ci, int Co) {
 
 size_t fwd_zero_bytes(int Ci) { return ((size_t)8 * Ci * 4 + 1024 + 255) / 256 * 256; }
 
-int launch_fwd(const float* x, const float* w, float* y, const float* zero, int N, int H, int W, int Ci, int Co, hipStream_t st) {
+int launch_fwd(const float* x, const float* w, float* y, const float* zero, int N, int H, int W, int Ci, int Co, hipStream_t st,
+               int stride = 1) {
   FwdArgs a;
   a.x = x; a.w = w; a.y = y; a.zero = zero;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
@@ -910,11 +927,12 @@ int launch_fwd(const float* x, const float* w, float* y, const float* zero, int 
   // 256-pixel tiles unless they would fill less than one round of workgroups (one per CU) that 128-pixel tiles fill better
   static const int force_bm = conv_env("T2O_FWD_BM", 0);
   const int wg256 = ((P + 255) / 256) * a.tiles_n;
-  const int bm = force_bm == 1 || force_bm == 2 ? force_bm : (wg256 < 256 ? 1 : 2);
+  const int bm = stride == 2 ? 1 : (force_bm == 1 || force_bm == 2 ? force_bm : (wg256 < 256 ? 1 : 2));      // (stride 2: two x planes, 128-pixel tiles)
   a.tiles_p = (P + 128 * bm - 1) / (128 * bm);
   a.stamps = nullptr;
   const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
-  if (bm == 1) k_conv3x3_fwd<1><<<grid, kFwdThreads, 0, st>>>(a);
+  if (stride == 2) k_conv3x3_fwd<1, 2><<<grid, kFwdThreads, 0, st>>>(a);
+  else if (bm == 1) k_conv3x3_fwd<1><<<grid, kFwdThreads, 0, st>>>(a);
   else k_conv3x3_fwd<2><<<grid, kFwdThreads, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : T2O_ELAUNCH;
 }
@@ -1040,6 +1058,21 @@ int t2o_conv3x3_fwd_nhwc(const float* x, const float* w, float* y, void* workspa
   hipStream_t st = (hipStream_t)stream;
   const int rc = launch_fwd(x, w, y, zero_region(workspace, fwd_zero_bytes(Ci), st), N, H, W, Ci, Co, st);
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_fwd launch failed");
+}
+
+size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {
+  return (fwd_supported(N, Ho, Wo, Ci, Co) && (size_t)N * Ho * Wo * 4 + 1024 < ((size_t)1 << 31)) ? fwd_zero_bytes(2 * Ci) : 0;
+}
+
+int t2o_conv3x3s2_fwd_nhwc(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes,
+                           int N, int Ho, int Wo, int Ci, int Co, void* stream) {
+  if (!x || !w || !y) return set_error(T2O_EINVAL, "conv3x3s2_fwd: null pointer");
+  const size_t need = t2o_conv3x3s2_fwd_workspace_bytes(N, Ho, Wo, Ci, Co);
+  if (need == 0) return set_error(T2O_EUNSUPPORTED, "conv3x3s2_fwd: Ci must be a multiple of 32, Co of 64, the output width of 8");
+  if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "conv3x3s2_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = launch_fwd(x, w, y, zero_region(workspace, need, st), N, Ho, Wo, Ci, Co, st, 2);
+  return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3s2_fwd launch failed");
 }
 
 size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co) {

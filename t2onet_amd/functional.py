@@ -463,6 +463,28 @@ def conv3x3s2_dgrad(dy, weight):
     return dx
 
 
+def conv3x3s2_forward(x, weight):
+    """conv2d(x, weight, None, stride 2, padding 1) for an even-sized x (t2o_conv3x3s2_fwd_nhwc).  x (N,Ci,2Ho,2Wo)
+    and weight (Co,Ci,3,3) channels-last; returns y (N,Co,Ho,Wo) channels-last."""
+    _need_gpu(x, weight)
+    N, Ci, Hi, Wi = x.shape
+    Co = weight.shape[0]
+    if Hi % 2 or Wi % 2:
+        raise ValueError('conv3x3s2_forward: the image size must be even')
+    Ho, Wo = Hi // 2, Wi // 2
+    x = x.contiguous(memory_format=torch.channels_last)
+    weight = weight.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3s2_fwd_workspace_bytes(N, Ho, Wo, Ci, Co)
+    if need == 0:
+        raise RuntimeError('conv3x3s2_forward: unsupported shape (Ci % 32, Co % 64, Wo % 8 must be 0)')
+    ws = _conv_workspace(x.device, need)
+    y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    rc = lib.t2o_conv3x3s2_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(ws), ws.numel(), N, Ho, Wo, Ci, Co, _stream(x.device))
+    _lib.check(rc, 't2o_conv3x3s2_fwd_nhwc')
+    return y
+
+
 def conv3x3s2_wgrad(x, dy):
     """Weight gradient of conv2d(x, w, None, stride 2, padding 1) (t2o_conv3x3s2_wgrad_nhwc).  x (N,Ci,2Ho,2Wo),
     dy (N,Co,Ho,Wo), both channels-last; returns dw (Co,Ci,3,3) channels-last."""
@@ -498,12 +520,14 @@ def conv3x3s2_supported(x, weight, stride, padding):
 
 
 class _Conv3x3S2Fn(torch.autograd.Function):
-    """conv2d(x, w, 3x3, stride 2, padding 1): forward and weight gradient are library calls, the data gradient the
-    hand-written kernel ('s' in T2O_OWN_CONV)."""
+    """conv2d(x, w, 3x3, stride 2, padding 1) on the hand-written kernels: 'F' forward, 's' data gradient, 'S' weight
+    gradient in T2O_OWN_CONV (the 3-channel stem: only its data gradient; the rest are library calls)."""
 
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        if ('F' in _CONV_OWN and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0 and x.shape[3] % 16 == 0):
+            return conv3x3s2_forward(x, weight)
         return torch.nn.functional.conv2d(x, weight, None, 2, 1)
 
     @staticmethod
@@ -538,9 +562,9 @@ def conv3x3_supported(x, weight, stride, padding):
 
 
 # which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
-# 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 's' data gradient, 'S' weight gradient of the
-# stride-2 layers
-_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdsS')
+# 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 'F' forward, 's' data gradient, 'S' weight
+# gradient of the stride-2 layers
+_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdFsS')
 
 
 def _own_direct(x):

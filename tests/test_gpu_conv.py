@@ -135,6 +135,21 @@ def test_stride2_dgrad_matches_conv2d_fp64(shape):
     np.testing.assert_allclose(dx.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 64, 8, 8), (3, 64, 128, 5, 16), (1, 128, 64, 3, 24), (2, 32, 64, 1, 8), (2, 128, 256, 20, 8), (1, 64, 64, 2, 136)])
+def test_stride2_forward_matches_conv2d_fp64(shape):
+    import t2onet_amd.functional as T
+    N, Ci, Co, Ho, Wo = shape
+    x = synth.uniform((N, Ci, 2 * Ho, 2 * Wo), 781, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 782, -1.0, 1.0)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 1)
+    dev = torch.device('cuda:0')
+    y = T.conv3x3s2_forward(x.to(dev).contiguous(memory_format=torch.channels_last),
+                            w.to(dev).contiguous(memory_format=torch.channels_last))
+    assert y.shape == (N, Co, Ho, Wo) and y.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 64, 8, 8), (3, 64, 128, 5, 12), (1, 128, 64, 3, 4), (2, 64, 64, 33, 20), (1, 128, 256, 2, 40), (2, 64, 64, 5, 64)])
 def test_stride2_wgrad_matches_conv2d_fp64(shape):
     import t2onet_amd.functional as T
@@ -185,7 +200,7 @@ def test_kernels_inside_replayed_graphs():
     gy2 = torch.randn(16, c, h // 2, h // 2, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     fns = {'fwd': lambda: T.conv3x3_forward(x, w), 'dgrad': lambda: T.conv3x3_dgrad(gy, w),
            'wgrad': lambda: T.conv3x3_wgrad(x, gy), 's2': lambda: T.conv3x3s2_dgrad(gy2, w),
-           's2w': lambda: T.conv3x3s2_wgrad(x, gy2)}
+           's2w': lambda: T.conv3x3s2_wgrad(x, gy2), 's2f': lambda: T.conv3x3s2_forward(x, w)}
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -212,7 +227,7 @@ def test_kernels_inside_replayed_graphs():
         torch.cuda.synchronize()
         ref = {'fwd': torch.nn.functional.conv2d(x, w, None, 1, 1), 'dgrad': lib_bwd(gy, 1, [True, False, False])[0],
                'wgrad': lib_bwd(gy, 1, [False, True, False])[1], 's2': lib_bwd(gy2, 2, [True, False, False])[0],
-               's2w': lib_bwd(gy2, 2, [False, True, False])[1]}
+               's2w': lib_bwd(gy2, 2, [False, True, False])[1], 's2f': torch.nn.functional.conv2d(x, w, None, 2, 1)}
         for name in fns:
             err = float((outs[name] - ref[name]).abs().max() / ref[name].abs().max())
             assert err < 2e-5, (trial, name, err)

@@ -64,6 +64,13 @@ if 's' in DIRS:
         print('%-6s dgrad %6.2f GFLOP  MIOpen %.3f ms (%6.1f TF/s)   own %.3f ms (%6.1f TF/s)   x%.2f   rel err vs MIOpen %.1e' % (
             name, gf, t_lib, gf / t_lib, t_own, gf / t_own, t_lib / t_own, err), flush=True)
         if ci % 64 == 0:
+            lib = lambda: torch.nn.functional.conv2d(x, w, None, 2, 1)
+            own = lambda: T.conv3x3s2_forward(x, w)
+            t_lib, t_own = timeit(lib), timeit(own)
+            ref = lib()
+            err = ((own() - ref).abs().max() / ref.abs().max()).item()
+            print('%-6s fwd   %6.2f GFLOP  MIOpen %.3f ms (%6.1f TF/s)   own %.3f ms (%6.1f TF/s)   x%.2f   rel err vs MIOpen %.1e' % (
+                name, gf, t_lib, gf / t_lib, t_own, gf / t_own, t_lib / t_own, err), flush=True)
             lib = lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
             own = lambda: T.conv3x3s2_wgrad(x, gy)
             t_lib, t_own = timeit(lib), timeit(own)
