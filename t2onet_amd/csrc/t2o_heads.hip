@@ -2,7 +2,8 @@
 // (models/operators.py:73-88 extract_parameters = op_param_regressor(fc2(LeakyReLU(fc1(features)))), called per
 // operator group by models/actor.py:244-255).  The reference runs 2 small GEMMs + ~5 elementwise kernels per group
 // (and as many again, twice, in the backward); the batched PyTorch form of that costs ~150 launches per decoder step.
-// Here: one forward launch (one workgroup per sample evaluates ITS operator's head) and two backward launches.
+// Here: two forward launches (each sample evaluates ITS operator's head: fc1 dealt over 8 workgroups per sample, then
+// fc2 + regressor) and two backward launches.
 //
 //   hidden_b = lrelu(W1[op_b] ctx_b + b1[op_b])      W1 (512,512), slope 0.01
 //   raw_b    = W2[op_b] hidden_b + b2[op_b]          W2 (n_op, 512), n_op in {1, 8, 24}
@@ -93,25 +94,41 @@ __device__ __forceinline__ float regress_grad(const HeadArgs& a, int op, float f
   }
 }
 
-__global__ __launch_bounds__(kHT) void k_heads_fwd(HeadArgs a) {
+constexpr int kSlices = 8;          // one sample's fc1 rows (forward) / W1 columns (backward) are dealt to this many workgroups
+constexpr int kSliceW = kD / kSlices;
+
+// fc1 + LeakyReLU.  blockIdx.x = sample, blockIdx.y = 64-row slice of its operator's W1: 8 x B workgroups stream
+// the 1 MB weight of each selected head instead of B (64 workgroups leave three quarters of the chip idle).
+__global__ __launch_bounds__(kHT) void k_heads_fc1(HeadArgs a) {
   __shared__ __attribute__((aligned(16))) float ctx[kD];
-  __shared__ __attribute__((aligned(16))) float hid[kD];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int op = a.op_id[b];
+  float* hid = a.hidden + (size_t)b * kD + sl * kSliceW;
   if (!has_head(op)) {
-    if (tid < kPad) { a.param[(size_t)b * kPad + tid] = 0.0f; a.raw[(size_t)b * kPad + tid] = 0.0f; }
-    for (int i = tid; i < kD; i += kHT) a.hidden[(size_t)b * kD + i] = 0.0f;
+    if (tid < kSliceW) hid[tid] = 0.0f;
+    if (sl == 0 && tid < kPad) { a.param[(size_t)b * kPad + tid] = 0.0f; a.raw[(size_t)b * kPad + tid] = 0.0f; }
     return;
   }
   for (int i = tid; i < kD; i += kHT) ctx[i] = a.ctx[(size_t)b * kD + i];
   __syncthreads();
-  const float* w1 = a.w1[op];
-  for (int j = wave; j < kD; j += kHT / 64) {
-    const float s = row_dot(w1 + (size_t)j * kD, ctx, lane) + a.b1[op][j];
-    if (lane == 0) hid[j] = s > 0.0f ? s : 0.01f * s;
+  constexpr int kRows = kSliceW / (kHT / 64);                  // rows per wave
+  const int j0 = sl * kSliceW + wave * kRows;
+  const float* w1 = a.w1[op] + (size_t)j0 * kD;
+#pragma unroll 4
+  for (int k = 0; k < kRows; ++k) {
+    const float s = row_dot(w1 + (size_t)k * kD, ctx, lane) + a.b1[op][j0 + k];
+    if (lane == 0) hid[wave * kRows + k] = s > 0.0f ? s : 0.01f * s;
   }
+}
+
+// fc2 + the operator's parameter regressor.  One workgroup per sample.
+__global__ __launch_bounds__(kHT) void k_heads_fc2(HeadArgs a) {
+  __shared__ __attribute__((aligned(16))) float hid[kD];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int op = a.op_id[b];
+  if (!has_head(op)) return;                                   // (k_heads_fc1 wrote the zeros)
+  for (int i = tid; i < kD; i += kHT) hid[i] = a.hidden[(size_t)b * kD + i];
   __syncthreads();
-  for (int i = tid; i < kD; i += kHT) a.hidden[(size_t)b * kD + i] = hid[i];
   const int n = n_params(op);
   for (int r = wave; r < kPad; r += kHT / 64) {
     float f = 0.0f, p = 0.0f;
@@ -123,14 +140,17 @@ __global__ __launch_bounds__(kHT) void k_heads_fwd(HeadArgs a) {
   }
 }
 
-// per sample: dpre_b (gradient at fc1's pre-activation) and gctx_b = W1^T dpre_b
+// per sample: dpre_b (gradient at fc1's pre-activation) and gctx_b = W1^T dpre_b.  blockIdx.x = sample, blockIdx.y =
+// 64-column slice of gctx; every slice recomputes the sample's dpre (512 x n multiply-adds) rather than wait for it.
 __global__ __launch_bounds__(kHT) void k_heads_bwd_sample(HeadArgs a) {
   __shared__ float df[kPad];
   __shared__ __attribute__((aligned(16))) float dp[kD];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float red[16][kSliceW];
+  const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const int op = a.op_id[b];
+  const size_t slice = (size_t)b * kD + sl * kSliceW;
   if (!has_head(op)) {
-    for (int i = tid; i < kD; i += kHT) { a.dpre[(size_t)b * kD + i] = 0.0f; a.gctx[(size_t)b * kD + i] = 0.0f; }
+    if (tid < kSliceW) { a.dpre[slice + tid] = 0.0f; a.gctx[slice + tid] = 0.0f; }
     return;
   }
   const int n = n_params(op);
@@ -140,40 +160,56 @@ __global__ __launch_bounds__(kHT) void k_heads_bwd_sample(HeadArgs a) {
     float s = 0.0f;
     for (int r = 0; r < n; ++r) s += a.w2[op][(size_t)r * kD + i] * df[r];
     const float h = a.hidden[(size_t)b * kD + i];
-    const float d = h > 0.0f ? s : 0.01f * s;
-    dp[i] = d;
-    a.dpre[(size_t)b * kD + i] = d;
+    dp[i] = h > 0.0f ? s : 0.01f * s;
   }
   __syncthreads();
-  const float* w1 = a.w1[op];
-  for (int i = tid; i < kD; i += kHT) {                        // gctx_i = sum_j W1[j][i] dpre_j (threads walk a row: coalesced)
-    float s = 0.0f;
+  if (tid < kSliceW) a.dpre[slice + tid] = dp[sl * kSliceW + tid];
+  // gctx_i = sum_j W1[j][i] dpre_j over this slice's columns: 16 lanes x float4 span the 64 columns, the 16 lane
+  // groups take 32 rows each, partial sums meet in LDS in a fixed order
+  const int cq = tid & 15, rp = tid >> 4;
+  const float* w1 = a.w1[op] + (size_t)(rp * 32) * kD + sl * kSliceW + 4 * cq;
+  float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll 8
-    for (int j = 0; j < kD; ++j) s += w1[(size_t)j * kD + i] * dp[j];
-    a.gctx[(size_t)b * kD + i] = s;
+  for (int j = 0; j < 32; ++j) {
+    const float4 w = *reinterpret_cast<const float4*>(w1 + (size_t)j * kD);
+    const float d = dp[rp * 32 + j];
+    s.x += w.x * d; s.y += w.y * d; s.z += w.z * d; s.w += w.w * d;
+  }
+  *reinterpret_cast<float4*>(&red[rp][4 * cq]) = s;
+  __syncthreads();
+  if (tid < kSliceW) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][tid];
+    a.gctx[slice + tid] = t;
   }
 }
 
 // weight gradients.  blockIdx.y = operator; blockIdx.x < 64: a 64x64 tile of gW1 (+ gb1 on the first tile column);
-// blockIdx.x == 64: gW2 and gb2.  Samples are visited in batch order: deterministic sums.
+// blockIdx.x >= 64: a 64-column slice of gW2 (+ gb2 on the first).  Samples are visited in batch order:
+// deterministic sums.  The operator's samples are found 64 at a time with one ballot.
 __global__ __launch_bounds__(kHT) void k_heads_bwd_weights(HeadArgs a) {
-  const int op = blockIdx.y, tid = threadIdx.x;
+  const int op = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   if (op == 4) return;
   if (blockIdx.x < 64) {
     const int tr = (blockIdx.x / 8) * 64, tc = (blockIdx.x % 8) * 64;     // rows = output units (dpre), cols = inputs (ctx)
     const int r0 = tr + (tid / 16) * 4, c0 = tc + (tid % 16) * 4;
     float acc[4][4] = {};
     float accb[4] = {};
-    for (int b = 0; b < a.B; ++b) {
-      if (a.op_id[b] != op) continue;                                      // uniform branch
-      const float4 d = *reinterpret_cast<const float4*>(a.dpre + (size_t)b * kD + r0);
-      const float4 c = *reinterpret_cast<const float4*>(a.ctx + (size_t)b * kD + c0);
-      const float dv[4] = {d.x, d.y, d.z, d.w}, cv[4] = {c.x, c.y, c.z, c.w};
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+      unsigned long long m = __ballot(b0 + lane < a.B && a.op_id[min(b0 + lane, a.B - 1)] == op);
+      while (m) {                                                          // uniform
+        const int b = b0 + __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float4 d = *reinterpret_cast<const float4*>(a.dpre + (size_t)b * kD + r0);
+        const float4 c = *reinterpret_cast<const float4*>(a.ctx + (size_t)b * kD + c0);
+        const float dv[4] = {d.x, d.y, d.z, d.w}, cv[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        accb[i] += dv[i];
+        for (int i = 0; i < 4; ++i) {
+          accb[i] += dv[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += dv[i] * cv[j];
+          for (int j = 0; j < 4; ++j) acc[i][j] += dv[i] * cv[j];
+        }
       }
     }
 #pragma unroll
@@ -184,25 +220,36 @@ __global__ __launch_bounds__(kHT) void k_heads_bwd_weights(HeadArgs a) {
       for (int i = 0; i < 4; ++i) a.gb1[op][r0 + i] = accb[i];
     }
   } else {
-    const int n = n_params(op);
-    for (int e = tid; e < n * kD; e += kHT) {
-      const int r = e / kD, i = e % kD;
-      float s = 0.0f;
-      for (int b = 0; b < a.B; ++b) {
-        if (a.op_id[b] != op) continue;
-        const float f = a.raw[(size_t)b * kPad + r];
-        s += a.gparam[(size_t)b * kPad + r] * regress_grad(a, op, f) * a.hidden[(size_t)b * kD + i];
+    __shared__ float df[64][kPad];                                         // gparam * regressor' of 64 samples (0: not this operator's)
+    const int sl = blockIdx.x - 64, n = n_params(op);
+    const int i = sl * kSliceW + lane, ph = tid >> 6;                      // thread: column i, rows ph, ph + 4, ...
+    float acc[kPad / 4] = {};
+    float accb = 0.0f;
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+      const unsigned long long m0 = __ballot(b0 + lane < a.B && a.op_id[min(b0 + lane, a.B - 1)] == op);
+      if (m0 == 0) continue;                                               // uniform
+      __syncthreads();
+      for (int e = tid; e < 64 * kPad; e += kHT) {
+        const int bl = e / kPad, r = e % kPad, b = b0 + bl;
+        float v = 0.0f;
+        if (((m0 >> bl) & 1) && r < n) v = a.gparam[(size_t)b * kPad + r] * regress_grad(a, op, a.raw[(size_t)b * kPad + r]);
+        df[bl][r] = v;
       }
-      a.gw2[op][e] = s;
-    }
-    if (tid < n) {
-      float s = 0.0f;
-      for (int b = 0; b < a.B; ++b) {
-        if (a.op_id[b] != op) continue;
-        s += a.gparam[(size_t)b * kPad + tid] * regress_grad(a, op, a.raw[(size_t)b * kPad + tid]);
+      __syncthreads();
+      unsigned long long m = m0;
+      while (m) {
+        const int bl = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float h = a.hidden[(size_t)(b0 + bl) * kD + i];
+#pragma unroll
+        for (int k = 0; k < kPad / 4; ++k) acc[k] += df[bl][ph + 4 * k] * h;
+        if (sl == 0 && tid < kPad) accb += df[bl][tid];
       }
-      a.gb2[op][tid] = s;
     }
+#pragma unroll
+    for (int k = 0; k < kPad / 4; ++k)
+      if (ph + 4 * k < n) a.gw2[op][(size_t)(ph + 4 * k) * kD + i] = acc[k];
+    if (sl == 0 && tid < n) a.gb2[op][tid] = accb;
   }
 }
 
@@ -227,7 +274,8 @@ int t2o_param_heads_fwd(const int* op_id, const float* ctx, const float* const* 
   if (!fill(a, w1, b1, w2, b2)) return set_error(T2O_EINVAL, "param_heads_fwd: a head's weight pointer is null");
   a.op_id = op_id; a.ctx = ctx; a.hidden = hidden; a.raw = raw; a.param = param; a.B = B;
   a.brightness_range = brightness_range; a.sat_lo = sat_lo; a.sat_hi = sat_hi; a.sharpness_range = sharpness_range;
-  k_heads_fwd<<<B, kHT, 0, (hipStream_t)stream>>>(a);
+  k_heads_fc1<<<dim3(B, kSlices), kHT, 0, (hipStream_t)stream>>>(a);
+  k_heads_fc2<<<B, kHT, 0, (hipStream_t)stream>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "param_heads_fwd launch failed");
 }
 
@@ -249,8 +297,8 @@ int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* 
   a.gparam = gparam; a.gctx = gctx; a.dpre = dpre; a.B = B;
   a.brightness_range = brightness_range; a.sat_lo = sat_lo; a.sat_hi = sat_hi; a.sharpness_range = sharpness_range;
   hipStream_t st = (hipStream_t)stream;
-  k_heads_bwd_sample<<<B, kHT, 0, st>>>(a);
-  k_heads_bwd_weights<<<dim3(65, kOps), kHT, 0, st>>>(a);
+  k_heads_bwd_sample<<<dim3(B, kSlices), kHT, 0, st>>>(a);
+  k_heads_bwd_weights<<<dim3(64 + kSlices, kOps), kHT, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "param_heads_bwd launch failed");
 }
 
