@@ -917,7 +917,7 @@ T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid,
     const bool live = g < hw;                        // dead threads carry zeros into the reductions
     const unsigned px = live ? g : 0;
     float x[3], gg[3], sv[SV_LDS ? 1 : K][3];        // SV_LDS: operator inputs saved in the LDS area instead (fewer registers)
-    unsigned pass = 0u;
+    bool pass[K][3];                                 // clamp passed? -- lane masks in scalar registers, no vector register
     T2O_UNROLL
     for (int c = 0; c < 3; ++c) { x[c] = xn[c]; gg[c] = gn[c]; }
     if (it + 1 < a.iters) {
@@ -936,8 +936,8 @@ T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid,
       const Rgb r = chain_op_fwd(SEQ::ops[k], xi, tab + k * kTabStride);
       T2O_UNROLL
       for (int c = 0; c < 3; ++c) {
-        pass |= (r.c[c] >= 0.0f && r.c[c] <= 1.0f) ? (1u << (3 * k + c)) : 0u;
         x[c] = clamp01(r.c[c]);
+        pass[k][c] = x[c] == r.c[c];                   // == (0 <= r && r <= 1), NaN included: one compare on the clamped value
       }
     }
     T2O_UNROLL
@@ -954,7 +954,7 @@ T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid,
       T2O_UNROLL
       for (int c = 0; c < 3; ++c) {
         xi.c[c] = SV_LDS ? svl[(k * 3 + c) * kThreads + tid] : sv[k][c];
-        gi.c[c] = ((pass >> (3 * k + c)) & 1u) ? gg[c] : 0.0f;
+        gi.c[c] = pass[k][c] ? gg[c] : 0.0f;
       }
       Rgb gx;
       if (op == OP_COLOR) gx = chain_curve_bwd<true>(xi, t, gi, red[k], it == 0);
@@ -1182,7 +1182,7 @@ inline void chain_geometry(int B, int H, int W, int forced_iters, int& vec, int&
   const size_t groups = hw / vec;
   size_t it = forced_iters > 0 ? (size_t)forced_iters : (groups * (size_t)B) / ((size_t)kThreads * 4096);
   if (it < 1) it = 1;
-  if (it > 8) it = 8;
+  if (it > (forced_iters > 0 ? 64 : 8)) it = forced_iters > 0 ? 64 : 8;
   iters = (int)it;
   nblk = (int)((groups + (size_t)kThreads * it - 1) / ((size_t)kThreads * it));
 }
