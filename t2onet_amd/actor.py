@@ -25,6 +25,8 @@ from .actor_resnet import ResNet
 from .executor import Executor, PARAM_PAD
 from .lang_encoder import RNNEncoder
 
+_OVERLAP_LANG = os.environ.get('T2O_OVERLAP_LANG', '1') != '0'   # request encoder on a side stream (Actor._encode_request)
+
 # operators the FiveK path may choose: END + brightness/contrast/saturation/color/tone/sharpness
 # (inpaint_obj = 7 and color_bg = 10 are local edits, blocked: actor.py:211)
 OP_MASK = [0., 0., 1., 1., 1., 1., 1., 0., 1., 1., 0.]
@@ -128,6 +130,32 @@ class Actor(nn.Module):
         group_inds = [torch.nonzero(ops == u).squeeze(1) for u in unqs]
         return unqs, group_inds, torch.argsort(torch.cat(group_inds))
 
+    def _encode_request(self, x, lengths, img_x, want_feat=True):
+        """Request encoder + decoder initial state, and the image features of call 0.
+
+        On a GPU in training mode the request encoder (a 17-step BiLSTM: ~1 ms forward and ~2 ms backward of
+        small, latency-bound library kernels) runs on a SIDE stream while the first image-encoder pass -- which
+        does not depend on it -- runs on the caller's stream; autograd runs each node's backward on its forward's
+        stream, so the recurrent backward likewise overlaps the last image-encoder backward.  T2O_OVERLAP_LANG=0:
+        everything on the caller's stream."""
+        if not (img_x.is_cuda and self.training and torch.is_grad_enabled() and _OVERLAP_LANG):
+            enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
+            return enc_out, self.decoder._init_state(enc_hidden), (self.image_features(img_x, 0) if want_feat else None)
+        dev = img_x.device
+        side = self.__dict__.get('_side_stream')
+        if side is None or side.device != dev:
+            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)                                 # x (and the parameters' last update) come from the caller's stream
+        with torch.cuda.stream(side):
+            enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
+            hidden = self.decoder._init_state(enc_hidden)
+        feat = self.image_features(img_x, 0) if want_feat else None    # enqueued before the caller's stream waits for the side stream
+        main.wait_stream(side)
+        for t in (enc_out,) + tuple(hidden):
+            t.record_stream(main)                              # allocated on the side stream, consumed on the caller's
+        return enc_out, hidden, feat
+
     def _execute(self, img, ops_vocab, context, mask=None):
         """ops_vocab (B,) operator-vocabulary ids; executor index = id - 3, negative -> identity."""
         return self.executor.execute_per_sample(img, ops_vocab.view(-1) - 3, mask, features=context)
@@ -146,15 +174,14 @@ class Actor(nn.Module):
             if mask.dim() != 5 or mask.shape[0] != x.shape[0] or mask.shape[2] not in (1, 3):
                 raise ValueError('mask must be (bs, n_steps, 1|3, h, w), got %s' % (tuple(mask.shape),))
             mask = mask.to(img_x.device)
-        enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
-        hidden = self.decoder._init_state(enc_hidden)
         step = int((y != self.null_id).sum(1).max())
+        enc_out, hidden, feat0 = self._encode_request(x, lengths, img_x, step > 1)
         if mask is not None and mask.shape[1] < step - 2:
             raise ValueError('mask covers %d steps, the operator sequence has %d' % (mask.shape[1], step - 2))
         pred_params, pred_imgs, logprobs = [], [], []
         ops = y[:, 0].unsqueeze(-1)
         for i in range(1, step):
-            feat = self.image_features(img_x, i - 1)
+            feat = feat0 if i == 1 else self.image_features(img_x, i - 1)
             logp, hidden, _, context = self.decoder.forward_step(ops, hidden, enc_out, feat)
             logprobs.append(logp)
             ops = y[:, i].unsqueeze(-1)
@@ -171,14 +198,13 @@ class Actor(nn.Module):
         """actor.py:184-284.  Returns (state, pred_imgs (B,T,3,H,W), pred_ops (B,T), pred_params list of T (B,24))."""
         B = x.shape[0]
         dev = img_x.device
-        enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
-        hidden = self.decoder._init_state(enc_hidden)
+        enc_out, hidden, feat0 = self._encode_request(x, lengths, img_x, self.opt.decoder_max_len > 0)
         hiddens = [tuple(h.detach() for h in hidden)]
         op_mask = self._op_mask_row.repeat(B, 1)                # device-resident: no host-to-device copy (a sync)
         pred_op = torch.full((B, 1), self.start_id, dtype=torch.long, device=dev)
         pred_ops, pred_params, pred_imgs, pred_masks = [], [], [], []
         for call in range(self.opt.decoder_max_len):
-            feat = self.image_features(img_x, call)
+            feat = feat0 if call == 0 else self.image_features(img_x, call)
             logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
             hiddens.append(tuple(h.detach() for h in hidden))
             probs = torch.exp(logp).squeeze(1)

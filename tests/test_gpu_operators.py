@@ -602,7 +602,8 @@ def test_forward_bit_identical_to_reference_arithmetic(executor, dev):
     assert (out.cpu() - ref).abs().max().item() <= 2.4e-7
 
 
-def test_fused_param_heads_match_library_gemms(dev):
+@pytest.mark.parametrize('B', [37, 150])             # 150: the weight-gradient kernels find an operator's samples 64 at a time
+def test_fused_param_heads_match_library_gemms(dev, B):
     """t2o_param_heads_fwd/_bwd (each sample evaluates only its own operator's head) against the same heads through
     library GEMMs + gather (Executor.predict_params_gemm): parameters, feature gradient and all 28 head gradients,
     with identity / inpaint rows and heads that no sample selected."""
@@ -611,9 +612,8 @@ def test_fused_param_heads_match_library_gemms(dev):
     torch.manual_seed(5)
     ex_a = t2onet_amd.Executor(t2onet_amd.default_options()).to(dev)
     ex_b = copy.deepcopy(ex_a)
-    B = 37
     feats = synth.uniform((B, 512), 801, -1.0, 1.0).to(dev)
-    op_ids = torch.tensor([0, 1, 2, 3, 5, 6, -1, 4, 3, 5, 0, 2] * 4)[:B].to(dev).to(torch.int32)     # no sample uses op 7
+    op_ids = torch.tensor([0, 1, 2, 3, 5, 6, -1, 4, 3, 5, 0, 2] * 13)[:B].to(dev).to(torch.int32)    # no sample uses op 7
     gout = synth.uniform((B, 24), 802, -1.0, 1.0).to(dev)
     fa, fb = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
     pa = ex_a.predict_params(op_ids, fa)
