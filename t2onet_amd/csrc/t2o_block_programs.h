@@ -116,18 +116,22 @@ T2O_HD void curve_table_build(const float* p, bool color, float* t) {
   }
 }
 
-// segment index and clamped offset inside it
-T2O_HD void curve_locate(float x, int& i, float& frac) {
-  const float x8 = fminf(fmaxf(x * (float)kCurveSteps, 0.0f), (float)kCurveSteps - 0.5f);
+// segment index and clamped offset inside it.  unit: the caller guarantees 0 <= x <= 1 (the clamped output of the
+// previous operator of a fused chain): x - i/8 then lies in [0, 1/8] by construction and the two clamps are dropped
+// -- same values, fewer vector instructions (the chain kernels are bound by their vector-instruction count).
+T2O_HD void curve_locate(float x, int& i, float& frac, bool unit = false) {
+  const float x8 = unit ? fminf(x * (float)kCurveSteps, (float)kCurveSteps - 0.5f)
+                        : fminf(fmaxf(x * (float)kCurveSteps, 0.0f), (float)kCurveSteps - 0.5f);
   i = (int)x8;
-  frac = fminf(fmaxf(x - (float)i / kCurveSteps, 0.0f), 1.0f / kCurveSteps);
+  const float d = x - (float)i / kCurveSteps;
+  frac = unit ? d : fminf(fmaxf(d, 0.0f), 1.0f / kCurveSteps);
 }
 
 // pre-clamp output of a curve operator for channel c
-T2O_HD float curve_lut_fwd(const float* t, bool color, int c, float x) {
+T2O_HD float curve_lut_fwd(const float* t, bool color, int c, float x, bool unit = false) {
   const int cc = color ? c : 0;
   int i; float frac;
-  curve_locate(x, i, frac);
+  curve_locate(x, i, frac, unit);
   const float total = t[kTabP + cc * (kCurveSteps + 1) + i] + frac * t[kTabK + cc * kCurveSteps + i];
   return color ? total * t[kTabScale + cc]
                : div_by(total * (float)kCurveSteps, t[kTabSum + cc], t[kTabRsum + cc]);
@@ -136,13 +140,14 @@ T2O_HD float curve_lut_fwd(const float* t, bool color, int c, float x) {
 // backward of one channel of a curve operator through the table: g = gradient w.r.t. the pre-clamp output
 // (already zero where the clamp was active); adds the raw sums red_row[j] += g * t_j (red_row = this
 // channel's 8 slots), returns the gradient w.r.t. x
-T2O_HD float curve_lut_bwd_1(const float* t, bool color, int c, float x, float g, float* red_row, bool first = false) {
+T2O_HD float curve_lut_bwd_1(const float* t, bool color, int c, float x, float g, float* red_row, bool first = false,
+                             bool unit = false) {
   const int cc = color ? c : 0;
   const float* kk = t + kTabK + cc * kCurveSteps;
   int i; float frac;
-  curve_locate(x, i, frac);
+  curve_locate(x, i, frac, unit);
   const float d = x - (float)i / kCurveSteps;
-  float slope = (d >= 0.0f && d <= 1.0f / kCurveSteps) ? kk[i] : 0.0f;
+  float slope = (unit || (d >= 0.0f && d <= 1.0f / kCurveSteps)) ? kk[i] : 0.0f;   // unit: d is inside by construction
   if (d == 0.0f && i > 0) slope += kk[i - 1];                       // on a knot both neighbours pass (inclusive clamp)
   curve_bins_accumulate(x, g, red_row, first);
   return g * t[kTabScale + cc] * slope;
@@ -637,7 +642,7 @@ T2O_HD void chain_build_table(const ChainArgs& a, int b, int k, float* tab) {
 }
 
 // forward of chain operator `op` on one pixel (pre-clamp); t = this operator's table row
-T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
+T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t, bool unit = false) {
   Rgb o;
   switch (op) {
     case OP_BRIGHTNESS: return brightness_fwd(x, t[0]);
@@ -646,7 +651,7 @@ T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
     case OP_COLOR:
     case OP_TONE:
       T2O_UNROLL
-      for (int c = 0; c < 3; ++c) o.c[c] = curve_lut_fwd(t, op == OP_COLOR, c, x.c[c]);
+      for (int c = 0; c < 3; ++c) o.c[c] = curve_lut_fwd(t, op == OP_COLOR, c, x.c[c], unit);
       return o;
     case OP_WHITE: o.c[0] = o.c[1] = o.c[2] = 1.0f; return o;
     default: return x;
@@ -661,13 +666,13 @@ T2O_HD Rgb chain_op_fwd(int op, const Rgb& x, const float* t) {
 // measured 3x SLOWER on MI355X: ds_add_f32 with per-lane addresses runs at roughly one lane per
 // 3 cycles per CU.  Kept out.)
 template <bool COLOR>
-T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* red, bool first) {
+T2O_HD Rgb chain_curve_bwd(const Rgb& x, const float* t, const Rgb& dz, float* red, bool first, bool unit = false) {
   Rgb gx;
   T2O_UNROLL
   for (int c = 0; c < 3; ++c) {
     constexpr int kOne = COLOR ? 1 : 0;
     const int cc = c * kOne;                                         // static after unrolling
-    gx.c[c] = curve_lut_bwd_1(t, COLOR, c, x.c[c], dz.c[c], red + cc * kCurveSteps, first && (COLOR || c == 0));
+    gx.c[c] = curve_lut_bwd_1(t, COLOR, c, x.c[c], dz.c[c], red + cc * kCurveSteps, first && (COLOR || c == 0), unit);
   }
   return gx;
 }
@@ -871,7 +876,7 @@ T2O_HD float chain_fwd_thread_static(const ChainArgs& a, int b, int blk, int tid
       T2O_UNROLL
       for (int i = 0; i < V; ++i) {
         Rgb xi = {{x[0][i], x[1][i], x[2][i]}};
-        const Rgb r = chain_op_fwd(SEQ::ops[k], xi, tab + k * kTabStride);
+        const Rgb r = chain_op_fwd(SEQ::ops[k], xi, tab + k * kTabStride, k > 0);   // k > 0: xi = clamp01(...)
         T2O_UNROLL
         for (int c = 0; c < 3; ++c) x[c][i] = clamp01(r.c[c]);
       }
@@ -933,7 +938,7 @@ T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid,
       for (int c = 0; c < 3; ++c) {
         if (SV_LDS) svl[(k * 3 + c) * kThreads + tid] = xi.c[c]; else sv[k][c] = xi.c[c];
       }
-      const Rgb r = chain_op_fwd(SEQ::ops[k], xi, tab + k * kTabStride);
+      const Rgb r = chain_op_fwd(SEQ::ops[k], xi, tab + k * kTabStride, k > 0);   // k > 0: xi = clamp01(...)
       T2O_UNROLL
       for (int c = 0; c < 3; ++c) {
         x[c] = clamp01(r.c[c]);
@@ -957,8 +962,8 @@ T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid,
         gi.c[c] = pass[k][c] ? gg[c] : 0.0f;
       }
       Rgb gx;
-      if (op == OP_COLOR) gx = chain_curve_bwd<true>(xi, t, gi, red[k], it == 0);
-      else if (op == OP_TONE) gx = chain_curve_bwd<false>(xi, t, gi, red[k], it == 0);
+      if (op == OP_COLOR) gx = chain_curve_bwd<true>(xi, t, gi, red[k], it == 0, k > 0);
+      else if (op == OP_TONE) gx = chain_curve_bwd<false>(xi, t, gi, red[k], it == 0, k > 0);
       else if (op == OP_WHITE) gx.c[0] = gx.c[1] = gx.c[2] = 0.0f;
       else gx = chain_scalar_bwd(op, xi, t, gi, red[k]);
       T2O_UNROLL
