@@ -189,6 +189,14 @@ int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, 
                          float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* out,
                          float momentum, float eps, int relu, void* workspace, size_t workspace_bytes,
                          int M, int C, void* stream);
+/* t2o_bn_relu_nhwc_fwd with the batch statistics taken from per-tile partial sums a producer already holds
+ * (t2o_conv3x3_fwd_stats_nhwc: the convolution's accumulators) instead of a pass over x: partial is
+ * (partial_rows, 2, C) fp32 -- per row the channels' sums, then their sums of squares -- combined in fp64 in row order.
+ * Everything else as t2o_bn_relu_nhwc_fwd. */
+int t2o_bn_relu_nhwc_fwd_partials(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
+                                  float* running_var, float* save_mean, float* save_invstd, float* out, float momentum,
+                                  float eps, int relu, const float* partial, int partial_rows, void* workspace,
+                                  size_t workspace_bytes, int M, int C, void* stream);
 int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
                          const float* save_mean, const float* save_invstd, float* dx, float* dres,
                          float* dweight, float* dbias, int has_res, int relu, void* workspace,
@@ -227,6 +235,15 @@ int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* wor
 size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co);
 int t2o_conv3x3s2_fwd_nhwc(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes,
                            int N, int Ho, int Wo, int Ci, int Co, void* stream);
+
+/* The forward convolution (stride 1 or 2, shapes as t2o_conv3x3_fwd_nhwc / t2o_conv3x3s2_fwd_nhwc; Ho, Wo = output
+ * grid) that also leaves the batch-norm statistics of its output: stats is (rows, 2, Co) fp32 with rows =
+ * t2o_conv3x3_fwd_stats_rows(...) -- per pixel tile the per-channel sum and sum of squares of y, summed in a fixed
+ * order from the accumulators -- the input of t2o_bn_relu_nhwc_fwd_partials.  Replaces conv2d + the statistics half
+ * of BatchNorm2d (models/actor_resnet.py:38-44: bn(conv(x))): the activation is not read back for its mean. */
+int t2o_conv3x3_fwd_stats_rows(int N, int Ho, int Wo, int Co, int stride);
+int t2o_conv3x3_fwd_stats_nhwc(const float* x, const float* w, float* y, float* stats, void* workspace, size_t workspace_bytes,
+                               int N, int Ho, int Wo, int Ci, int Co, int stride, void* stream);
 
 /* ---- weight gradient of the same stride-2 convolutions (t2o_conv.hip, the stride-1 kernel with a two-plane x tile):
  *   dw[co][kh][kw][ci] = sum_{n,a,b} dy[n][a][b][co] * x[n][2a+kh-1][2b+kw-1][ci]   (zero padding)

@@ -53,6 +53,7 @@ SIGNATURES = {
     't2o_bn_nhwc_workspace_bytes': (_Z, [_I, _I]),
     't2o_bn_relu_nhwc_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _Z, _I, _I, _P]),
     't2o_bn_relu_nhwc_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _Z, _I, _I, _P]),
+    't2o_bn_relu_nhwc_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _I, _P, _Z, _I, _I, _P]),
     't2o_param_heads_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P]),
     't2o_param_heads_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P]),
     't2o_adam_step': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     't2o_conv_set_zero_region': (_I, [_I, _P, _Z]),
     't2o_conv3x3s2_fwd_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3s2_fwd_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    't2o_conv3x3_fwd_stats_rows': (_I, [_I, _I, _I, _I, _I]),
+    't2o_conv3x3_fwd_stats_nhwc': (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3s2_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_dgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),

@@ -21,21 +21,36 @@ _FUSED = os.environ.get('T2O_FUSED_BN', '1') != '0'      # 0: PyTorch's batch no
 _OWN_WGRAD = os.environ.get('T2O_OWN_WGRAD', '1') != '0'
 
 
-def _conv(conv, x):
+# T2O_CONV_BN_STATS=0: every fused batch norm makes its own statistics pass (A/B); default: the own forward
+# convolution leaves the per-channel sums of its output (from its accumulators) and the batch norm starts there
+_CONV_STATS = os.environ.get('T2O_CONV_BN_STATS', '1') != '0'
+
+
+def _conv(conv, x, bn=None):
+    """conv(x).  bn: the BatchNorm2d applied to the result next; returns (y, stats) then, stats = the partial sums
+    for T.batch_norm_relu(..., partial=stats) where the own forward kernel ran and bn will take the fused path,
+    else None."""
+    want = bn is not None and _CONV_STATS and _FUSED and bn.training
+    y = stats = None
     if _OWN_WGRAD and conv.bias is None and T.conv3x3_supported(x, conv.weight, conv.stride, conv.padding) \
             and conv.weight.is_contiguous(memory_format=torch.channels_last):
-        return T.conv3x3(x, conv.weight)
-    if _OWN_WGRAD and conv.bias is None and T.conv3x3s2_supported(x, conv.weight, conv.stride, conv.padding) \
+        y = T.conv3x3(x, conv.weight, True) if want else T.conv3x3(x, conv.weight)
+    elif _OWN_WGRAD and conv.bias is None and T.conv3x3s2_supported(x, conv.weight, conv.stride, conv.padding) \
             and conv.weight.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled() and x.requires_grad:
-        return T.conv3x3s2(x, conv.weight)
-    return conv(x)
+        y = T.conv3x3s2(x, conv.weight, True) if want else T.conv3x3s2(x, conv.weight)
+    else:
+        y, want = conv(x), False
+    if want:
+        y, stats = y
+    return (y, stats) if bn is not None else y
 
 
-def _bn_relu(bn, x, residual=None, counted=False):
+def _bn_relu(bn, x, residual=None, counted=False, partial=None):
     """relu(bn(x) (+ residual)): fused kernels in training mode on the GPU.  counted: num_batches_tracked of the
-    fused layers was already advanced for this forward (ResNet.forward, one launch for all of them)."""
+    fused layers was already advanced for this forward (ResNet.forward, one launch for all of them).  partial: the
+    producing convolution's statistics (see _conv)."""
     if _FUSED and bn.training and x.is_cuda:
-        return T.batch_norm_relu(x, bn, residual, count=not counted)
+        return T.batch_norm_relu(x, bn, residual, count=not counted, partial=partial if T._is_nhwc(x) else None)
     out = bn(x)
     return F.relu(out if residual is None else out + residual)
 
@@ -61,9 +76,11 @@ class BasicBlock(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
     def forward(self, x, counted=False):
-        out = _bn_relu(self.bn1, _conv(self.conv1, x), None, counted)
+        y, st = _conv(self.conv1, x, self.bn1)
+        out = _bn_relu(self.bn1, y, None, counted, st)
         sc = _bn_plain(self.shortcut[1], self.shortcut[0](x), counted) if len(self.shortcut) else x
-        return _bn_relu(self.bn2, _conv(self.conv2, out), sc, counted)
+        y, st = _conv(self.conv2, out, self.bn2)
+        return _bn_relu(self.bn2, y, sc, counted, st)
 
 
 class ResNet(nn.Module):
@@ -103,7 +120,8 @@ class ResNet(nn.Module):
             # num_batches_tracked of all 21 batch norms: one multi-tensor launch instead of 21 one-element kernels
             torch._foreach_add_(self._batch_counters(), 1)
             counted = True
-        x = _bn_relu(self.bn1, _conv(self.conv1, x), None, counted)
+        y, st = _conv(self.conv1, x, self.bn1)
+        x = _bn_relu(self.bn1, y, None, counted, st)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for block in layer:
                 x = block(x, counted)

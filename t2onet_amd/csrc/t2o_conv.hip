@@ -420,6 +420,7 @@ struct FwdArgs {
   const float* zero;    // zero region (global), >= 8 * Ci * 4 bytes
   int N, H, W, Ci, Co;
   int tiles_p, tiles_n;
+  float* stats;         // null, or (tiles_p, 2, Co): per pixel tile the sum and the sum of squares of y per channel
   unsigned long long* stamps;   // diagnostic builds only
 };
 
@@ -632,6 +633,25 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
       const int p = p0 + wm * 32 * kBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (p < P) a.y[(size_t)p * a.Co + co0 + wn * 32 + ln] = acc[i][r];
     }
+  // Batch-norm statistics of the layer that follows, straight from the accumulators (a lane holds 16 * kBM pixels of
+  // ONE channel): the statistics pass over y (one full read of the activation) is not needed.  Rows past the end
+  // of the image batch accumulated zeros.  Fixed order: lane, its partner lane + 32, the four pixel waves.
+  if (a.stats) {                       // (kernel argument: uniform)
+    __shared__ float red[2][4][kFwdCo];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kBM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1 += acc[i][r]; s2 += acc[i][r] * acc[i][r]; }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lh == 0) { red[0][wm][wn * 32 + ln] = s1; red[1][wm][wn * 32 + ln] = s2; }
+    __syncthreads();
+    if (tid < 2 * kFwdCo) {
+      const int which = tid / kFwdCo, c = tid % kFwdCo;
+      a.stats[((size_t)pt * 2 + which) * a.Co + co0 + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+    }
+  }
 #ifdef T2O_CONV_DIAG
   if (a.stamps && tid == 0) {          // [start, prologue, loop, g0..g3, epilogue issue] per workgroup
     unsigned long long* q = a.stamps + (size_t)blockIdx.x * 8;
@@ -917,18 +937,25 @@ bool fwd_supported(int N, int H, int W, int Ci, int Co) {
 
 size_t fwd_zero_bytes(int Ci) { return ((size_t)8 * Ci * 4 + 1024 + 255) / 256 * 256; }
 
+// pixels per workgroup tile of the forward kernel for a layer (256, or 128 where 256-pixel tiles would fill less than
+// one round of workgroups, one per CU, and for the two-plane x tile of stride 2)
+int fwd_tile_pixels(int P, int Co, int stride) {
+  static const int force_bm = conv_env("T2O_FWD_BM", 0);
+  const int wg256 = ((P + 255) / 256) * (Co / kFwdCo);
+  const int bm = stride == 2 ? 1 : (force_bm == 1 || force_bm == 2 ? force_bm : (wg256 < 256 ? 1 : 2));
+  return 128 * bm;
+}
+
 int launch_fwd(const float* x, const float* w, float* y, const float* zero, int N, int H, int W, int Ci, int Co, hipStream_t st,
-               int stride = 1) {
+               int stride = 1, float* stats = nullptr) {
   FwdArgs a;
   a.x = x; a.w = w; a.y = y; a.zero = zero;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   const int P = N * H * W;
   a.tiles_n = Co / kFwdCo;
-  // 256-pixel tiles unless they would fill less than one round of workgroups (one per CU) that 128-pixel tiles fill better
-  static const int force_bm = conv_env("T2O_FWD_BM", 0);
-  const int wg256 = ((P + 255) / 256) * a.tiles_n;
-  const int bm = stride == 2 ? 1 : (force_bm == 1 || force_bm == 2 ? force_bm : (wg256 < 256 ? 1 : 2));      // (stride 2: two x planes, 128-pixel tiles)
+  const int bm = fwd_tile_pixels(P, Co, stride) / 128;
   a.tiles_p = (P + 128 * bm - 1) / (128 * bm);
+  a.stats = stats;
   a.stamps = nullptr;
   const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
   if (stride == 2) k_conv3x3_fwd<1, 2><<<grid, kFwdThreads, 0, st>>>(a);
@@ -1058,6 +1085,24 @@ int t2o_conv3x3_fwd_nhwc(const float* x, const float* w, float* y, void* workspa
   hipStream_t st = (hipStream_t)stream;
   const int rc = launch_fwd(x, w, y, zero_region(workspace, fwd_zero_bytes(Ci), st), N, H, W, Ci, Co, st);
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_fwd launch failed");
+}
+
+int t2o_conv3x3_fwd_stats_rows(int N, int Ho, int Wo, int Co, int stride) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || Co < kFwdCo || Co % kFwdCo != 0 || (stride != 1 && stride != 2)) return 0;
+  const int P = N * Ho * Wo, tp = fwd_tile_pixels(P, Co, stride);
+  return (P + tp - 1) / tp;
+}
+
+int t2o_conv3x3_fwd_stats_nhwc(const float* x, const float* w, float* y, float* stats, void* workspace, size_t workspace_bytes,
+                               int N, int Ho, int Wo, int Ci, int Co, int stride, void* stream) {
+  if (!x || !w || !y || !stats) return set_error(T2O_EINVAL, "conv3x3_fwd_stats: null pointer");
+  if (stride != 1 && stride != 2) return set_error(T2O_EUNSUPPORTED, "conv3x3_fwd_stats: stride 1 or 2");
+  const size_t need = stride == 1 ? t2o_conv3x3_fwd_workspace_bytes(N, Ho, Wo, Ci, Co) : t2o_conv3x3s2_fwd_workspace_bytes(N, Ho, Wo, Ci, Co);
+  if (need == 0) return set_error(T2O_EUNSUPPORTED, "conv3x3_fwd_stats: Ci must be a multiple of 32, Co of 64, the output width of 8");
+  if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "conv3x3_fwd_stats: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = launch_fwd(x, w, y, zero_region(workspace, need, st), N, Ho, Wo, Ci, Co, st, stride, stats);
+  return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_fwd_stats launch failed");
 }
 
 size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {

@@ -590,6 +590,31 @@ int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, 
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
+int t2o_bn_relu_nhwc_fwd_partials(const float* x, const float* res, const float* weight, const float* bias, float* running_mean,
+                                  float* running_var, float* save_mean, float* save_invstd, float* out, float momentum,
+                                  float eps, int relu, const float* partial, int partial_rows, void* workspace,
+                                  size_t workspace_bytes, int M, int C, void* stream) {
+  if (!x || M <= 0 || !nhwc_channels_ok(C) || !weight || !bias || !save_mean || !save_invstd || !out)
+    return set_error(T2O_EINVAL, "bn_relu_nhwc_fwd_partials: null pointer or bad shape (C must be a power of two in [4, 1024])");
+  if (!partial || partial_rows <= 0) return set_error(T2O_EINVAL, "bn_relu_nhwc_fwd_partials: no partial sums");
+  if ((running_mean == nullptr) != (running_var == nullptr))
+    return set_error(T2O_EINVAL, "bn_relu_nhwc_fwd_partials: running_mean and running_var must both be given or both be null");
+  if (!workspace || workspace_bytes < t2o_bn_nhwc_workspace_bytes(M, C)) return set_error(T2O_EWORKSPACE, "bn_relu_nhwc_fwd_partials: workspace too small");
+  BnArgs a = {};
+  a.x = x; a.res = res; a.out = out; a.weight = weight; a.bias = bias;
+  a.running_mean = running_mean; a.running_var = running_var; a.save_mean = save_mean; a.save_invstd = save_invstd;
+  a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.eps = eps; a.momentum = momentum;
+  a.relu = relu;
+  a.partials = (double*)workspace;
+  a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
+  hipStream_t st = (hipStream_t)stream;
+  k_bn_nhwc_finalize<false><<<C / 4, kThreads, 0, st>>>(a, partial, partial_rows);
+  const size_t total4 = (size_t)M * (C >> 2);
+  const unsigned grid = flat_grid(total4, 1, kUnroll);
+  if (res) k_bn_nhwc_apply<true><<<grid, kThreads, 0, st>>>(a, total4); else k_bn_nhwc_apply<false><<<grid, kThreads, 0, st>>>(a, total4);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
+}
+
 int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
                          const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
                          float* dbias, int has_res, int relu, void* workspace, size_t workspace_bytes, int M, int C,

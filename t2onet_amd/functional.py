@@ -228,7 +228,7 @@ class _BnReluFn(torch.autograd.Function):
     Channels-last activations stay channels-last (t2o_bn_relu_nhwc_*); anything else runs on NCHW planes."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, momentum, eps, relu=True):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, momentum, eps, relu=True, partial=None):
         _need_gpu(x, res, weight, bias)
         nhwc = _is_nhwc(x)
         if not relu and not nhwc:
@@ -243,7 +243,14 @@ class _BnReluFn(torch.autograd.Function):
         save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_workspace(lib, N, C, x.device, nhwc, HW)
-        if nhwc:
+        if nhwc and partial is not None:                       # statistics from the producing convolution's accumulators
+            if partial.dim() != 3 or partial.shape[1] != 2 or partial.shape[2] != C or not partial.is_contiguous():
+                raise ValueError('batch_norm_relu: partial must be a contiguous (rows, 2, C) tensor')
+            rc = lib.t2o_bn_relu_nhwc_fwd_partials(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean),
+                                                   _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), _ptr(out),
+                                                   float(momentum), float(eps), 1 if relu else 0, _ptr(partial),
+                                                   partial.shape[0], _ptr(ws), ws.numel(), N * HW, C, _stream(x.device))
+        elif nhwc:
             rc = lib.t2o_bn_relu_nhwc_fwd(_ptr(x), _ptr(res), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                                           _ptr(save_mean), _ptr(save_invstd), _ptr(out), float(momentum), float(eps),
                                           1 if relu else 0, _ptr(ws), ws.numel(), N * HW, C, _stream(x.device))
@@ -280,7 +287,7 @@ class _BnReluFn(torch.autograd.Function):
                                      _ptr(dx), _ptr(dres), _ptr(dweight), _ptr(dbias), 1 if ctx.has_res else 0,
                                      _ptr(ws), ws.numel(), N, C, HW, _stream(x.device))
         _lib.check(rc, 't2o_bn_relu_bwd')
-        return dx, dres, dweight, dbias, None, None, None, None, None
+        return dx, dres, dweight, dbias, None, None, None, None, None, None
 
 
 _bn_ws = {}
@@ -295,17 +302,19 @@ def _bn_workspace(lib, N, C, device, nhwc=False, HW=1):
     return ws
 
 
-def batch_norm_relu(x, bn, residual=None, relu=True, count=True):
+def batch_norm_relu(x, bn, residual=None, relu=True, count=True, partial=None):
     """relu(bn(x) (+ residual)) for a torch.nn.BatchNorm2d `bn` in TRAINING mode on the GPU: batch
     statistics, running statistics and num_batches_tracked updated as nn.BatchNorm2d does
     (models/actor_resnet.py:38-44, :99-100).  One statistics pass + one fused normalise/add/ReLU pass.
     relu=False: plain bn(x) (channels-last only: the shortcut branch).  count=False: the caller advances
-    num_batches_tracked itself (the encoder does it for all its layers with one launch)."""
+    num_batches_tracked itself (the encoder does it for all its layers with one launch).  partial: (rows, 2, C)
+    per-tile sums / sums of squares of x from the convolution that produced it (conv3x3(..., want_stats=True)):
+    the statistics pass over x is skipped (channels-last only)."""
     if bn.momentum is None or not bn.affine or not bn.track_running_stats:
         raise NotImplementedError('batch_norm_relu: affine BatchNorm2d with running statistics and a fixed momentum only')
     if count:
         bn.num_batches_tracked.add_(1)
-    return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu)
+    return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, partial)
 
 
 HEAD_OPS = (0, 1, 2, 3, 5, 6, 7)          # executor indices with a parameter head on this path (4 = inpaint: none)
@@ -406,9 +415,11 @@ def _conv_workspace(device, need):
     return torch.empty(need, dtype=torch.uint8, device=device)
 
 
-def conv3x3_forward(x, weight):
+def conv3x3_forward(x, weight, want_stats=False):
     """conv2d(x, weight, None, 1, 1) on the fp32 matrix cores (t2o_conv3x3_fwd_nhwc).  x (N,Ci,H,W) and weight
-    (Co,Ci,3,3) channels-last; returns y (N,Co,H,W) channels-last."""
+    (Co,Ci,3,3) channels-last; returns y (N,Co,H,W) channels-last.  want_stats: returns (y, stats) with stats
+    (rows, 2, Co) = per pixel tile the channels' sums and sums of squares of y (t2o_conv3x3_fwd_stats_nhwc), the
+    input of batch_norm_relu(..., partial=stats)."""
     _need_gpu(x, weight)
     N, Ci, H, W = x.shape
     Co = weight.shape[0]
@@ -420,6 +431,12 @@ def conv3x3_forward(x, weight):
         raise RuntimeError('conv3x3_forward: unsupported shape (Ci % 32, Co % 64, W % 8 must be 0)')
     ws = _conv_workspace(x.device, need)
     y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if want_stats:
+        stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(N, H, W, Co, 1), 2, Co), dtype=torch.float32, device=x.device)
+        rc = lib.t2o_conv3x3_fwd_stats_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(stats), _ptr(ws), ws.numel(), N, H, W, Ci, Co, 1,
+                                            _stream(x.device))
+        _lib.check(rc, 't2o_conv3x3_fwd_stats_nhwc')
+        return y, stats
     rc = lib.t2o_conv3x3_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(ws), ws.numel(), N, H, W, Ci, Co, _stream(x.device))
     _lib.check(rc, 't2o_conv3x3_fwd_nhwc')
     return y
@@ -463,9 +480,9 @@ def conv3x3s2_dgrad(dy, weight):
     return dx
 
 
-def conv3x3s2_forward(x, weight):
+def conv3x3s2_forward(x, weight, want_stats=False):
     """conv2d(x, weight, None, stride 2, padding 1) for an even-sized x (t2o_conv3x3s2_fwd_nhwc).  x (N,Ci,2Ho,2Wo)
-    and weight (Co,Ci,3,3) channels-last; returns y (N,Co,Ho,Wo) channels-last."""
+    and weight (Co,Ci,3,3) channels-last; returns y (N,Co,Ho,Wo) channels-last (want_stats: as conv3x3_forward)."""
     _need_gpu(x, weight)
     N, Ci, Hi, Wi = x.shape
     Co = weight.shape[0]
@@ -480,6 +497,12 @@ def conv3x3s2_forward(x, weight):
         raise RuntimeError('conv3x3s2_forward: unsupported shape (Ci % 32, Co % 64, Wo % 8 must be 0)')
     ws = _conv_workspace(x.device, need)
     y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if want_stats:
+        stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(N, Ho, Wo, Co, 2), 2, Co), dtype=torch.float32, device=x.device)
+        rc = lib.t2o_conv3x3_fwd_stats_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(stats), _ptr(ws), ws.numel(), N, Ho, Wo, Ci, Co, 2,
+                                            _stream(x.device))
+        _lib.check(rc, 't2o_conv3x3_fwd_stats_nhwc')
+        return y, stats
     rc = lib.t2o_conv3x3s2_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(ws), ws.numel(), N, Ho, Wo, Ci, Co, _stream(x.device))
     _lib.check(rc, 't2o_conv3x3s2_fwd_nhwc')
     return y
@@ -524,14 +547,18 @@ class _Conv3x3S2Fn(torch.autograd.Function):
     gradient in T2O_OWN_CONV (the 3-channel stem: only its data gradient; the rest are library calls)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         ctx.save_for_backward(x, weight)
-        if ('F' in _CONV_OWN and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0 and x.shape[3] % 16 == 0):
-            return conv3x3s2_forward(x, weight)
-        return torch.nn.functional.conv2d(x, weight, None, 2, 1)
+        own = 'F' in _CONV_OWN and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0 and x.shape[3] % 16 == 0
+        if want_stats:                                       # (y, stats); stats None where the library computes y
+            y, stats = conv3x3s2_forward(x, weight, True) if own else (torch.nn.functional.conv2d(x, weight, None, 2, 1), None)
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
+            return y, stats
+        return conv3x3s2_forward(x, weight) if own else torch.nn.functional.conv2d(x, weight, None, 2, 1)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _gstats=None):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         own = ctx.needs_input_grad[0] and 's' in _CONV_OWN
@@ -545,11 +572,12 @@ class _Conv3x3S2Fn(torch.autograd.Function):
             dx = conv3x3s2_dgrad(dy, weight)
         if own_w:
             dw = conv3x3s2_wgrad(x, dy)
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3x3s2(x, weight):
-    return _Conv3x3S2Fn.apply(x, weight)
+def conv3x3s2(x, weight, want_stats=False):
+    """want_stats: (y, stats or None) -- see conv3x3_forward."""
+    return _Conv3x3S2Fn.apply(x, weight, want_stats)
 
 
 def conv3x3_supported(x, weight, stride, padding):
@@ -576,14 +604,18 @@ class _Conv3x3Fn(torch.autograd.Function):
     """conv2d(x, w, 3x3, stride 1, padding 1) on the hand-written MFMA kernels (t2o_conv.hip)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats=False):
         ctx.save_for_backward(x, weight)
-        if 'f' in _CONV_OWN and _own_direct(x):
-            return conv3x3_forward(x, weight)
-        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+        own = 'f' in _CONV_OWN and _own_direct(x)
+        if want_stats:                                       # (y, stats); stats None where the library computes y
+            y, stats = conv3x3_forward(x, weight, True) if own else (torch.nn.functional.conv2d(x, weight, None, 1, 1), None)
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
+            return y, stats
+        return conv3x3_forward(x, weight) if own else torch.nn.functional.conv2d(x, weight, None, 1, 1)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _gstats=None):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = None
@@ -600,11 +632,12 @@ class _Conv3x3Fn(torch.autograd.Function):
             else:
                 dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3x3(x, weight):
-    return _Conv3x3Fn.apply(x, weight)
+def conv3x3(x, weight, want_stats=False):
+    """want_stats: (y, stats or None) -- see conv3x3_forward."""
+    return _Conv3x3Fn.apply(x, weight, want_stats)
 
 
 class _SequenceFn(torch.autograd.Function):

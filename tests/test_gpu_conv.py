@@ -259,3 +259,69 @@ def test_conv3x3_autograd_function_matches_library():
     torch.nn.functional.conv2d(x2, w2, None, 1, 1).backward(gy)
     np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(w1.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(w2.grad.abs().max()))
+
+
+# (N, Ci, Co, H, W, stride); H, W = OUTPUT grid: 128- and 256-pixel tiles, a ragged last tile, several channel tiles,
+# the encoder's first stage at batch 64 (1024 tiles)
+STATS_SHAPES = [(2, 64, 64, 8, 8, 1), (3, 128, 192, 5, 16, 1), (9, 64, 64, 40, 40, 1), (2, 64, 128, 6, 8, 2), (3, 128, 64, 10, 24, 2),
+                (64, 64, 64, 64, 64, 1)]
+
+
+@pytest.mark.parametrize('shape', STATS_SHAPES)
+def test_forward_leaves_the_batch_norm_statistics_of_its_output(shape):
+    """conv3x3(..., want_stats=True): y unchanged, per-tile channel sums / sums of squares from the accumulators add up
+    to those of y (fp64), and the batch norm that starts from them equals the one that reads y itself
+    (models/actor_resnet.py:38-44 bn(conv(x)))."""
+    import copy
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W, stride = shape
+    dev = torch.device('cuda:0')
+    x = synth.uniform((N, Ci, H * stride, W * stride), 761, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    w = synth.uniform((Co, Ci, 3, 3), 762, -0.1, 0.1).to(dev).contiguous(memory_format=torch.channels_last)
+    fwd = T.conv3x3_forward if stride == 1 else T.conv3x3s2_forward
+    y0 = fwd(x, w)
+    y, st = fwd(x, w, True)
+    assert torch.equal(y, y0)
+    assert st.shape[1:] == (2, Co) and st.shape[0] in (-(-N * H * W // 128), -(-N * H * W // 256))       # one row per pixel tile
+    got = st.double().sum(0).cpu().numpy()
+    y64 = y.double()
+    ref = torch.stack([y64.sum((0, 2, 3)), (y64 * y64).sum((0, 2, 3))]).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6 * np.abs(ref).max())
+    torch.manual_seed(3)
+    bn_a = torch.nn.BatchNorm2d(Co).to(dev).train()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5)
+        bn_a.bias.uniform_(-0.5, 0.5)
+    bn_b = copy.deepcopy(bn_a)
+    res = synth.uniform(tuple(y.shape), 763, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    out_a = T.batch_norm_relu(y, bn_a, res, partial=st)
+    out_b = T.batch_norm_relu(y, bn_b, res)
+    assert float((out_a - out_b).detach().abs().max()) <= 1e-5
+    np.testing.assert_allclose(bn_a.running_mean.cpu().numpy(), bn_b.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(bn_a.running_var.cpu().numpy(), bn_b.running_var.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(st, fwd(x, w, True)[1])              # fixed summation order
+
+
+def test_encoder_with_and_without_convolution_statistics_agree(monkeypatch):
+    """The image encoder's forward and gradients with the batch norms fed from the convolutions' accumulators against
+    the same encoder making its own statistics passes."""
+    import copy
+    import t2onet_amd.actor_resnet as R
+    dev = torch.device('cuda:0')
+    torch.manual_seed(4)
+    net_a = R.ResNet().to(dev).train().to(memory_format=torch.channels_last)
+    net_b = copy.deepcopy(net_a)
+    x = synth.uniform((4, 3, 64, 64), 771, 0.0, 1.0).to(dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    monkeypatch.setattr(R, '_CONV_STATS', True)
+    fa = net_a(xa)
+    monkeypatch.setattr(R, '_CONV_STATS', False)
+    fb = net_b(xb)
+    assert float((fa - fb).detach().abs().max()) <= 2e-5 * max(1.0, float(fb.detach().abs().max()))
+    g = synth.uniform(tuple(fa.shape), 772, -1.0, 1.0).to(dev)
+    fa.backward(g)
+    fb.backward(g)
+    ga, gb = xa.grad, xb.grad
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+    for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * max(float(pb.grad.abs().max()), 1e-6), n
