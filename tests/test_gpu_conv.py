@@ -304,24 +304,31 @@ def test_forward_leaves_the_batch_norm_statistics_of_its_output(shape):
 
 def test_encoder_with_and_without_convolution_statistics_agree(monkeypatch):
     """The image encoder's forward and gradients with the batch norms fed from the convolutions' accumulators against
-    the same encoder making its own statistics passes."""
+    the same encoder making its own statistics passes.  The two differ in the rounding of the batch statistics
+    (1e-7 relative); a ReLU whose input is that close to zero may then switch, which changes single gradient entries
+    by their full size: gradients are compared in the L2 norm."""
     import copy
     import t2onet_amd.actor_resnet as R
     dev = torch.device('cuda:0')
     torch.manual_seed(4)
     net_a = R.ResNet().to(dev).train().to(memory_format=torch.channels_last)
     net_b = copy.deepcopy(net_a)
-    x = synth.uniform((4, 3, 64, 64), 771, 0.0, 1.0).to(dev)
+    x = synth.uniform((8, 3, 128, 128), 771, 0.0, 1.0).to(dev)
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     monkeypatch.setattr(R, '_CONV_STATS', True)
     fa = net_a(xa)
     monkeypatch.setattr(R, '_CONV_STATS', False)
     fb = net_b(xb)
     assert float((fa - fb).detach().abs().max()) <= 2e-5 * max(1.0, float(fb.detach().abs().max()))
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        if 'running' in n:
+            np.testing.assert_allclose(ba.cpu().numpy(), bb.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
     g = synth.uniform(tuple(fa.shape), 772, -1.0, 1.0).to(dev)
     fa.backward(g)
     fb.backward(g)
-    ga, gb = xa.grad, xb.grad
-    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+
+    def rel(a, b):
+        return float((a - b).double().norm()) / max(float(b.double().norm()), 1e-12)
+    assert rel(xa.grad, xb.grad) <= 2e-3
     for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
-        assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * max(float(pb.grad.abs().max()), 1e-6), n
+        assert rel(pa.grad, pb.grad) <= 2e-3, n
