@@ -286,6 +286,15 @@ int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* 
                         const float* gparam, float* gctx, float* dpre, float* const* gw1, float* const* gb1,
                         float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
                         float sharpness_range, int B, int D, void* stream);
+/* The same with accumulate != 0: the heads' weight gradients are ADDED to gw1 / gb1 / gw2 / gb2 (every element has
+ * exactly one writer: still deterministic).  For a trainer whose gradient buffers are persistent and zeroed before
+ * the backward: the 28 gradient tensors of a decoder step then need no accumulation launches of their own
+ * (140 per episode step under autograd). */
+int t2o_param_heads_bwd_acc(const int* op_id, const float* ctx, const float* const* w1, const float* const* b1,
+                        const float* const* w2, const float* const* b2, const float* hidden, const float* raw,
+                        const float* gparam, float* gctx, float* dpre, float* const* gw1, float* const* gb1,
+                        float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
+                        float sharpness_range, int B, int D, int accumulate, void* stream);
 
 /* Rewrites a captured, not yet instantiated hipGraph (hipGraph_t) in place: every memset node becomes a kernel node
  * doing the same fill, with the same dependencies and dependents; *replaced = how many.  Memset nodes were seen to

@@ -56,6 +56,7 @@ SIGNATURES = {
     't2o_bn_relu_nhwc_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _I, _P, _Z, _I, _I, _P]),
     't2o_param_heads_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P]),
     't2o_param_heads_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P]),
+    't2o_param_heads_bwd_acc': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _P]),
     't2o_adam_step': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P]),
     't2o_graph_memsets_to_kernels': (_I, [_P, _P]),
     't2o_conv3x3_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),

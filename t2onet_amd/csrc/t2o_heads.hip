@@ -45,6 +45,7 @@ struct HeadArgs {
   float* dpre;             // (B,512) backward scratch: gradient w.r.t. fc1's pre-activation
   float* gctx;             // (B,512)
   int B;
+  int accumulate;          // backward: weight gradients are ADDED to gw1 / gb1 / gw2 / gb2 (each element has one writer)
   float brightness_range, sat_lo, sat_hi, sharpness_range;
 };
 
@@ -213,11 +214,15 @@ __global__ __launch_bounds__(kHT) void k_heads_bwd_weights(HeadArgs a) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(a.gw1[op] + (size_t)(r0 + i) * kD + c0) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    for (int i = 0; i < 4; ++i) {
+      float4* dst = reinterpret_cast<float4*>(a.gw1[op] + (size_t)(r0 + i) * kD + c0);
+      float4 v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      if (a.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *dst = v;
+    }
     if (tc == 0 && tid % 16 == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a.gb1[op][r0 + i] = accb[i];
+      for (int i = 0; i < 4; ++i) a.gb1[op][r0 + i] = accb[i] + (a.accumulate ? a.gb1[op][r0 + i] : 0.0f);
     }
   } else {
     __shared__ float df[64][kPad];                                         // gparam * regressor' of 64 samples (0: not this operator's)
@@ -248,8 +253,11 @@ __global__ __launch_bounds__(kHT) void k_heads_bwd_weights(HeadArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < kPad / 4; ++k)
-      if (ph + 4 * k < n) a.gw2[op][(size_t)(ph + 4 * k) * kD + i] = acc[k];
-    if (sl == 0 && tid < n) a.gb2[op][tid] = accb;
+      if (ph + 4 * k < n) {
+        float* dst = a.gw2[op] + (size_t)(ph + 4 * k) * kD + i;
+        *dst = acc[k] + (a.accumulate ? *dst : 0.0f);
+      }
+    if (sl == 0 && tid < n) a.gb2[op][tid] = accb + (a.accumulate ? a.gb2[op][tid] : 0.0f);
   }
 }
 
@@ -279,11 +287,11 @@ int t2o_param_heads_fwd(const int* op_id, const float* ctx, const float* const* 
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "param_heads_fwd launch failed");
 }
 
-int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* w1, const float* const* b1,
+int t2o_param_heads_bwd_acc(const int* op_id, const float* ctx, const float* const* w1, const float* const* b1,
                         const float* const* w2, const float* const* b2, const float* hidden, const float* raw,
                         const float* gparam, float* gctx, float* dpre, float* const* gw1, float* const* gb1,
                         float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
-                        float sharpness_range, int B, int D, void* stream) {
+                        float sharpness_range, int B, int D, int accumulate, void* stream) {
   if (!op_id || !ctx || !w1 || !b1 || !w2 || !b2 || !hidden || !raw || !gparam || !gctx || !dpre || !gw1 || !gb1 || !gw2 || !gb2)
     return set_error(T2O_EINVAL, "param_heads_bwd: null pointer");
   if (B <= 0 || D != kD) return set_error(T2O_EINVAL, "param_heads_bwd: B must be positive and the feature width 512");
@@ -294,12 +302,21 @@ int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* 
     if (k != 4 && (!gw1[k] || !gb1[k] || !gw2[k] || !gb2[k])) return set_error(T2O_EINVAL, "param_heads_bwd: a gradient pointer is null");
   }
   a.op_id = op_id; a.ctx = ctx; a.hidden = const_cast<float*>(hidden); a.raw = const_cast<float*>(raw);
-  a.gparam = gparam; a.gctx = gctx; a.dpre = dpre; a.B = B;
+  a.gparam = gparam; a.gctx = gctx; a.dpre = dpre; a.B = B; a.accumulate = accumulate ? 1 : 0;
   a.brightness_range = brightness_range; a.sat_lo = sat_lo; a.sat_hi = sat_hi; a.sharpness_range = sharpness_range;
   hipStream_t st = (hipStream_t)stream;
   k_heads_bwd_sample<<<dim3(B, kSlices), kHT, 0, st>>>(a);
   k_heads_bwd_weights<<<dim3(64 + kSlices, kOps), kHT, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "param_heads_bwd launch failed");
+}
+
+int t2o_param_heads_bwd(const int* op_id, const float* ctx, const float* const* w1, const float* const* b1,
+                        const float* const* w2, const float* const* b2, const float* hidden, const float* raw,
+                        const float* gparam, float* gctx, float* dpre, float* const* gw1, float* const* gb1,
+                        float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
+                        float sharpness_range, int B, int D, void* stream) {
+  return t2o_param_heads_bwd_acc(op_id, ctx, w1, b1, w2, b2, hidden, raw, gparam, gctx, dpre, gw1, gb1, gw2, gb2, brightness_range, sat_lo,
+                                 sat_hi, sharpness_range, B, D, 0, stream);
 }
 
 }  // extern "C"

@@ -63,7 +63,8 @@ class Executor(nn.Module):
             heads = {k: (Op.fc1.weight, Op.fc1.bias, Op.fc2.weight, Op.fc2.bias) for k, Op in enumerate(self.ops) if k != 4}
             lo, hi = self.opt.saturation_range
             return T.param_heads(features, op_ids.to(torch.int32), heads,
-                                 (self.opt.brightness_range, lo, hi, self.opt.sharpness_range))
+                                 (self.opt.brightness_range, lo, hi, self.opt.sharpness_range),
+                                 into_grad=self.__dict__.get('heads_grad_in_place', False))
         return self.predict_params_gemm(op_ids, features)
 
     def predict_params_gemm(self, op_ids, features):

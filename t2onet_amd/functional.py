@@ -334,8 +334,14 @@ class _ParamHeadsFn(torch.autograd.Function):
     backward (t2o_param_heads_*), instead of every head on the whole batch + gather."""
 
     @staticmethod
-    def forward(ctx, features, op_ids, consts, *flat):
+    def forward(ctx, features, op_ids, consts, into_grad, *flat):
         _need_gpu(features, *flat)
+        # into_grad: the backward ADDS the heads' gradients to the parameters' existing .grad tensors inside its
+        # kernel and hands autograd no gradient for them (a trainer with persistent, pre-zeroed gradient buffers)
+        ctx.grad_targets = None
+        if into_grad and all(t.grad is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32
+                             and t.grad.shape == t.shape and t.is_contiguous() for t in flat):
+            ctx.grad_targets = [t.grad for t in flat]
         features = features.contiguous()
         B, D = features.shape
         flat = [t.contiguous() for t in flat]
@@ -357,25 +363,29 @@ class _ParamHeadsFn(torch.autograd.Function):
         flat = ctx.saved_tensors[4:]
         B, D = features.shape
         tabs = [{op: flat[4 * k + j] for k, op in enumerate(HEAD_OPS)} for j in range(4)]
-        grads = [torch.empty_like(t) for t in flat]
+        acc = ctx.grad_targets is not None
+        grads = ctx.grad_targets if acc else [torch.empty_like(t) for t in flat]
         gtabs = [{op: grads[4 * k + j] for k, op in enumerate(HEAD_OPS)} for j in range(4)]
         gctx = torch.empty_like(features)
         dpre = torch.empty_like(features)
         c = ctx.consts
-        rc = _lib.load().t2o_param_heads_bwd(_ptr(op_ids), _ptr(features), _ptr_table(tabs[0]), _ptr_table(tabs[1]),
-                                             _ptr_table(tabs[2]), _ptr_table(tabs[3]), _ptr(hidden), _ptr(raw),
-                                             _ptr(gparam.contiguous()), _ptr(gctx), _ptr(dpre), _ptr_table(gtabs[0]),
-                                             _ptr_table(gtabs[1]), _ptr_table(gtabs[2]), _ptr_table(gtabs[3]),
-                                             c[0], c[1], c[2], c[3], B, D, _stream(features.device))
-        _lib.check(rc, 't2o_param_heads_bwd')
-        return (gctx, None, None) + tuple(grads)
+        rc = _lib.load().t2o_param_heads_bwd_acc(_ptr(op_ids), _ptr(features), _ptr_table(tabs[0]), _ptr_table(tabs[1]),
+                                                 _ptr_table(tabs[2]), _ptr_table(tabs[3]), _ptr(hidden), _ptr(raw),
+                                                 _ptr(gparam.contiguous()), _ptr(gctx), _ptr(dpre), _ptr_table(gtabs[0]),
+                                                 _ptr_table(gtabs[1]), _ptr_table(gtabs[2]), _ptr_table(gtabs[3]),
+                                                 c[0], c[1], c[2], c[3], B, D, 1 if acc else 0, _stream(features.device))
+        _lib.check(rc, 't2o_param_heads_bwd_acc')
+        return (gctx, None, None, None) + (tuple(None for _ in flat) if acc else tuple(grads))
 
 
-def param_heads(features, op_ids, heads, consts):
+def param_heads(features, op_ids, heads, consts, into_grad=False):
     """heads: {executor index: (fc1.weight, fc1.bias, fc2.weight, fc2.bias)} for HEAD_OPS; consts =
-    (brightness_range, saturation lo, saturation hi, sharpness_range); op_ids (B,) int32 on the GPU."""
+    (brightness_range, saturation lo, saturation hi, sharpness_range); op_ids (B,) int32 on the GPU.
+    into_grad: the backward adds the heads' gradients to the parameters' existing .grad tensors itself (inside its
+    kernel) instead of returning them to autograd -- only for a caller that zeroes those .grad tensors before every
+    backward and reads them afterwards (t2onet_amd.train.Trainer); torch.autograd.grad then sees no gradient for them."""
     flat = [t for op in HEAD_OPS for t in heads[op]]
-    return _ParamHeadsFn.apply(features, op_ids, tuple(float(v) for v in consts), *flat)
+    return _ParamHeadsFn.apply(features, op_ids, tuple(float(v) for v in consts), bool(into_grad), *flat)
 
 
 

@@ -8,6 +8,8 @@ of one pre-zeroed flat buffer, so a head that no local sample selected contribut
 all-reduce and Adam sees a zero gradient -- the behaviour of the reference under the
 zero-filling `zero_grad()` of the torch version it was written for.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -117,6 +119,11 @@ class Trainer:
             self.optimizer = torch.optim.Adam(self.grads.params, lr=lr)
         self.itr = 0
         self.graph_encoder = graph_encoder
+        # the parameter heads add their gradients into the flat buffer inside their backward kernel (this trainer
+        # zeroes it before every backward): 28 tensors x 5 decoder steps of autograd accumulation launches less
+        executor = getattr(model, 'executor', None)
+        if executor is not None and self.grads.flat.is_cuda and os.environ.get('T2O_HEADS_GRAD_IN_PLACE', '1') != '0':
+            executor.__dict__['heads_grad_in_place'] = True
 
     def _maybe_graph(self, img):
         if self.graph_encoder and img.is_cuda and '_graphed_encoders' not in self.model.__dict__:

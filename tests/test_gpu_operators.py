@@ -631,3 +631,31 @@ def test_fused_param_heads_match_library_gemms(dev, B):
         gb = torch.zeros_like(qb) if qb.grad is None else qb.grad
         np.testing.assert_allclose(ga.cpu().numpy(), gb.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(float(gb.abs().max()), 1e-6), err_msg=n)
     assert float(ex_a.white_op.fc1.weight.grad.abs().max()) == 0.0                      # unused head: exact zeros
+
+
+def test_param_heads_add_their_gradients_into_existing_grad_tensors(dev):
+    """Executor.heads_grad_in_place (set by the Trainer): the heads' backward kernel adds into the parameters' .grad
+    tensors itself and autograd gets no gradient for them -- two backwards leave exactly twice the gradients of the
+    ordinary path, the feature gradient is unchanged."""
+    import copy
+    import t2onet_amd
+    torch.manual_seed(6)
+    ex_a = t2onet_amd.Executor(t2onet_amd.default_options()).to(dev)
+    ex_b = copy.deepcopy(ex_a)
+    B = 70
+    feats = synth.uniform((B, 512), 811, -1.0, 1.0).to(dev)
+    op_ids = torch.tensor([0, 1, 2, 3, 5, 6, 7, -1, 4, 3] * 7)[:B].to(dev).to(torch.int32)
+    gout = synth.uniform((B, 24), 812, -1.0, 1.0).to(dev)
+    for p in ex_a.parameters():
+        p.grad = torch.zeros_like(p)
+    ex_a.__dict__['heads_grad_in_place'] = True
+    fa, fb = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    for _ in range(2):
+        (ex_a.predict_params(op_ids, fa) * gout).sum().backward()
+    (ex_b.predict_params(op_ids, fb) * gout).sum().backward()
+    assert torch.equal(fa.grad, 2 * fb.grad)
+    for (n, qa), (_, qb) in zip(ex_a.named_parameters(), ex_b.named_parameters()):
+        if 'inpaint' in n:
+            continue
+        want = 2 * (torch.zeros_like(qb) if qb.grad is None else qb.grad)
+        np.testing.assert_allclose(qa.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-6 * max(float(want.abs().max()), 1e-6), err_msg=n)
