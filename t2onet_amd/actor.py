@@ -26,6 +26,7 @@ from .executor import Executor, PARAM_PAD
 from .lang_encoder import RNNEncoder
 
 _OVERLAP_LANG = os.environ.get('T2O_OVERLAP_LANG', '1') != '0'   # request encoder on a side stream (Actor._encode_request)
+_SIDE_STREAMS = {}
 
 # operators the FiveK path may choose: END + brightness/contrast/saturation/color/tone/sharpness
 # (inpaint_obj = 7 and color_bg = 10 are local edits, blocked: actor.py:211)
@@ -142,9 +143,9 @@ class Actor(nn.Module):
             enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
             return enc_out, self.decoder._init_state(enc_hidden), (self.image_features(img_x, 0) if want_feat else None)
         dev = img_x.device
-        side = self.__dict__.get('_side_stream')
-        if side is None or side.device != dev:
-            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=dev)
+        side = _SIDE_STREAMS.get(dev)                          # one per device for the process (module state, not the
+        if side is None:                                       # model's: copy.deepcopy(model) must not meet a stream)
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)                                 # x (and the parameters' last update) come from the caller's stream
         with torch.cuda.stream(side):
