@@ -245,6 +245,13 @@ int t2o_conv3x3_fwd_stats_rows(int N, int Ho, int Wo, int Co, int stride);
 int t2o_conv3x3_fwd_stats_nhwc(const float* x, const float* w, float* y, float* stats, void* workspace, size_t workspace_bytes,
                                int N, int Ho, int Wo, int Ci, int Co, int stride, void* stream);
 
+/* Forward of the image encoder's stem, conv2d(x, w, None, stride 2, padding 1) with 3 input and 32 / 64 output channels
+ * (models/actor_resnet.py:99): x (N, 2Ho, 2Wo, 3), w (Co,3,3,3) channels-last, y (N, Ho, Wo, Co).  stats: null, or
+ * (t2o_stem_fwd_stats_rows(N, Ho, Wo), 2, Co) per-workgroup channel sums / sums of squares of y for
+ * t2o_bn_relu_nhwc_fwd_partials (the stem's batch norm then makes no statistics pass over its 268 MB at bs=64). */
+int t2o_stem_fwd_stats_rows(int N, int Ho, int Wo);
+int t2o_stem_fwd_nhwc(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, void* stream);
+
 /* ---- weight gradient of the same stride-2 convolutions (t2o_conv.hip, the stride-1 kernel with a two-plane x tile):
  *   dw[co][kh][kw][ci] = sum_{n,a,b} dy[n][a][b][co] * x[n][2a+kh-1][2b+kw-1][ci]   (zero padding)
  *   x (N,2Ho,2Wo,Ci), dy (N,Ho,Wo,Co), dw (Co,3,3,Ci).  Ci, Co multiples of 64, Wo a multiple of 4.  Deterministic

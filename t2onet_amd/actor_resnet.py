@@ -36,7 +36,8 @@ def _conv(conv, x, bn=None):
             and conv.weight.is_contiguous(memory_format=torch.channels_last):
         y = T.conv3x3(x, conv.weight, True) if want else T.conv3x3(x, conv.weight)
     elif _OWN_WGRAD and conv.bias is None and T.conv3x3s2_supported(x, conv.weight, conv.stride, conv.padding) \
-            and conv.weight.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled() and x.requires_grad:
+            and conv.weight.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled() \
+            and (x.requires_grad or conv.weight.requires_grad):
         y = T.conv3x3s2(x, conv.weight, True) if want else T.conv3x3s2(x, conv.weight)
     else:
         y, want = conv(x), False

@@ -925,6 +925,97 @@ __global__ __launch_bounds__(256) void k_stem_dgrad(const float* __restrict__ dy
   }
 }
 
+// ---- forward of the 3 -> 32 / 64 channel stem (stride 2, padding 1), with the batch-norm statistics of its output
+// 27 multiply-adds per output: a streaming kernel like its data gradient above.  A workgroup stages the 17 x 65 x 3
+// input window of an 8 x 32 output tile in LDS; thread = (pixel slot, channel quad): the 16 (8) threads of a pixel
+// write its 256 (128) output bytes as consecutive float4s; the 4 x 27 weights of a thread's channels stay in
+// registers across the workgroup's tiles.  stats (optional): one row (2, Co) per workgroup -- sum and sum of squares of
+// its outputs per channel, pixel slots added in a fixed order -- for t2o_bn_relu_nhwc_fwd_partials.
+constexpr int kSfTH = 8, kSfTW = 32;
+constexpr int kSfRows = 2 * kSfTH + 1, kSfRowFloats = (2 * kSfTW + 1) * 3;      // 17 rows of 195 floats
+constexpr int kSfTilesPerWg = 8;          // consecutive tiles of a workgroup: the next window is loaded during a tile's arithmetic
+
+template <int kCo>
+__global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                  float* __restrict__ stats, int N, int Ho, int Wo, int tiles_total) {
+  constexpr int CQ = kCo / 4, PP = 256 / CQ, kPasses = (kSfTH * kSfTW) / PP;
+  __shared__ __attribute__((aligned(16))) float patch[kSfRows][kSfRowFloats + 1];       // (196 floats per row: 8-byte aligned pairs)
+  __shared__ float red[2][PP][kCo];
+  const int tid = threadIdx.x, cq = tid % CQ, ps = tid / CQ;
+  const int tiles_w = (Wo + kSfTW - 1) / kSfTW, tiles_h = (Ho + kSfTH - 1) / kSfTH;
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  float wr[4][27];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wr[j][t] = w[(size_t)(4 * cq + j) * 27 + t];
+  float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  constexpr int kLoads = (kSfRows * kSfRowFloats + 255) / 256;         // 13 per thread
+  float stage[kLoads];
+  // the input window of a tile into registers: input rows 2 a0 - 1 .. 2 a0 + 15, columns 2 b0 - 1 .. 2 b0 + 63 (a
+  // window row is 195 consecutive floats of x); all loads in flight at once
+  auto issue = [&](int tile) {
+    const int n = tile / (tiles_h * tiles_w), th = (tile / tiles_w) % tiles_h, tw = tile % tiles_w;
+    const int ih0 = 2 * th * kSfTH - 1, iw0 = 2 * tw * kSfTW - 1;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int f = tid + 256 * k;
+      const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
+      const int ih = ih0 + rr, iw = iw0 + cc / 3;
+      stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * Hi + ih) * Wi + iw0) * 3 + cc] : 0.0f;
+    }
+  };
+  const int tile0 = blockIdx.x * kSfTilesPerWg;
+  if (tile0 < tiles_total) issue(tile0);
+  for (int tt = 0; tt < kSfTilesPerWg; ++tt) {
+    const int tile = tile0 + tt;
+    if (tile >= tiles_total) break;                        // (workgroup-uniform)
+    const int n = tile / (tiles_h * tiles_w), th = (tile / tiles_w) % tiles_h, tw = tile % tiles_w;
+    const int a0 = th * kSfTH, b0 = tw * kSfTW;
+    if (tt) __syncthreads();                               // every wave is done with the previous window
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int f = tid + 256 * k;
+      const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
+      if (f < kSfRows * kSfRowFloats) patch[rr][cc] = stage[k];
+    }
+    __syncthreads();
+    if (tt + 1 < kSfTilesPerWg && tile + 1 < tiles_total) issue(tile + 1);     // the next window travels during this tile's arithmetic
+#pragma unroll 2
+    for (int pass = 0; pass < kPasses; ++pass) {
+      const int pix = pass * PP + ps, r = pix / kSfTW, c = pix % kSfTW;
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* row = &patch[2 * r + kh][6 * c];      // (kw, ci) = 9 consecutive floats
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float xv = row[t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, wr[j][kh * 9 + t], acc[j]);
+        }
+      }
+      const int oh = a0 + r, ow = b0 + c;
+      if (oh < Ho && ow < Wo) {
+        *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oh) * Wo + ow) * kCo + 4 * cq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][ps][4 * cq + j] = s1[j]; red[1][ps][4 * cq + j] = s2[j]; }
+    __syncthreads();
+    if (tid < 2 * kCo) {
+      const int which = tid / kCo, ch = tid % kCo;
+      float t = 0.0f;
+      for (int k = 0; k < PP; ++k) t += red[which][k][ch];
+      stats[((size_t)blockIdx.x * 2 + which) * kCo + ch] = t;
+    }
+  }
+}
+
 int conv_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -1103,6 +1194,25 @@ int t2o_conv3x3_fwd_stats_nhwc(const float* x, const float* w, float* y, float* 
   hipStream_t st = (hipStream_t)stream;
   const int rc = launch_fwd(x, w, y, zero_region(workspace, need, st), N, Ho, Wo, Ci, Co, st, stride, stats);
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_fwd_stats launch failed");
+}
+
+int t2o_stem_fwd_stats_rows(int N, int Ho, int Wo) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  const long long tiles = (long long)N * ((Ho + kSfTH - 1) / kSfTH) * ((Wo + kSfTW - 1) / kSfTW);
+  return (int)((tiles + kSfTilesPerWg - 1) / kSfTilesPerWg);
+}
+
+int t2o_stem_fwd_nhwc(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, void* stream) {
+  if (!x || !w || !y) return set_error(T2O_EINVAL, "stem_fwd: null pointer");
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || (Co != 32 && Co != 64) || (size_t)N * Ho * Wo * 4 * 3 >= ((size_t)1 << 40))
+    return set_error(T2O_EUNSUPPORTED, "stem_fwd: 3 input channels, 32 or 64 output channels");
+  const long long tiles = (long long)N * ((Ho + kSfTH - 1) / kSfTH) * ((Wo + kSfTW - 1) / kSfTW);
+  if (tiles >= ((long long)1 << 30)) return set_error(T2O_EUNSUPPORTED, "stem_fwd: too many tiles");
+  const unsigned grid = (unsigned)t2o_stem_fwd_stats_rows(N, Ho, Wo);
+  hipStream_t st = (hipStream_t)stream;
+  if (Co == 64) k_stem_fwd<64><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles);
+  else k_stem_fwd<32><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_fwd launch failed");
 }
 
 size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {

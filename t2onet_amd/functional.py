@@ -518,6 +518,26 @@ def conv3x3s2_forward(x, weight, want_stats=False):
     return y
 
 
+def stem_forward(x, weight, want_stats=False):
+    """conv2d(x, weight, None, stride 2, padding 1) for the encoder's stem: 3 input channels, 32 / 64 output channels
+    (t2o_stem_fwd_nhwc).  x (N,3,2Ho,2Wo), weight (Co,3,3,3) channels-last; returns y (N,Co,Ho,Wo) channels-last, with
+    want_stats also the (rows, 2, Co) partial sums for batch_norm_relu(..., partial=)."""
+    _need_gpu(x, weight)
+    N, Ci, Hi, Wi = x.shape
+    Co = weight.shape[0]
+    if Ci != 3 or Co not in (32, 64) or Hi % 2 or Wi % 2:
+        raise ValueError('stem_forward: 3 input channels, 32 or 64 output channels, even image size')
+    Ho, Wo = Hi // 2, Wi // 2
+    x = x.contiguous(memory_format=torch.channels_last)
+    weight = weight.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    stats = torch.empty((lib.t2o_stem_fwd_stats_rows(N, Ho, Wo), 2, Co), dtype=torch.float32, device=x.device) if want_stats else None
+    rc = lib.t2o_stem_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(stats), N, Ho, Wo, Co, _stream(x.device))
+    _lib.check(rc, 't2o_stem_fwd_nhwc')
+    return (y, stats) if want_stats else y
+
+
 def conv3x3s2_wgrad(x, dy):
     """Weight gradient of conv2d(x, w, None, stride 2, padding 1) (t2o_conv3x3s2_wgrad_nhwc).  x (N,Ci,2Ho,2Wo),
     dy (N,Co,Ho,Wo), both channels-last; returns dw (Co,Ci,3,3) channels-last."""
@@ -560,12 +580,14 @@ class _Conv3x3S2Fn(torch.autograd.Function):
     def forward(ctx, x, weight, want_stats=False):
         ctx.save_for_backward(x, weight)
         own = 'F' in _CONV_OWN and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0 and x.shape[3] % 16 == 0
+        stem = 'T' in _CONV_OWN and weight.shape[1] == 3 and weight.shape[0] in (32, 64)
+        fwd = conv3x3s2_forward if own else stem_forward if stem else None
         if want_stats:                                       # (y, stats); stats None where the library computes y
-            y, stats = conv3x3s2_forward(x, weight, True) if own else (torch.nn.functional.conv2d(x, weight, None, 2, 1), None)
+            y, stats = fwd(x, weight, True) if fwd else (torch.nn.functional.conv2d(x, weight, None, 2, 1), None)
             if stats is not None:
                 ctx.mark_non_differentiable(stats)
             return y, stats
-        return conv3x3s2_forward(x, weight) if own else torch.nn.functional.conv2d(x, weight, None, 2, 1)
+        return fwd(x, weight) if fwd else torch.nn.functional.conv2d(x, weight, None, 2, 1)
 
     @staticmethod
     def backward(ctx, dy, _gstats=None):
@@ -601,8 +623,8 @@ def conv3x3_supported(x, weight, stride, padding):
 
 # which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
 # 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 'F' forward, 's' data gradient, 'S' weight
-# gradient of the stride-2 layers
-_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdFsS')
+# gradient of the stride-2 layers, 'T' forward of the 3-channel stem
+_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdFsST')
 
 
 def _own_direct(x):

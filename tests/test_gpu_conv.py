@@ -332,3 +332,43 @@ def test_encoder_with_and_without_convolution_statistics_agree(monkeypatch):
     assert rel(xa.grad, xb.grad) <= 2e-3
     for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
         assert rel(pa.grad, pb.grad) <= 2e-3, n
+
+
+# (N, Co, Ho, Wo): full and ragged tiles (8 x 32 outputs), one-row / one-column images, both channel counts, several
+# tiles per workgroup
+@pytest.mark.parametrize('shape', [(2, 64, 8, 32), (3, 32, 5, 12), (1, 64, 1, 40), (2, 64, 17, 1), (5, 64, 16, 64), (2, 32, 9, 70)])
+def test_stem_forward_matches_conv2d_fp64_and_leaves_statistics(shape):
+    """t2o_stem_fwd_nhwc: conv2d(x, w, None, 2, 1) with 3 input channels (models/actor_resnet.py:99) and the channel
+    sums / sums of squares of its output."""
+    import t2onet_amd.functional as T
+    N, Co, Ho, Wo = shape
+    x = synth.uniform((N, 3, 2 * Ho, 2 * Wo), 795, 0.0, 1.0)
+    w = synth.uniform((Co, 3, 3, 3), 796, -1.0, 1.0)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 1)
+    dev = torch.device('cuda:0')
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    wg = w.to(dev).contiguous(memory_format=torch.channels_last)
+    y = T.stem_forward(xg, wg)
+    assert y.shape == (N, Co, Ho, Wo) and y.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    y2, st = T.stem_forward(xg, wg, True)
+    assert torch.equal(y, y2) and st.shape[1:] == (2, Co)
+    y64 = y.double()
+    want = torch.stack([y64.sum((0, 2, 3)), (y64 * y64).sum((0, 2, 3))]).cpu().numpy()
+    np.testing.assert_allclose(st.double().sum(0).cpu().numpy(), want, rtol=2e-6, atol=2e-6 * np.abs(want).max())
+    assert torch.equal(st, T.stem_forward(xg, wg, True)[1])
+
+
+def test_stem_autograd_function_matches_library():
+    """The stem through conv3x3s2 (own forward and data gradient, library weight gradient) against F.conv2d."""
+    import t2onet_amd.functional as T
+    dev = torch.device('cuda:0')
+    x = synth.uniform((3, 3, 32, 48), 797, 0.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    w = synth.uniform((64, 3, 3, 3), 798, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    g = synth.uniform((3, 64, 16, 24), 799, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xb, wb = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    T.conv3x3s2(xa, wa).backward(g)
+    torch.nn.functional.conv2d(xb, wb, None, 2, 1).backward(g)
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(xb.grad.abs().max()))
+    np.testing.assert_allclose(wa.grad.cpu().numpy(), wb.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(wb.grad.abs().max()))
