@@ -252,6 +252,13 @@ int t2o_conv3x3_fwd_stats_nhwc(const float* x, const float* w, float* y, float* 
 int t2o_stem_fwd_stats_rows(int N, int Ho, int Wo);
 int t2o_stem_fwd_nhwc(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, void* stream);
 
+/* Weight gradient of the same stem convolution: x (N, 2Ho, 2Wo, 3), dy (N, Ho, Wo, Co) -> dw (Co,3,3,3) channels-last.
+ * Deterministic (per-workgroup partial blocks in the workspace, added in order), unlike the atomic kernel the library
+ * picks for this layer.  Workspace: t2o_stem_wgrad_workspace_bytes. */
+size_t t2o_stem_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co);
+int t2o_stem_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int Ho, int Wo,
+                        int Co, void* stream);
+
 /* ---- weight gradient of the same stride-2 convolutions (t2o_conv.hip, the stride-1 kernel with a two-plane x tile):
  *   dw[co][kh][kw][ci] = sum_{n,a,b} dy[n][a][b][co] * x[n][2a+kh-1][2b+kw-1][ci]   (zero padding)
  *   x (N,2Ho,2Wo,Ci), dy (N,Ho,Wo,Co), dw (Co,3,3,Ci).  Ci, Co multiples of 64, Wo a multiple of 4.  Deterministic

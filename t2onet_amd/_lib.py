@@ -72,6 +72,8 @@ SIGNATURES = {
     't2o_conv3x3_fwd_stats_nhwc': (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     't2o_stem_fwd_stats_rows': (_I, [_I, _I, _I]),
     't2o_stem_fwd_nhwc': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    't2o_stem_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I]),
+    't2o_stem_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3s2_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_dgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),

@@ -1016,6 +1016,90 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
   }
 }
 
+// ---- weight gradient of the stem: dw[co][kh][kw][ci] = sum over output pixels of dy[p][co] * x[window of p][kh][kw][ci]
+// The forward kernel with the roles of weights and accumulators exchanged: the same input window in LDS, the same
+// thread = (pixel slot, channel quad); a thread keeps 4 x 27 accumulators across its workgroup's tiles and reads its
+// pixel's 4 dy values with one 16-byte load (the 16 threads of a pixel: 256 consecutive bytes).  The pixel slots are
+// combined through LDS in a fixed order, one partial (Co, 27) block per workgroup, k_conv_wgrad_reduce adds the
+// blocks: deterministic, no atomics, no output clearing (the library's kernel for this layer adds atomically).
+template <int kCo>
+__global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                    int N, int Ho, int Wo, int tiles_total) {
+  constexpr int CQ = kCo / 4, PP = 256 / CQ, kPasses = (kSfTH * kSfTW) / PP;
+  __shared__ __attribute__((aligned(16))) float patch[kSfRows][kSfRowFloats + 1];
+  __shared__ float red[PP][kCo + 1];
+  const int tid = threadIdx.x, cq = tid % CQ, ps = tid / CQ;
+  const int tiles_w = (Wo + kSfTW - 1) / kSfTW, tiles_h = (Ho + kSfTH - 1) / kSfTH;
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  float acc[4][27];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[j][t] = 0.0f;
+  constexpr int kLoads = (kSfRows * kSfRowFloats + 255) / 256;
+  float stage[kLoads];
+  auto issue = [&](int tile) {
+    const int n = tile / (tiles_h * tiles_w), th = (tile / tiles_w) % tiles_h, tw = tile % tiles_w;
+    const int ih0 = 2 * th * kSfTH - 1, iw0 = 2 * tw * kSfTW - 1;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int f = tid + 256 * k;
+      const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
+      const int ih = ih0 + rr, iw = iw0 + cc / 3;
+      stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * Hi + ih) * Wi + iw0) * 3 + cc] : 0.0f;
+    }
+  };
+  const int tile0 = blockIdx.x * kSfTilesPerWg;
+  if (tile0 < tiles_total) issue(tile0);
+  for (int tt = 0; tt < kSfTilesPerWg; ++tt) {
+    const int tile = tile0 + tt;
+    if (tile >= tiles_total) break;                        // (workgroup-uniform)
+    const int n = tile / (tiles_h * tiles_w), th = (tile / tiles_w) % tiles_h, tw = tile % tiles_w;
+    const int a0 = th * kSfTH, b0 = tw * kSfTW;
+    if (tt) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int f = tid + 256 * k;
+      const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
+      if (f < kSfRows * kSfRowFloats) patch[rr][cc] = stage[k];
+    }
+    __syncthreads();
+    if (tt + 1 < kSfTilesPerWg && tile + 1 < tiles_total) issue(tile + 1);
+#pragma unroll 2
+    for (int pass = 0; pass < kPasses; ++pass) {
+      const int pix = pass * PP + ps, r = pix / kSfTW, c = pix % kSfTW;
+      const int oh = a0 + r, ow = b0 + c;
+      float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // pixels outside the image add nothing
+      if (oh < Ho && ow < Wo) d = ldg4(dy + (((size_t)n * Ho + oh) * Wo + ow) * kCo + 4 * cq);
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* row = &patch[2 * r + kh][6 * c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float xv = row[t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j][kh * 9 + t] = fmaf(dv[j], xv, acc[j][kh * 9 + t]);
+        }
+      }
+    }
+  }
+  // the PP pixel slots of every (channel, tap), one tap at a time through LDS, slots added in order
+  float* out = partial + (size_t)blockIdx.x * kCo * 27;
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[ps][4 * cq + j] = acc[j][t];
+    __syncthreads();
+    if (tid < kCo) {
+      float sum = 0.0f;
+      for (int k = 0; k < PP; ++k) sum += red[k][tid];
+      out[tid * 27 + t] = sum;
+    }
+  }
+}
+
 int conv_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -1213,6 +1297,29 @@ int t2o_stem_fwd_nhwc(const float* x, const float* w, float* y, float* stats, in
   if (Co == 64) k_stem_fwd<64><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles);
   else k_stem_fwd<32><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_fwd launch failed");
+}
+
+size_t t2o_stem_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co) {
+  if (Co != 32 && Co != 64) return 0;
+  return sizeof(float) * (size_t)t2o_stem_fwd_stats_rows(N, Ho, Wo) * Co * 27;
+}
+
+int t2o_stem_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int Ho, int Wo,
+                        int Co, void* stream) {
+  if (!x || !dy || !dw) return set_error(T2O_EINVAL, "stem_wgrad: null pointer");
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || (Co != 32 && Co != 64)) return set_error(T2O_EUNSUPPORTED, "stem_wgrad: 3 input channels, 32 or 64 output channels");
+  const long long tiles = (long long)N * ((Ho + kSfTH - 1) / kSfTH) * ((Wo + kSfTW - 1) / kSfTW);
+  if (tiles >= ((long long)1 << 30)) return set_error(T2O_EUNSUPPORTED, "stem_wgrad: too many tiles");
+  const size_t need = t2o_stem_wgrad_workspace_bytes(N, Ho, Wo, Co);
+  if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "stem_wgrad: workspace too small");
+  const int rows = t2o_stem_fwd_stats_rows(N, Ho, Wo);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  if (Co == 64) k_stem_wgrad<64><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles);
+  else k_stem_wgrad<32><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles);
+  const size_t n = (size_t)Co * 27, n4 = n / 4;
+  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(partial, dw, n4, rows, n);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_wgrad launch failed");
 }
 
 size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {

@@ -538,6 +538,23 @@ def stem_forward(x, weight, want_stats=False):
     return (y, stats) if want_stats else y
 
 
+def stem_wgrad(x, dy):
+    """Weight gradient of the stem convolution (t2o_stem_wgrad_nhwc): x (N,3,2Ho,2Wo), dy (N,Co,Ho,Wo), Co = 32 / 64,
+    both channels-last; returns dw (Co,3,3,3) channels-last.  Deterministic."""
+    _need_gpu(x, dy)
+    N, Co, Ho, Wo = dy.shape
+    if tuple(x.shape) != (N, 3, 2 * Ho, 2 * Wo) or Co not in (32, 64):
+        raise ValueError('stem_wgrad: x must be (N, 3, 2 Ho, 2 Wo) and dy have 32 or 64 channels')
+    x = x.contiguous(memory_format=torch.channels_last)
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    ws = torch.empty(lib.t2o_stem_wgrad_workspace_bytes(N, Ho, Wo, Co), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((Co, 3, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    rc = lib.t2o_stem_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), N, Ho, Wo, Co, _stream(x.device))
+    _lib.check(rc, 't2o_stem_wgrad_nhwc')
+    return dw
+
+
 def conv3x3s2_wgrad(x, dy):
     """Weight gradient of conv2d(x, w, None, stride 2, padding 1) (t2o_conv3x3s2_wgrad_nhwc).  x (N,Ci,2Ho,2Wo),
     dy (N,Co,Ho,Wo), both channels-last; returns dw (Co,Ci,3,3) channels-last."""
@@ -596,7 +613,8 @@ class _Conv3x3S2Fn(torch.autograd.Function):
         own = ctx.needs_input_grad[0] and 's' in _CONV_OWN
         own_w = (ctx.needs_input_grad[1] and 'S' in _CONV_OWN and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
                  and dy.shape[3] % 4 == 0)
-        mask = [ctx.needs_input_grad[0] and not own, ctx.needs_input_grad[1] and not own_w, False]
+        stem_w = ctx.needs_input_grad[1] and 'W' in _CONV_OWN and weight.shape[1] == 3 and weight.shape[0] in (32, 64)
+        mask = [ctx.needs_input_grad[0] and not own, ctx.needs_input_grad[1] and not own_w and not stem_w, False]
         dx = dw = None
         if mask[0] or mask[1]:
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, mask)
@@ -604,6 +622,8 @@ class _Conv3x3S2Fn(torch.autograd.Function):
             dx = conv3x3s2_dgrad(dy, weight)
         if own_w:
             dw = conv3x3s2_wgrad(x, dy)
+        elif stem_w:
+            dw = stem_wgrad(x, dy)
         return dx, dw, None
 
 
@@ -623,8 +643,8 @@ def conv3x3_supported(x, weight, stride, padding):
 
 # which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
 # 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 'F' forward, 's' data gradient, 'S' weight
-# gradient of the stride-2 layers, 'T' forward of the 3-channel stem
-_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdFsST')
+# gradient of the stride-2 layers, 'T' forward and 'W' weight gradient of the 3-channel stem
+_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdFsSTW')
 
 
 def _own_direct(x):

@@ -360,7 +360,7 @@ def test_stem_forward_matches_conv2d_fp64_and_leaves_statistics(shape):
 
 
 def test_stem_autograd_function_matches_library():
-    """The stem through conv3x3s2 (own forward and data gradient, library weight gradient) against F.conv2d."""
+    """The stem through conv3x3s2 (own forward, data gradient and weight gradient) against F.conv2d."""
     import t2onet_amd.functional as T
     dev = torch.device('cuda:0')
     x = synth.uniform((3, 3, 32, 48), 797, 0.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
@@ -372,3 +372,22 @@ def test_stem_autograd_function_matches_library():
     torch.nn.functional.conv2d(xb, wb, None, 2, 1).backward(g)
     np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(xb.grad.abs().max()))
     np.testing.assert_allclose(wa.grad.cpu().numpy(), wb.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(wb.grad.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 8, 32), (3, 32, 5, 12), (1, 64, 1, 40), (2, 64, 17, 1), (5, 64, 16, 64), (2, 32, 9, 70), (40, 64, 32, 32)])
+def test_stem_wgrad_matches_conv2d_fp64(shape):
+    """t2o_stem_wgrad_nhwc against the weight gradient of F.conv2d(x, w, None, 2, 1) in fp64; bit-identical on a rerun."""
+    import t2onet_amd.functional as T
+    N, Co, Ho, Wo = shape
+    x = synth.uniform((N, 3, 2 * Ho, 2 * Wo), 793, 0.0, 1.0)
+    dy = synth.uniform((N, Co, Ho, Wo), 794, -1.0, 1.0)
+    w = torch.zeros(Co, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(x.double(), w, None, 2, 1) * dy.double()).sum().backward()
+    ref = w.grad
+    dev = torch.device('cuda:0')
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    dg = dy.to(dev).contiguous(memory_format=torch.channels_last)
+    dw = T.stem_wgrad(xg, dg)
+    assert dw.shape == (Co, 3, 3, 3) and dw.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert torch.equal(dw, T.stem_wgrad(xg, dg))
