@@ -887,12 +887,20 @@ __global__ __launch_bounds__(256) void k_stem_dgrad(const float* __restrict__ dy
   for (int c0 = 0; c0 < kCo; c0 += kPass) {
     if (c0) __syncthreads();
     // stage dy[n][a0 .. a0+8][b0 .. b0+32][c0 .. c0+32): 8 consecutive threads read one pixel's 128 bytes
-    for (int f = threadIdx.x; f < kStemPix * CQ; f += 256) {
+    constexpr int kLoads = (kStemPix * CQ + 255) / 256;    // 10 per thread: all in flight before the first LDS store
+    float4 stage[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int f = threadIdx.x + 256 * k;
       const int px = f / CQ, cq = f % CQ;
       const int sa = a0 + px / (kStemTW + 1), sb = b0 + px % (kStemTW + 1);
-      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (sa < Ho && sb < Wo) v = ldg4(dy + (((size_t)n * Ho + sa) * Wo + sb) * kCo + c0 + 4 * cq);
-      tile[cq][px] = v;
+      stage[k] = (f < kStemPix * CQ && sa < Ho && sb < Wo) ? ldg4(dy + (((size_t)n * Ho + sa) * Wo + sb) * kCo + c0 + 4 * cq)
+                                                            : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const int f = threadIdx.x + 256 * k;
+      if (f < kStemPix * CQ) tile[f % CQ][f / CQ] = stage[k];
     }
     __syncthreads();
 #pragma unroll 2
