@@ -310,6 +310,60 @@ int t2o_param_heads_bwd_acc(const int* op_id, const float* ctx, const float* con
                         float* const* gw2, float* const* gb2, float brightness_range, float sat_lo, float sat_hi,
                         float sharpness_range, int B, int D, int accumulate, void* stream);
 
+/* ---- round 3: the forms the encoder's explicit forward/backward schedule (t2onet_amd/encoder.py) calls ----
+ * Gradient buffers of a trainer are persistent and zeroed once per step, so the weight-gradient kernels can ADD their
+ * result (accumulate != 0; every element has one writer: still deterministic) instead of handing a fresh tensor to an
+ * accumulation launch; transformed weights are made once per optimiser step, not once per data-gradient call. */
+
+/* t2o_bn_relu_nhwc_bwd with accumulate: dweight / dbias += instead of = (models/actor_resnet.py:38-44 backward). */
+int t2o_bn_relu_nhwc_bwd_acc(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
+                             const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
+                             float* dbias, int has_res, int relu, int accumulate, void* workspace, size_t workspace_bytes,
+                             int M, int C, void* stream);
+
+/* Weight gradient of a 3x3 convolution, stride 1 or 2 ((N,Ho,Wo) = the dy grid; shapes / workspace as
+ * t2o_conv3x3_wgrad_nhwc / t2o_conv3x3s2_wgrad_nhwc); accumulate != 0: dw += . */
+int t2o_conv3x3_wgrad_acc_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                               int N, int Ho, int Wo, int Ci, int Co, int stride, int accumulate, void* stream);
+
+/* wt[ci][t'][co] = w[co][t][ci] for a (Co, taps, Ci) weight, t' = taps-1-t when flip != 0 else t.  taps = 9, flip = 1: the
+ * weight the stride-1 data gradient runs the forward kernel with; taps = 9, flip = 0: the stride-2 data gradient's;
+ * taps = 1: the transposed 1x1 shortcut weight.  Co, Ci multiples of 32. */
+int t2o_conv_weight_transform(const float* w, float* wt, int Co, int Ci, int taps, int flip, void* stream);
+
+/* t2o_conv3x3_dgrad_nhwc with the transformed weight supplied (wt from t2o_conv_weight_transform(w, wt, Co, Ci, 9, 1))
+ * and an optional addend (N,H,W,Ci) added to dx in the kernel's epilogue: the gradient a BasicBlock's input receives
+ * through the identity shortcut (models/actor_resnet.py:43 `out += self.shortcut(x)`), so no separate add pass.
+ * workspace: t2o_conv3x3_fwd_workspace_bytes(N, H, W, Co, Ci) (the zero region only). */
+int t2o_conv3x3_dgrad_pre_nhwc(const float* dy, const float* wt, const float* addend, float* dx, void* workspace,
+                               size_t workspace_bytes, int N, int H, int W, int Ci, int Co, void* stream);
+/* t2o_conv3x3s2_dgrad_nhwc with wt = t2o_conv_weight_transform(w, wt, Co, Ci, 9, 0) supplied. */
+int t2o_conv3x3s2_dgrad_pre_nhwc(const float* dy, const float* wt, float* dx, void* workspace, size_t workspace_bytes,
+                                 int N, int Ho, int Wo, int Ci, int Co, void* stream);
+
+/* The stem (models/actor_resnet.py:99, conv 3 -> 32 / 64, stride 2) reading / writing the image in its own layout:
+ * planar != 0: x / dx are (N,3,2Ho,2Wo) NCHW (what the operators produce: no channels-last copy of the image per encoder
+ * call); planar == 0: (N,2Ho,2Wo,3).  y / dy are (N,Ho,Wo,Co) NHWC, w (Co,3,3,3) channels-last.  accumulate != 0: the
+ * weight gradient is added to dw, the data gradient to dx (the image gradient already holds the operator's part). */
+int t2o_stem_fwd(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, int planar, void* stream);
+int t2o_stem_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int Ho, int Wo,
+                   int Co, int planar, int accumulate, void* stream);
+int t2o_stem_dgrad(const float* dy, const float* w, float* dx, int N, int Ho, int Wo, int Co, int planar, int accumulate, void* stream);
+
+/* ---- the 1x1 stride-2 shortcut convolutions of the encoder's stages (models/actor_resnet.py:33-36: nn.Conv2d(in, out,
+ * kernel_size=1, stride=stride, bias=False)), fp32 matrix cores (t2o_conv1x1.hip).  Ho = (H+1)/2, Wo = (W+1)/2.
+ *   forward        y[n][a][b][co]    = sum_ci x[n][2a][2b][ci] * w[co][ci]                x (N,H,W,Ci), w (Co,Ci), y (N,Ho,Wo,Co)
+ *   data gradient  dx[n][2a][2b][ci] += sum_co dy[n][a][b][co] * w[co][ci]                ADDS into an existing dx (the 3x3
+ *                  branch's data gradient, which covers every pixel); wt (Ci,Co) = t2o_conv_weight_transform(w, wt, Co, Ci, 1, 0)
+ *   weight gradient dw[co][ci]       (+)= sum_{n,a,b} dy[n][a][b][co] * x[n][2a][2b][ci]   deterministic split-K
+ * Ci, Co multiples of 64.  Replace F.conv2d(x, w, None, 2) and both halves of convolution_backward for these layers
+ * (the library's kernels add atomically and need their output cleared first). */
+int t2o_conv1x1s2_fwd_nhwc(const float* x, const float* w, float* y, int N, int H, int W, int Ci, int Co, void* stream);
+int t2o_conv1x1s2_dgrad_acc_nhwc(const float* dy, const float* wt, float* dx, int N, int H, int W, int Ci, int Co, void* stream);
+size_t t2o_conv1x1s2_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
+int t2o_conv1x1s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                             int N, int H, int W, int Ci, int Co, int accumulate, void* stream);
+
 /* Rewrites a captured, not yet instantiated hipGraph (hipGraph_t) in place: every memset node becomes a kernel node
  * doing the same fill, with the same dependencies and dependents; *replaced = how many.  Memset nodes were seen to
  * run out of order with neighbouring kernel nodes on replay (ROCm 7.2 / gfx950): t2onet_amd/graphs.py calls this on

@@ -78,6 +78,18 @@ SIGNATURES = {
     't2o_conv3x3s2_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_dgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3s2_dgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    't2o_bn_relu_nhwc_bwd_acc': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _I, _I, _P]),
+    't2o_conv3x3_wgrad_acc_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_conv_weight_transform': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    't2o_conv3x3_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    't2o_conv3x3s2_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    't2o_stem_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_stem_wgrad': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_stem_dgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_conv1x1s2_fwd_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_conv1x1s2_dgrad_acc_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_conv1x1s2_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
+    't2o_conv1x1s2_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -1,8 +1,13 @@
 """Image encoder of the actor (models/actor_resnet.py): ResNet-18 layout with a 3x3 stride-2
 stem, no max-pool, every stage stride 2 (/32), global mean, fc.  The only dense contraction of
-the hot path: convolutions go to MIOpen (MFMA) through PyTorch-ROCm.  The HBM-bound passes between
-them -- training-mode batch norm, residual add, ReLU -- are one fused HIP statistics pass + one fused
-apply pass (t2o_bn_relu_fwd / _bwd); evaluation mode and CPU tensors take PyTorch's own batch norm.
+the hot path.  Three ways through it, same arithmetic:
+  * training mode, channels-last weights, a GPU image whose stages the matrix-core kernels take (W % 256 == 0,
+    H % 32 == 0): the whole convolutional trunk is ONE autograd node with an explicit forward / backward schedule over
+    this library's kernels (encoder.py: every convolution incl. the 1x1 shortcuts, fused batch norm + add + ReLU,
+    in-kernel gradient accumulation) -- no library convolution, no autograd between the layers;
+  * other training-mode GPU calls: per-layer autograd functions (functional.py) -- own kernels where the shape allows,
+    library (MIOpen) convolutions elsewhere, fused batch-norm kernels;
+  * evaluation mode / CPU tensors: plain PyTorch modules.
 Module names follow the reference so its checkpoints load."""
 import os
 
@@ -24,6 +29,8 @@ _OWN_WGRAD = os.environ.get('T2O_OWN_WGRAD', '1') != '0'
 # T2O_CONV_BN_STATS=0: every fused batch norm makes its own statistics pass (A/B); default: the own forward
 # convolution leaves the per-channel sums of its output (from its accumulators) and the batch norm starts there
 _CONV_STATS = os.environ.get('T2O_CONV_BN_STATS', '1') != '0'
+# T2O_TRUNK=0: never take the one-node trunk (encoder.py); the per-layer path everywhere (A/B, and what the tests compare it with)
+_TRUNK = os.environ.get('T2O_TRUNK', '1') != '0'
 
 
 def _conv(conv, x, bn=None):
@@ -111,7 +118,22 @@ class ResNet(nn.Module):
             self.in_planes = planes
         return nn.Sequential(*blocks)
 
+    def trunk_plan(self):
+        """The explicit-schedule trunk (encoder.TrunkPlan), built once (not a submodule: state_dict unchanged)."""
+        plan = self.__dict__.get('_trunk_plan')
+        if plan is None or plan.params[0] is not self.conv1.weight:       # (.to() / a re-homed parameter: rebuild)
+            from .encoder import TrunkPlan
+            plan = self.__dict__['_trunk_plan'] = TrunkPlan(self)
+        return plan
+
     def forward(self, x):
+        if _TRUNK and _FUSED and _OWN_WGRAD and self.training and x.is_cuda and torch.is_grad_enabled():
+            plan = self.trunk_plan()
+            if plan.supported(x):
+                from .encoder import trunk_forward
+                torch._foreach_add_(self._batch_counters(), 1)
+                x = trunk_forward(plan, x).mean((2, 3))
+                return self.fc(x.view(x.size(0), -1))
         if self.conv1.weight.is_contiguous(memory_format=torch.channels_last) and x.is_cuda:
             # channels-last encoder (Actor.use_channels_last): one packed NHWC copy of the 3-channel image, then every
             # convolution and every fused batch-norm pass runs NHWC -- no layout transposes inside the encoder

@@ -370,7 +370,8 @@ __global__ __launch_bounds__(kConvThreads, kMinWaves) void k_conv3x3_wgrad(Wgrad
 // output; its 8 thread rows each add every 8th split (in split order), then the 8 partial sums are added in row
 // order through LDS: deterministic, and 8 x as many loads in flight as one thread per output (with 168 splits of
 // a 64-channel layer that serial loop took 50 us for 25 MB).
-__global__ __launch_bounds__(kConvThreads) void k_conv_wgrad_reduce(const float* partial, float* dw, size_t n4, int splits, size_t stride) {
+// acc != 0: the sum is ADDED to dw (a trainer's persistent, pre-zeroed gradient buffer; one writer per element).
+__global__ __launch_bounds__(kConvThreads) void k_conv_wgrad_reduce(const float* partial, float* dw, size_t n4, int splits, size_t stride, int acc) {
   __shared__ float4 part[8][32];
   const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
   const size_t i = (size_t)blockIdx.x * 32 + col;
@@ -386,6 +387,10 @@ __global__ __launch_bounds__(kConvThreads) void k_conv_wgrad_reduce(const float*
 #pragma unroll
     for (int r = 1; r < 8; ++r) {
       const float4 v = part[r][col];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (acc) {
+      const float4 v = ldg4(dw + 4 * i);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     *reinterpret_cast<float4*>(dw + 4 * i) = s;
@@ -421,6 +426,8 @@ struct FwdArgs {
   int N, H, W, Ci, Co;
   int tiles_p, tiles_n;
   float* stats;         // null, or (tiles_p, 2, Co): per pixel tile the sum and the sum of squares of y per channel
+  const float* addend;  // null, or (N,H,W,Co): added to y in the epilogue (the data gradient of a block's first convolution
+                        // plus the gradient its input receives through the identity shortcut: one pass instead of an add kernel)
   unsigned long long* stamps;   // diagnostic builds only
 };
 
@@ -631,7 +638,10 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int p = p0 + wm * 32 * kBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (p < P) a.y[(size_t)p * a.Co + co0 + wn * 32 + ln] = acc[i][r];
+      if (p < P) {
+        const size_t o = (size_t)p * a.Co + co0 + wn * 32 + ln;
+        a.y[o] = a.addend ? acc[i][r] + a.addend[o] : acc[i][r];
+      }
     }
   // Batch-norm statistics of the layer that follows, straight from the accumulators (a lane holds 16 * kBM pixels of
   // ONE channel): the statistics pass over y (one full read of the activation) is not needed.  Rows past the end
@@ -665,15 +675,16 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 
 // wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci] (flip: the stride-1 data gradient is the forward kernel on dy with these
 // weights) or wt[ci][kh][kw][co] = w[co][kh][kw][ci] (no flip: the stride-2 data gradient indexes taps itself)
+// (taps = gridDim.z: 9 for the 3x3 layers, 1 for the 1x1 shortcuts -- a plain transpose)
 __global__ __launch_bounds__(kConvThreads) void k_conv_flip_weight(const float* w, float* wt, int Co, int Ci, int flip) {
   __shared__ float tile[32][33];
-  const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int taps = gridDim.z, tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((size_t)(co0 + r) * 9 + tap) * Ci + ci0 + tx];
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((size_t)(co0 + r) * taps + tap) * Ci + ci0 + tx];
   __syncthreads();
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * 9 + (flip ? 8 - tap : tap)) * Co + co0 + tx] = tile[tx][r];
+  for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * taps + (flip ? taps - 1 - tap : tap)) * Co + co0 + tx] = tile[tx][r];
 }
 
 // ================================================================================================================
@@ -870,9 +881,11 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a
 constexpr int kStemTH = 8, kStemTW = 32;                 // dy-grid tile of a workgroup (256 threads)
 constexpr int kStemPix = (kStemTH + 1) * (kStemTW + 1);  // with the +1 row / column the taps kh = 0 / kw = 0 read
 
-template <int kCo>
+// kPlanar: dx is (N,3,2Ho,2Wo) -- the image's own NCHW layout -- and, with acc != 0, the result is ADDED to it (the image
+// gradient already holds the operator's contribution: no add kernel, no layout conversion).
+template <int kCo, bool kPlanar>
 __global__ __launch_bounds__(256) void k_stem_dgrad(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                    int N, int Ho, int Wo) {
+                                                    int N, int Ho, int Wo, int acc_out) {
   constexpr int kPass = 32;                              // channels staged per pass: 38 KB of LDS, 4 workgroups per CU
   constexpr int CQ = kPass / 4;
   __shared__ float4 tile[CQ][kStemPix + 1];              // (+1: plane stride 298 * 16 B, co-prime with the 16 bank groups of a b128 access)
@@ -924,11 +937,23 @@ __global__ __launch_bounds__(256) void k_stem_dgrad(const float* __restrict__ dy
     }
   }
   if (al < Ho && be < Wo) {
+    if constexpr (kPlanar) {
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      float* o = dx + ((((size_t)n * 2 * Ho + 2 * al + ph) * 2 * Wo) + 2 * be) * 3;      // 6 consecutive floats (pw = 0, 1)
+      for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int q = 0; q < 6; ++q) o[q] = acc[ph][q / 3][q % 3];
+        for (int ph = 0; ph < 2; ++ph) {
+          float2* o = reinterpret_cast<float2*>(dx + (((size_t)n * 3 + c) * 2 * Ho + 2 * al + ph) * 2 * Wo + 2 * be);
+          float2 v = make_float2(acc[ph][0][c], acc[ph][1][c]);
+          if (acc_out) { const float2 u = *o; v.x += u.x; v.y += u.y; }
+          *o = v;
+        }
+    } else {
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        float* o = dx + ((((size_t)n * 2 * Ho + 2 * al + ph) * 2 * Wo) + 2 * be) * 3;      // 6 consecutive floats (pw = 0, 1)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[q] = acc_out ? o[q] + acc[ph][q / 3][q % 3] : acc[ph][q / 3][q % 3];
+      }
     }
   }
 }
@@ -940,10 +965,10 @@ __global__ __launch_bounds__(256) void k_stem_dgrad(const float* __restrict__ dy
 // registers across the workgroup's tiles.  stats (optional): one row (2, Co) per workgroup -- sum and sum of squares of
 // its outputs per channel, pixel slots added in a fixed order -- for t2o_bn_relu_nhwc_fwd_partials.
 constexpr int kSfTH = 8, kSfTW = 32;
-constexpr int kSfRows = 2 * kSfTH + 1, kSfRowFloats = (2 * kSfTW + 1) * 3;      // 17 rows of 195 floats
+constexpr int kSfRows = 2 * kSfTH + 1, kSfRowPix = 2 * kSfTW + 1, kSfRowFloats = kSfRowPix * 3;      // 17 rows of 65 pixels = 195 floats
 constexpr int kSfTilesPerWg = 8;          // consecutive tiles of a workgroup: the next window is loaded during a tile's arithmetic
 
-template <int kCo>
+template <int kCo, bool kPlanar>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                   float* __restrict__ stats, int N, int Ho, int Wo, int tiles_total) {
   constexpr int CQ = kCo / 4, PP = 256 / CQ, kPasses = (kSfTH * kSfTW) / PP;
@@ -969,8 +994,13 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
     for (int k = 0; k < kLoads; ++k) {
       const int f = tid + 256 * k;
       const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
-      const int ih = ih0 + rr, iw = iw0 + cc / 3;
-      stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * Hi + ih) * Wi + iw0) * 3 + cc] : 0.0f;
+      if constexpr (kPlanar) {                             // x is (N,3,Hi,Wi): a window row is 3 runs of 65 consecutive floats
+        const int ci = cc / kSfRowPix, ih = ih0 + rr, iw = iw0 + (cc - ci * kSfRowPix);
+        stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * 3 + ci) * Hi + ih) * Wi + iw] : 0.0f;
+      } else {
+        const int ih = ih0 + rr, iw = iw0 + cc / 3;
+        stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * Hi + ih) * Wi + iw0) * 3 + cc] : 0.0f;
+      }
     }
   };
   const int tile0 = blockIdx.x * kSfTilesPerWg;
@@ -985,7 +1015,8 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
     for (int k = 0; k < kLoads; ++k) {
       const int f = tid + 256 * k;
       const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
-      if (f < kSfRows * kSfRowFloats) patch[rr][cc] = stage[k];
+      const int pc = kPlanar ? (cc % kSfRowPix) * 3 + cc / kSfRowPix : cc;      // (pixel, channel) interleaved in LDS either way
+      if (f < kSfRows * kSfRowFloats) patch[rr][pc] = stage[k];
     }
     __syncthreads();
     if (tt + 1 < kSfTilesPerWg && tile + 1 < tiles_total) issue(tile + 1);     // the next window travels during this tile's arithmetic
@@ -1030,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, c
 // pixel's 4 dy values with one 16-byte load (the 16 threads of a pixel: 256 consecutive bytes).  The pixel slots are
 // combined through LDS in a fixed order, one partial (Co, 27) block per workgroup, k_conv_wgrad_reduce adds the
 // blocks: deterministic, no atomics, no output clearing (the library's kernel for this layer adds atomically).
-template <int kCo>
+template <int kCo, bool kPlanar>
 __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
                                                     int N, int Ho, int Wo, int tiles_total) {
   constexpr int CQ = kCo / 4, PP = 256 / CQ, kPasses = (kSfTH * kSfTW) / PP;
@@ -1053,8 +1084,13 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
     for (int k = 0; k < kLoads; ++k) {
       const int f = tid + 256 * k;
       const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
-      const int ih = ih0 + rr, iw = iw0 + cc / 3;
-      stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * Hi + ih) * Wi + iw0) * 3 + cc] : 0.0f;
+      if constexpr (kPlanar) {                             // x is (N,3,Hi,Wi): a window row is 3 runs of 65 consecutive floats
+        const int ci = cc / kSfRowPix, ih = ih0 + rr, iw = iw0 + (cc - ci * kSfRowPix);
+        stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * 3 + ci) * Hi + ih) * Wi + iw] : 0.0f;
+      } else {
+        const int ih = ih0 + rr, iw = iw0 + cc / 3;
+        stage[k] = (f < kSfRows * kSfRowFloats && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? x[(((size_t)n * Hi + ih) * Wi + iw0) * 3 + cc] : 0.0f;
+      }
     }
   };
   const int tile0 = blockIdx.x * kSfTilesPerWg;
@@ -1069,7 +1105,8 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
     for (int k = 0; k < kLoads; ++k) {
       const int f = tid + 256 * k;
       const int rr = f / kSfRowFloats, cc = f - rr * kSfRowFloats;
-      if (f < kSfRows * kSfRowFloats) patch[rr][cc] = stage[k];
+      const int pc = kPlanar ? (cc % kSfRowPix) * 3 + cc / kSfRowPix : cc;      // (pixel, channel) interleaved in LDS either way
+      if (f < kSfRows * kSfRowFloats) patch[rr][pc] = stage[k];
     }
     __syncthreads();
     if (tt + 1 < kSfTilesPerWg && tile + 1 < tiles_total) issue(tile + 1);
@@ -1130,7 +1167,7 @@ int fwd_tile_pixels(int P, int Co, int stride) {
 }
 
 int launch_fwd(const float* x, const float* w, float* y, const float* zero, int N, int H, int W, int Ci, int Co, hipStream_t st,
-               int stride = 1, float* stats = nullptr) {
+               int stride = 1, float* stats = nullptr, const float* addend = nullptr) {
   FwdArgs a;
   a.x = x; a.w = w; a.y = y; a.zero = zero;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
@@ -1139,6 +1176,7 @@ int launch_fwd(const float* x, const float* w, float* y, const float* zero, int 
   const int bm = fwd_tile_pixels(P, Co, stride) / 128;
   a.tiles_p = (P + 128 * bm - 1) / (128 * bm);
   a.stats = stats;
+  a.addend = addend;
   a.stamps = nullptr;
   const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
   if (stride == 2) k_conv3x3_fwd<1, 2><<<grid, kFwdThreads, 0, st>>>(a);
@@ -1196,7 +1234,7 @@ WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int stride = 1) {
 
 // (N, H, W): the dy grid (= the x grid for stride 1; x is 2H x 2W for stride 2)
 int launch_wgrad(const float* x, const float* dy, float* dw, void* workspace, int N, int H, int W, int Ci, int Co, int stride,
-                 hipStream_t st) {
+                 hipStream_t st, int accumulate = 0) {
   const WgradPlan p = wgrad_plan(N, H, W, Ci, Co, stride);
   WgradArgs a;
   a.x = x; a.dy = dy; a.partial = (float*)((char*)workspace + p.zero_bytes);
@@ -1215,11 +1253,30 @@ int launch_wgrad(const float* x, const float* dy, float* dw, void* workspace, in
   else T2O_WGRAD_LAUNCH(64, 64, 1);
 #undef T2O_WGRAD_LAUNCH
   const size_t n = (size_t)Co * 9 * Ci, n4 = n / 4;
-  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(a.partial, dw, n4, p.splits, n);
+  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(a.partial, dw, n4, p.splits, n, accumulate);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3 weight-gradient launch failed");
 }
 
+int launch_dgrad2(const float* dy, const float* wt, float* dx, const float* zeros, int N, int Ho, int Wo, int Ci, int Co, hipStream_t st) {
+  Dgrad2Args a;
+  a.dy = dy; a.wt = wt; a.dx = dx; a.zero = zeros;
+  a.N = N; a.Ho = Ho; a.Wo = Wo; a.Ci = Ci; a.Co = Co;
+  const int P = N * Ho * Wo;
+  a.tiles_p = (P + 127) / 128; a.tiles_n = Ci / 64;
+  const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
+  k_conv3x3s2_dgrad<<<grid, kFwdThreads, 0, st>>>(a);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3s2_dgrad launch failed");
+}
+
 }  // namespace
+
+namespace t2o {
+// fixed-order sum of split-K partial blocks (n floats each, n % 4 == 0) into dw (t2o_conv1x1.hip uses it too)
+void launch_wgrad_reduce(const float* partial, float* dw, size_t n, int splits, int accumulate, hipStream_t st) {
+  const size_t n4 = n / 4;
+  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(partial, dw, n4, splits, n, accumulate ? 1 : 0);
+}
+}  // namespace t2o
 
 extern "C" {
 
@@ -1231,12 +1288,18 @@ size_t t2o_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co) {
 
 int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream) {
+  return t2o_conv3x3_wgrad_acc_nhwc(x, dy, dw, workspace, workspace_bytes, N, H, W, Ci, Co, 1, 0, stream);
+}
+
+int t2o_conv3x3_wgrad_acc_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                               int N, int Ho, int Wo, int Ci, int Co, int stride, int accumulate, void* stream) {
   if (!x || !dy || !dw) return set_error(T2O_EINVAL, "conv3x3_wgrad: null pointer");
-  if (!wgrad_supported(N, H, W, Ci, Co))
-    return set_error(T2O_EUNSUPPORTED, "conv3x3_wgrad: channel counts must be multiples of 64 and the image width a multiple of 4");
-  if (!workspace || workspace_bytes < t2o_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co))
-    return set_error(T2O_EWORKSPACE, "conv3x3_wgrad: workspace too small");
-  return launch_wgrad(x, dy, dw, workspace, N, H, W, Ci, Co, 1, (hipStream_t)stream);
+  if (stride != 1 && stride != 2) return set_error(T2O_EUNSUPPORTED, "conv3x3_wgrad: stride 1 or 2");
+  const size_t need = stride == 1 ? t2o_conv3x3_wgrad_workspace_bytes(N, Ho, Wo, Ci, Co) : t2o_conv3x3s2_wgrad_workspace_bytes(N, Ho, Wo, Ci, Co);
+  if (need == 0)
+    return set_error(T2O_EUNSUPPORTED, "conv3x3_wgrad: channel counts must be multiples of 64 and the output-gradient width a multiple of 4");
+  if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "conv3x3_wgrad: workspace too small");
+  return launch_wgrad(x, dy, dw, workspace, N, Ho, Wo, Ci, Co, stride, (hipStream_t)stream, accumulate ? 1 : 0);
 }
 
 size_t t2o_conv3x3s2_wgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {
@@ -1253,6 +1316,14 @@ int t2o_conv3x3s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* w
     return set_error(T2O_EUNSUPPORTED, "conv3x3s2_wgrad: channel counts must be multiples of 64 and the output-gradient width a multiple of 4");
   if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "conv3x3s2_wgrad: workspace too small");
   return launch_wgrad(x, dy, dw, workspace, N, Ho, Wo, Ci, Co, 2, (hipStream_t)stream);
+}
+
+int t2o_conv_weight_transform(const float* w, float* wt, int Co, int Ci, int taps, int flip, void* stream) {
+  if (!w || !wt) return set_error(T2O_EINVAL, "conv_weight_transform: null pointer");
+  if (Co < 32 || Ci < 32 || Co % 32 != 0 || Ci % 32 != 0 || taps < 1 || taps > 9)
+    return set_error(T2O_EUNSUPPORTED, "conv_weight_transform: channel counts must be multiples of 32, 1..9 taps");
+  k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), (unsigned)taps), kConvThreads, 0, (hipStream_t)stream>>>(w, wt, Co, Ci, flip ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv_weight_transform launch failed");
 }
 
 size_t t2o_conv3x3_fwd_workspace_bytes(int N, int H, int W, int Ci, int Co) {
@@ -1295,6 +1366,10 @@ int t2o_stem_fwd_stats_rows(int N, int Ho, int Wo) {
 }
 
 int t2o_stem_fwd_nhwc(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, void* stream) {
+  return t2o_stem_fwd(x, w, y, stats, N, Ho, Wo, Co, 0, stream);
+}
+
+int t2o_stem_fwd(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, int planar, void* stream) {
   if (!x || !w || !y) return set_error(T2O_EINVAL, "stem_fwd: null pointer");
   if (N <= 0 || Ho <= 0 || Wo <= 0 || (Co != 32 && Co != 64) || (size_t)N * Ho * Wo * 4 * 3 >= ((size_t)1 << 40))
     return set_error(T2O_EUNSUPPORTED, "stem_fwd: 3 input channels, 32 or 64 output channels");
@@ -1302,8 +1377,8 @@ int t2o_stem_fwd_nhwc(const float* x, const float* w, float* y, float* stats, in
   if (tiles >= ((long long)1 << 30)) return set_error(T2O_EUNSUPPORTED, "stem_fwd: too many tiles");
   const unsigned grid = (unsigned)t2o_stem_fwd_stats_rows(N, Ho, Wo);
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 64) k_stem_fwd<64><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles);
-  else k_stem_fwd<32><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles);
+  if (Co == 64) { if (planar) k_stem_fwd<64, true><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); else k_stem_fwd<64, false><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); }
+  else { if (planar) k_stem_fwd<32, true><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); else k_stem_fwd<32, false><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); }
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_fwd launch failed");
 }
 
@@ -1314,6 +1389,11 @@ size_t t2o_stem_wgrad_workspace_bytes(int N, int Ho, int Wo, int Co) {
 
 int t2o_stem_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int Ho, int Wo,
                         int Co, void* stream) {
+  return t2o_stem_wgrad(x, dy, dw, workspace, workspace_bytes, N, Ho, Wo, Co, 0, 0, stream);
+}
+
+int t2o_stem_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int Ho, int Wo,
+                   int Co, int planar, int accumulate, void* stream) {
   if (!x || !dy || !dw) return set_error(T2O_EINVAL, "stem_wgrad: null pointer");
   if (N <= 0 || Ho <= 0 || Wo <= 0 || (Co != 32 && Co != 64)) return set_error(T2O_EUNSUPPORTED, "stem_wgrad: 3 input channels, 32 or 64 output channels");
   const long long tiles = (long long)N * ((Ho + kSfTH - 1) / kSfTH) * ((Wo + kSfTW - 1) / kSfTW);
@@ -1323,10 +1403,10 @@ int t2o_stem_wgrad_nhwc(const float* x, const float* dy, float* dw, void* worksp
   const int rows = t2o_stem_fwd_stats_rows(N, Ho, Wo);
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
-  if (Co == 64) k_stem_wgrad<64><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles);
-  else k_stem_wgrad<32><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles);
+  if (Co == 64) { if (planar) k_stem_wgrad<64, true><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles); else k_stem_wgrad<64, false><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles); }
+  else { if (planar) k_stem_wgrad<32, true><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles); else k_stem_wgrad<32, false><<<(unsigned)rows, 256, 0, st>>>(x, dy, partial, N, Ho, Wo, (int)tiles); }
   const size_t n = (size_t)Co * 27, n4 = n / 4;
-  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(partial, dw, n4, rows, n);
+  k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(partial, dw, n4, rows, n, accumulate ? 1 : 0);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_wgrad launch failed");
 }
 
@@ -1366,6 +1446,17 @@ int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* wor
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_dgrad launch failed");
 }
 
+int t2o_conv3x3_dgrad_pre_nhwc(const float* dy, const float* wt, const float* addend, float* dx, void* workspace, size_t workspace_bytes,
+                               int N, int H, int W, int Ci, int Co, void* stream) {
+  if (!dy || !wt || !dx) return set_error(T2O_EINVAL, "conv3x3_dgrad_pre: null pointer");
+  if (!fwd_supported(N, H, W, Co, Ci) || Co % 32 != 0 || Ci % 32 != 0)
+    return set_error(T2O_EUNSUPPORTED, "conv3x3_dgrad_pre: Co must be a multiple of 32, Ci of 64, the image width of 8");
+  if (!workspace || workspace_bytes < fwd_zero_bytes(Co)) return set_error(T2O_EWORKSPACE, "conv3x3_dgrad_pre: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = launch_fwd(dy, wt, dx, zero_region(workspace, fwd_zero_bytes(Co), st), N, H, W, Co, Ci, st, 1, nullptr, addend);
+  return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_dgrad_pre launch failed");
+}
+
 bool stem_dgrad_supported(int N, int Ho, int Wo, int Ci, int Co) {
   return N > 0 && Ho > 0 && Wo > 0 && Ci == 3 && (Co == 64 || Co == 32) && (size_t)N * Ho * Wo * 4 < ((size_t)1 << 31);
 }
@@ -1380,8 +1471,8 @@ int t2o_conv3x3s2_dgrad_nhwc(const float* dy, const float* w, float* dx, void* w
   if (!dy || !w || !dx) return set_error(T2O_EINVAL, "conv3x3s2_dgrad: null pointer");
   if (stem_dgrad_supported(N, Ho, Wo, Ci, Co)) {                     // the 3-channel stem: streaming kernel, no workspace
     const unsigned grid = (unsigned)(N * ((Ho + kStemTH - 1) / kStemTH) * ((Wo + kStemTW - 1) / kStemTW));
-    if (Co == 64) k_stem_dgrad<64><<<grid, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, Ho, Wo);
-    else k_stem_dgrad<32><<<grid, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, Ho, Wo);
+    if (Co == 64) k_stem_dgrad<64, false><<<grid, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, Ho, Wo, 0);
+    else k_stem_dgrad<32, false><<<grid, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, Ho, Wo, 0);
     return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3s2_dgrad (stem) launch failed");
   }
   if (!fwd_supported(N, Ho, Wo, Co, Ci) || (size_t)N * Ho * Wo * 4 + 1024 >= ((size_t)1 << 31))
@@ -1393,14 +1484,28 @@ int t2o_conv3x3s2_dgrad_nhwc(const float* dy, const float* w, float* dx, void* w
   const float* zeros = zero_region(workspace, zb, st);
   float* wt = (float*)((char*)workspace + zb);
   k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci, 0);
-  Dgrad2Args a;
-  a.dy = dy; a.wt = wt; a.dx = dx; a.zero = zeros;
-  a.N = N; a.Ho = Ho; a.Wo = Wo; a.Ci = Ci; a.Co = Co;
-  const int P = N * Ho * Wo;
-  a.tiles_p = (P + 127) / 128; a.tiles_n = Ci / 64;
-  const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
-  k_conv3x3s2_dgrad<<<grid, kFwdThreads, 0, st>>>(a);
-  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3s2_dgrad launch failed");
+  return launch_dgrad2(dy, wt, dx, zeros, N, Ho, Wo, Ci, Co, st);
+}
+
+int t2o_conv3x3s2_dgrad_pre_nhwc(const float* dy, const float* wt, float* dx, void* workspace, size_t workspace_bytes,
+                                 int N, int Ho, int Wo, int Ci, int Co, void* stream) {
+  if (!dy || !wt || !dx) return set_error(T2O_EINVAL, "conv3x3s2_dgrad_pre: null pointer");
+  if (!fwd_supported(N, Ho, Wo, Co, Ci) || (size_t)N * Ho * Wo * 4 + 1024 >= ((size_t)1 << 31))
+    return set_error(T2O_EUNSUPPORTED, "conv3x3s2_dgrad_pre: Co must be a multiple of 32, Ci of 64 and the output-gradient width of 8");
+  if (!workspace || workspace_bytes < fwd_zero_bytes(Co)) return set_error(T2O_EWORKSPACE, "conv3x3s2_dgrad_pre: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  return launch_dgrad2(dy, wt, dx, zero_region(workspace, fwd_zero_bytes(Co), st), N, Ho, Wo, Ci, Co, st);
+}
+
+int t2o_stem_dgrad(const float* dy, const float* w, float* dx, int N, int Ho, int Wo, int Co, int planar, int accumulate, void* stream) {
+  if (!dy || !w || !dx) return set_error(T2O_EINVAL, "stem_dgrad: null pointer");
+  if (!stem_dgrad_supported(N, Ho, Wo, 3, Co)) return set_error(T2O_EUNSUPPORTED, "stem_dgrad: 3 input channels, 32 or 64 output channels");
+  const unsigned grid = (unsigned)(N * ((Ho + kStemTH - 1) / kStemTH) * ((Wo + kStemTW - 1) / kStemTW));
+  hipStream_t st = (hipStream_t)stream;
+  const int acc = accumulate ? 1 : 0;
+  if (Co == 64) { if (planar) k_stem_dgrad<64, true><<<grid, 256, 0, st>>>(dy, w, dx, N, Ho, Wo, acc); else k_stem_dgrad<64, false><<<grid, 256, 0, st>>>(dy, w, dx, N, Ho, Wo, acc); }
+  else { if (planar) k_stem_dgrad<32, true><<<grid, 256, 0, st>>>(dy, w, dx, N, Ho, Wo, acc); else k_stem_dgrad<32, false><<<grid, 256, 0, st>>>(dy, w, dx, N, Ho, Wo, acc); }
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_dgrad launch failed");
 }
 
 int t2o_conv_set_zero_region(int device, const void* zeros, size_t bytes) {

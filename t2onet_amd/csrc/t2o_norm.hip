@@ -42,6 +42,7 @@ struct BnArgs {
   int N, C, HW, splits;
   float eps, momentum;
   int relu;              // NHWC kernels: 0 = plain batch norm (the shortcut branch, no activation); the NCHW kernels always apply it
+  int acc;               // backward: dweight / dbias are ADDED to (a trainer's persistent, pre-zeroed gradient buffers)
 };
 
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_sums(BnArgs a) {
 // per-channel epilogue of the backward sums: dgamma, dbeta and the coefficients of the apply pass
 __device__ __forceinline__ void bn_bwd_finalize_channel(const BnArgs& a, int c, double sg, double sgx) {
   const double m = (double)a.N * a.HW;
-  if (a.dbias) a.dbias[c] = (float)sg;
-  if (a.dweight) a.dweight[c] = (float)sgx;
+  if (a.dbias) a.dbias[c] = a.acc ? a.dbias[c] + (float)sg : (float)sg;
+  if (a.dweight) a.dweight[c] = a.acc ? a.dweight[c] + (float)sgx : (float)sgx;
   a.coef[c] = a.weight[c] * a.save_invstd[c];     // a_c
   a.coef[a.C + c] = (float)(sg / m);             // mean of g
   a.coef[2 * a.C + c] = (float)(sgx / m);        // mean of g * xhat
@@ -615,10 +616,10 @@ int t2o_bn_relu_nhwc_fwd_partials(const float* x, const float* res, const float*
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
-int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
-                         const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
-                         float* dbias, int has_res, int relu, void* workspace, size_t workspace_bytes, int M, int C,
-                         void* stream) {
+int t2o_bn_relu_nhwc_bwd_acc(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
+                             const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
+                             float* dbias, int has_res, int relu, int accumulate, void* workspace, size_t workspace_bytes,
+                             int M, int C, void* stream) {
   if (!x || M <= 0 || !nhwc_channels_ok(C) || !dy || !weight || !bias || !save_mean || !save_invstd || !dx)
     return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd: null pointer or bad shape (C must be a power of two in [4, 1024])");
   if (has_res && relu && !y) return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd: y is needed when a residual was added");
@@ -627,7 +628,7 @@ int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const 
   a.x = x; a.y = y; a.dy = dy; a.out = dx; a.dres = dres; a.weight = weight; a.bias = bias;
   a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
   a.dweight = dweight; a.dbias = dbias;
-  a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.relu = relu;
+  a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.relu = relu; a.acc = accumulate ? 1 : 0;
   a.partials = (double*)workspace;
   a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
   float* partial = a.coef + 4 * (size_t)C;
@@ -640,6 +641,14 @@ int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const 
   const unsigned grid = flat_grid(total4, 1, 2);
   if (has_res) k_bn_nhwc_bwd_apply<true><<<grid, kThreads, 0, st>>>(a, total4); else k_bn_nhwc_bwd_apply<false><<<grid, kThreads, 0, st>>>(a, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
+}
+
+int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
+                         const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
+                         float* dbias, int has_res, int relu, void* workspace, size_t workspace_bytes, int M, int C,
+                         void* stream) {
+  return t2o_bn_relu_nhwc_bwd_acc(x, y, dy, weight, bias, save_mean, save_invstd, dx, dres, dweight, dbias, has_res, relu, 0,
+                                  workspace, workspace_bytes, M, C, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,265 @@
+"""The image encoder's convolutional trunk (models/actor_resnet.py:98-105: stem + 4 stages of 2 BasicBlocks) as ONE
+autograd node with an explicit forward / backward schedule over the C ABI -- what the per-layer autograd functions of
+`functional.py` did, without the passes autograd had to insert between them:
+
+  * a block input that feeds both the first convolution and the shortcut gets ONE gradient: the data gradient of the
+    first convolution takes the identity shortcut's gradient as an addend in its epilogue
+    (t2o_conv3x3_dgrad_pre_nhwc), the 1x1 shortcut's data gradient is added into it in place
+    (t2o_conv1x1s2_dgrad_acc_nhwc) -- 8 full-tensor `add` launches per pass (up to 805 MB each) are gone;
+  * the 1x1 stride-2 shortcut convolutions run on this library's kernels (t2o_conv1x1.hip), all three directions:
+    the trunk contains no library convolution, no atomic (non-deterministic) gradient and no memset;
+  * the image is read and its gradient written in the image's own NCHW layout (t2o_stem_*: planar), the stem's data
+    gradient ADDS into the image gradient the caller already holds (operator backward), no channels-last copies;
+  * with persistent gradient buffers (`into_grad`: every parameter has a dense .grad -- the Trainer's flat buffer) all
+    weight / batch-norm gradients are accumulated by the kernels that produce them; autograd sees no parameter
+    gradient of the trunk (62 tensors x 5 encoder calls of accumulation launches per step);
+  * transformed weights (tap-mirrored transposes for the data gradients) are made once per optimiser step
+    (`TrunkPlan.weights_changed()` invalidates them), not once per data-gradient call.
+
+Arithmetic is that of the per-layer path (same kernels, same order inside every sum); tests/test_gpu_encoder.py holds
+both against fp64 autograd of the oracle's ResNet.
+"""
+import torch
+
+from . import _lib
+from .functional import _need_gpu, _ptr, _stream, _conv_workspace
+
+
+def _nhwc(N, H, W, C, dev):
+    return torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
+
+
+class TrunkPlan:
+    """Static description of a ResNet trunk for _TrunkFn: layer list, parameter order, transformed-weight cache."""
+
+    def __init__(self, resnet):
+        self.net = resnet
+        blocks = [b for layer in (resnet.layer1, resnet.layer2, resnet.layer3, resnet.layer4) for b in layer]
+        self.blocks = blocks
+        self.params = [resnet.conv1.weight, resnet.bn1.weight, resnet.bn1.bias]
+        self.index = {}                                        # id(parameter) -> position in self.params
+        for b in blocks:
+            self.params += [b.conv1.weight, b.bn1.weight, b.bn1.bias, b.conv2.weight, b.bn2.weight, b.bn2.bias]
+            if len(b.shortcut):
+                self.params += [b.shortcut[0].weight, b.shortcut[1].weight, b.shortcut[1].bias]
+        for i, p in enumerate(self.params):
+            self.index[id(p)] = i
+        self.bns = [resnet.bn1] + [m for b in blocks for m in ([b.bn1, b.bn2] + ([b.shortcut[1]] if len(b.shortcut) else []))]
+        self.persistent_wt = False                             # Trainer: transformed weights live until weights_changed()
+        self._wt = None
+
+    def weights_changed(self):
+        self._wt = None
+
+    def supported(self, img):
+        """fp32 GPU image (N,3,H,W) whose every stage the matrix-core kernels take: after the stem and four stride-2
+        stages the last feature map must still be a multiple of 8 pixels wide (W % 256 == 0), H a multiple of 32."""
+        net = self.net
+        if not (img.is_cuda and img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3):
+            return False
+        if img.shape[2] % 32 or img.shape[3] % 256 or net.conv1.weight.shape[0] != 64:
+            return False
+        if not (img.is_contiguous() or img.is_contiguous(memory_format=torch.channels_last)):
+            return False
+        for p in self.params:
+            if p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last):
+                return False
+        return all(bn.momentum is not None and bn.affine and bn.track_running_stats for bn in self.bns)
+
+    def transformed(self, lib, st):
+        """{id(conv): wt}: 3x3 stride-1 -> tap-mirrored transpose, 3x3 stride-2 -> plain transpose per tap, 1x1 -> transpose."""
+        if self._wt is not None:
+            return self._wt
+        wt = {}
+        for b in self.blocks:
+            convs = [(b.conv1, 9, 1 if b.conv1.stride[0] == 1 else 0), (b.conv2, 9, 1)]
+            if len(b.shortcut):
+                convs.append((b.shortcut[0], 1, 0))
+            for conv, taps, flip in convs:
+                w = conv.weight
+                Co, Ci = w.shape[0], w.shape[1]
+                t = torch.empty(Ci * taps * Co, dtype=torch.float32, device=w.device)
+                _lib.check(lib.t2o_conv_weight_transform(_ptr(w), _ptr(t), Co, Ci, taps, flip, st), 't2o_conv_weight_transform')
+                wt[id(conv)] = t
+        if self.persistent_wt:
+            self._wt = wt
+        return wt
+
+
+def _bn_fwd(lib, st, ws, bn, x, out, res, relu, partial, M, C):
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    if partial is not None:
+        rc = lib.t2o_bn_relu_nhwc_fwd_partials(_ptr(x), _ptr(res), _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
+                                               _ptr(bn.running_var), _ptr(mean), _ptr(invstd), _ptr(out), float(bn.momentum),
+                                               float(bn.eps), relu, _ptr(partial), partial.shape[0], _ptr(ws), ws.numel(), M, C, st)
+    else:
+        rc = lib.t2o_bn_relu_nhwc_fwd(_ptr(x), _ptr(res), _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
+                                      _ptr(bn.running_var), _ptr(mean), _ptr(invstd), _ptr(out), float(bn.momentum),
+                                      float(bn.eps), relu, _ptr(ws), ws.numel(), M, C, st)
+    _lib.check(rc, 't2o_bn_relu_nhwc_fwd')
+    return mean, invstd
+
+
+class _TrunkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, img, *params):
+        net = plan.net
+        _need_gpu(img, *params)
+        lib = _lib.load()
+        dev = img.device
+        st = _stream(dev)
+        planar = 1 if img.is_contiguous() else 0
+        N, _, H, W = img.shape
+        bn_ws = torch.empty(lib.t2o_bn_nhwc_workspace_bytes(1, 512), dtype=torch.uint8, device=dev)
+        conv_ws = _conv_workspace(dev, 64 << 10)               # zero region only (registered once per device: not cleared per call)
+        saved = []                                             # per layer: what the backward needs
+
+        def conv3(x, conv, Nn, Hi, Wi, want_stats):
+            """3x3, padding 1, stride 1 / 2 on (Nn,Hi,Wi,Ci) -> (y (Nn,Ho,Wo,Co), stats)."""
+            w = conv.weight
+            Co, Ci = w.shape[0], w.shape[1]
+            s = conv.stride[0]
+            Ho, Wo = Hi // s, Wi // s
+            y = _nhwc(Nn, Ho, Wo, Co, dev)
+            stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(Nn, Ho, Wo, Co, s), 2, Co), dtype=torch.float32, device=dev)
+            rc = lib.t2o_conv3x3_fwd_stats_nhwc(_ptr(x), _ptr(w), _ptr(y), _ptr(stats), _ptr(conv_ws), conv_ws.numel(), Nn, Ho, Wo,
+                                                Ci, Co, s, st)
+            _lib.check(rc, 't2o_conv3x3_fwd_stats_nhwc')
+            return y, stats
+
+        # ---- stem: conv 3 -> 64 stride 2 + bn + relu
+        Ho, Wo = H // 2, W // 2
+        C0 = net.conv1.weight.shape[0]
+        y0 = _nhwc(N, Ho, Wo, C0, dev)
+        st0 = torch.empty((lib.t2o_stem_fwd_stats_rows(N, Ho, Wo), 2, C0), dtype=torch.float32, device=dev)
+        _lib.check(lib.t2o_stem_fwd(_ptr(img), _ptr(net.conv1.weight), _ptr(y0), _ptr(st0), N, Ho, Wo, C0, planar, st), 't2o_stem_fwd')
+        a0 = torch.empty_like(y0)
+        m0, i0 = _bn_fwd(lib, st, bn_ws, net.bn1, y0, a0, None, 1, st0, N * Ho * Wo, C0)
+        stem = (y0, m0, i0)
+        x, Hc, Wc = a0, Ho, Wo
+        for b in plan.blocks:
+            s = b.conv1.stride[0]
+            Co = b.conv1.weight.shape[0]
+            Hn, Wn = Hc // s, Wc // s
+            M = N * Hn * Wn
+            y1, s1 = conv3(x, b.conv1, N, Hc, Wc, True)
+            a1 = torch.empty_like(y1)
+            m1, i1 = _bn_fwd(lib, st, bn_ws, b.bn1, y1, a1, None, 1, s1, M, Co)
+            rec = {'x': x, 'y1': y1, 'm1': m1, 'i1': i1, 'a1': a1, 'H': Hc, 'W': Wc}
+            if len(b.shortcut):
+                sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
+                ys = _nhwc(N, Hn, Wn, Co, dev)
+                rc = lib.t2o_conv1x1s2_fwd_nhwc(_ptr(x), _ptr(sc_conv.weight), _ptr(ys), N, Hc, Wc, sc_conv.weight.shape[1], Co, st)
+                _lib.check(rc, 't2o_conv1x1s2_fwd_nhwc')
+                sc = torch.empty_like(ys)
+                ms, is_ = _bn_fwd(lib, st, bn_ws, sc_bn, ys, sc, None, 0, None, M, Co)
+                rec.update(ys=ys, ms=ms, is_=is_)
+            else:
+                sc = x
+            y2, s2 = conv3(a1, b.conv2, N, Hn, Wn, True)
+            out = torch.empty_like(y2)
+            m2, i2 = _bn_fwd(lib, st, bn_ws, b.bn2, y2, out, sc, 1, s2, M, Co)
+            rec.update(y2=y2, m2=m2, i2=i2, out=out)
+            saved.append(rec)
+            x, Hc, Wc = out, Hn, Wn
+        ctx.plan, ctx.img, ctx.stem, ctx.saved, ctx.planar = plan, img, stem, saved, planar
+        ctx.a0 = a0
+        # persistent, dense gradient buffers for every parameter: the kernels accumulate into them
+        ctx.into_grad = all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape
+                            and p.grad.stride() == p.stride() for p in plan.params)
+        ctx.grads = [p.grad for p in plan.params] if ctx.into_grad else None
+        return x.permute(0, 3, 1, 2)                          # (N,C,h,w) view of the NHWC buffer = channels_last
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan, net = ctx.plan, ctx.plan.net
+        lib = _lib.load()
+        dev = dout.device
+        st = _stream(dev)
+        acc = 1 if ctx.into_grad else 0
+        N = ctx.img.shape[0]
+        grads = ctx.grads if acc else [torch.empty_like(p) for p in plan.params]
+
+        def g(p):
+            return grads[plan.index[id(p)]]
+
+        bn_ws = torch.empty(lib.t2o_bn_nhwc_workspace_bytes(1, 512), dtype=torch.uint8, device=dev)
+        conv_ws = _conv_workspace(dev, 64 << 10)
+        wt = plan.transformed(lib, st)
+
+        def bn_bwd(bn, x, y, dy, mean, invstd, has_res, relu, want_dres, M, C):
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if want_dres else None
+            rc = lib.t2o_bn_relu_nhwc_bwd_acc(_ptr(x), _ptr(y), _ptr(dy), _ptr(bn.weight), _ptr(bn.bias), _ptr(mean), _ptr(invstd),
+                                              _ptr(dx), _ptr(dres), _ptr(g(bn.weight)), _ptr(g(bn.bias)), has_res, relu, acc,
+                                              _ptr(bn_ws), bn_ws.numel(), M, C, st)
+            _lib.check(rc, 't2o_bn_relu_nhwc_bwd_acc')
+            return dx, dres
+
+        def wgrad3(conv, x, dy, Hn, Wn):
+            w = conv.weight
+            Co, Ci = w.shape[0], w.shape[1]
+            s = conv.stride[0]
+            need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            rc = lib.t2o_conv3x3_wgrad_acc_nhwc(_ptr(x), _ptr(dy), _ptr(g(w)), _ptr(ws), need, N, Hn, Wn, Ci, Co, s, acc, st)
+            _lib.check(rc, 't2o_conv3x3_wgrad_acc_nhwc')
+
+        d = dout.permute(0, 2, 3, 1).contiguous()              # NHWC (a no-op for a channels_last gradient)
+        for b, rec in zip(reversed(plan.blocks), reversed(ctx.saved)):
+            s = b.conv1.stride[0]
+            Co, Ci = b.conv1.weight.shape[0], b.conv1.weight.shape[1]
+            Hc, Wc = rec['H'], rec['W']
+            Hn, Wn = Hc // s, Wc // s
+            M = N * Hn * Wn
+            # out = relu(bn2(y2) + sc)
+            dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co)
+            da1 = torch.empty_like(rec['a1'])
+            rc = lib.t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy2), _ptr(wt[id(b.conv2)]), None, _ptr(da1), _ptr(conv_ws), conv_ws.numel(),
+                                                N, Hn, Wn, Co, Co, st)
+            _lib.check(rc, 't2o_conv3x3_dgrad_pre_nhwc')
+            wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn)
+            del dy2
+            # a1 = relu(bn1(y1))
+            dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co)
+            del da1
+            wgrad3(b.conv1, rec['x'], dy1, Hn, Wn)
+            dx = torch.empty_like(rec['x'])
+            if len(b.shortcut):
+                sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
+                dys, _ = bn_bwd(sc_bn, rec['ys'], None, dsc, rec['ms'], rec['is_'], 0, 0, False, M, Co)
+                need = lib.t2o_conv1x1s2_wgrad_workspace_bytes(N, Hc, Wc, Ci, Co)
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(rec['x']), _ptr(dys), _ptr(g(sc_conv.weight)), _ptr(ws), need, N, Hc, Wc, Ci, Co,
+                                                  acc, st)
+                _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
+                rc = lib.t2o_conv3x3s2_dgrad_pre_nhwc(_ptr(dy1), _ptr(wt[id(b.conv1)]), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
+                                                      N, Hn, Wn, Ci, Co, st)
+                _lib.check(rc, 't2o_conv3x3s2_dgrad_pre_nhwc')
+                rc = lib.t2o_conv1x1s2_dgrad_acc_nhwc(_ptr(dys), _ptr(wt[id(sc_conv)]), _ptr(dx), N, Hc, Wc, Ci, Co, st)
+                _lib.check(rc, 't2o_conv1x1s2_dgrad_acc_nhwc')
+            else:
+                rc = lib.t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy1), _ptr(wt[id(b.conv1)]), _ptr(dsc), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
+                                                    N, Hc, Wc, Ci, Co, st)
+                _lib.check(rc, 't2o_conv3x3_dgrad_pre_nhwc')
+            d = dx
+        # ---- stem
+        y0, m0, i0 = ctx.stem
+        _, Ho, Wo, C0 = y0.shape
+        dy0, _ = bn_bwd(net.bn1, y0, None, d, m0, i0, 0, 1, False, N * Ho * Wo, C0)
+        need = lib.t2o_stem_wgrad_workspace_bytes(N, Ho, Wo, C0)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        rc = lib.t2o_stem_wgrad(_ptr(ctx.img), _ptr(dy0), _ptr(g(net.conv1.weight)), _ptr(ws), need, N, Ho, Wo, C0, ctx.planar, acc, st)
+        _lib.check(rc, 't2o_stem_wgrad')
+        dimg = None
+        if ctx.needs_input_grad[1]:
+            dimg = torch.empty_like(ctx.img)                   # same layout as the image (planar NCHW or channels-last)
+            rc = lib.t2o_stem_dgrad(_ptr(dy0), _ptr(net.conv1.weight), _ptr(dimg), N, Ho, Wo, C0, ctx.planar, 0, st)
+            _lib.check(rc, 't2o_stem_dgrad')
+        return (None, dimg) + (tuple(None for _ in plan.params) if acc else tuple(grads))
+
+
+def trunk_forward(plan, img):
+    """relu(bn(conv...)) trunk output (N,512,H/32,W/32), channels_last, for a supported training-mode call."""
+    return _TrunkFn.apply(plan, img, *plan.params)

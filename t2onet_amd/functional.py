@@ -843,3 +843,105 @@ def candidates_l1(op, img, target, params):
                                   _ptr(ws), ws.numel(), H, W, _stream(img.device))
     _lib.check(rc, 't2o_op_candidates_l1')
     return loss
+
+
+# ---- round 3: entry points of the encoder's explicit schedule (encoder.py), exposed for tests and tools ----------------
+def conv_weight_transform(weight, taps, flip):
+    """wt (Ci, taps, Co) from a channels-last (Co, Ci, kh, kw) weight (t2o_conv_weight_transform)."""
+    _need_gpu(weight)
+    Co, Ci = weight.shape[0], weight.shape[1]
+    w = weight.contiguous(memory_format=torch.channels_last)
+    wt = torch.empty(Ci * taps * Co, dtype=torch.float32, device=weight.device)
+    _lib.check(_lib.load().t2o_conv_weight_transform(_ptr(w), _ptr(wt), Co, Ci, taps, 1 if flip else 0, _stream(weight.device)),
+               't2o_conv_weight_transform')
+    return wt
+
+
+def conv3x3_dgrad_pre(dy, wt, Ci, addend=None):
+    """t2o_conv3x3_dgrad_pre_nhwc: dy (N,Co,H,W) channels-last, wt = conv_weight_transform(w, 9, True); addend (N,Ci,H,W)
+    channels-last or None is added in the epilogue.  Returns dx (N,Ci,H,W) channels-last."""
+    _need_gpu(dy, wt, addend)
+    N, Co, H, W = dy.shape
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    addend = None if addend is None else addend.contiguous(memory_format=torch.channels_last)
+    ws = _conv_workspace(dy.device, 64 << 10)
+    dx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    rc = _lib.load().t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy), _ptr(wt), _ptr(addend), _ptr(dx), _ptr(ws), ws.numel(), N, H, W, Ci, Co,
+                                                _stream(dy.device))
+    _lib.check(rc, 't2o_conv3x3_dgrad_pre_nhwc')
+    return dx
+
+
+def conv1x1s2_forward(x, weight):
+    """conv2d(x, weight, None, stride 2) for a 1x1 weight (Co,Ci,1,1): x (N,Ci,H,W) channels-last -> y (N,Co,(H+1)//2,(W+1)//2)."""
+    _need_gpu(x, weight)
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    x = x.contiguous(memory_format=torch.channels_last)
+    w = weight.reshape(Co, Ci).contiguous()
+    y = torch.empty((N, Co, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.load().t2o_conv1x1s2_fwd_nhwc(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, _stream(x.device)), 't2o_conv1x1s2_fwd_nhwc')
+    return y
+
+
+def conv1x1s2_dgrad_acc(dy, weight, dx):
+    """dx[:, :, ::2, ::2] += data gradient of the 1x1 stride-2 convolution, in place (dx (N,Ci,H,W) channels-last)."""
+    _need_gpu(dy, weight, dx)
+    N, Ci, H, W = dx.shape
+    Co = weight.shape[0]
+    if not dx.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError('conv1x1s2_dgrad_acc: dx must be channels-last (it is updated in place)')
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    wt = conv_weight_transform(weight.reshape(Co, Ci, 1, 1), 1, False)
+    _lib.check(_lib.load().t2o_conv1x1s2_dgrad_acc_nhwc(_ptr(dy), _ptr(wt), _ptr(dx), N, H, W, Ci, Co, _stream(dx.device)),
+               't2o_conv1x1s2_dgrad_acc_nhwc')
+    return dx
+
+
+def conv1x1s2_wgrad(x, dy, into=None):
+    """Weight gradient (Co,Ci,1,1) of the 1x1 stride-2 convolution; into: an existing gradient tensor that is added to."""
+    _need_gpu(x, dy, into)
+    N, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    x = x.contiguous(memory_format=torch.channels_last)
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv1x1s2_wgrad_workspace_bytes(N, H, W, Ci, Co)
+    if need == 0:
+        raise RuntimeError('conv1x1s2_wgrad: unsupported shape (channel counts must be multiples of 64)')
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    dw = into if into is not None else torch.empty((Co, Ci, 1, 1), dtype=torch.float32, device=x.device)
+    rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), need, N, H, W, Ci, Co, 1 if into is not None else 0,
+                                      _stream(x.device))
+    _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
+    return dw
+
+
+def stem_planar(x, weight, dy=None, want='fwd', into=None):
+    """The stem kernels on an NCHW image (t2o_stem_fwd / _wgrad / _dgrad with planar = 1).  want = 'fwd': (y, stats);
+    'wgrad': dw (Co,3,3,3) channels-last (into: added to); 'dgrad': dx (N,3,2Ho,2Wo) NCHW (into: added to)."""
+    lib = _lib.load()
+    Co = weight.shape[0]
+    w = weight.contiguous(memory_format=torch.channels_last)
+    if want == 'dgrad':
+        N, _, Ho, Wo = dy.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = into if into is not None else torch.empty((N, 3, 2 * Ho, 2 * Wo), dtype=torch.float32, device=dy.device)
+        _lib.check(lib.t2o_stem_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, Ho, Wo, Co, 1, 1 if into is not None else 0, _stream(dy.device)),
+                   't2o_stem_dgrad')
+        return dx
+    x = x.contiguous()
+    N, _, Hi, Wi = x.shape
+    Ho, Wo = Hi // 2, Wi // 2
+    if want == 'fwd':
+        y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        stats = torch.empty((lib.t2o_stem_fwd_stats_rows(N, Ho, Wo), 2, Co), dtype=torch.float32, device=x.device)
+        _lib.check(lib.t2o_stem_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(stats), N, Ho, Wo, Co, 1, _stream(x.device)), 't2o_stem_fwd')
+        return y, stats
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    need = lib.t2o_stem_wgrad_workspace_bytes(N, Ho, Wo, Co)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    dw = into if into is not None else torch.empty((Co, 3, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(lib.t2o_stem_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), need, N, Ho, Wo, Co, 1, 1 if into is not None else 0,
+                                  _stream(x.device)), 't2o_stem_wgrad')
+    return dw

@@ -1,0 +1,188 @@
+"""The encoder's one-node trunk (t2onet_amd/encoder.py) and the kernels only it uses: 1x1 stride-2 shortcut
+convolutions (t2o_conv1x1.hip), the planar stem forms, the data gradient with pre-transformed weights and an addend
+-- against fp64 conv2d / the fp64 PyTorch ResNet (models/actor_resnet.py:21-44, :98-107) and against the per-layer
+autograd path (functional.py)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def _close(got, ref, tol=1e-5):
+    ref = ref.float().cpu()
+    scale = float(ref.abs().max()) or 1.0
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol * scale)
+
+
+# (N, Ci, Co, H, W): ragged pixel counts (tile tails), odd sizes, one row, every channel combination of the encoder
+SC_SHAPES = [(2, 64, 64, 8, 8), (3, 64, 128, 6, 10), (1, 128, 256, 7, 9), (2, 256, 512, 4, 4), (5, 64, 64, 1, 16),
+             (2, 128, 64, 33, 18), (1, 64, 64, 64, 66)]
+
+
+@pytest.mark.parametrize('shape', SC_SHAPES)
+def test_shortcut_conv_forward_dgrad_wgrad_vs_fp64(shape):
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    x = synth.uniform((N, Ci, H, W), 801, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 1, 1), 802, -1.0, 1.0)
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 2)
+    dy = synth.uniform(tuple(y64.shape), 803, -1.0, 1.0)
+    y64.backward(dy.double())
+    y = T.conv1x1s2_forward(_cl(x), w.to(DEV))
+    assert y.shape == y64.shape and y.is_contiguous(memory_format=torch.channels_last)
+    _close(y, y64.detach())
+    # data gradient: added into an existing tensor, only at the even positions
+    base = synth.uniform((N, Ci, H, W), 804, -1.0, 1.0)
+    dx = _cl(base).clone(memory_format=torch.channels_last)
+    T.conv1x1s2_dgrad_acc(_cl(dy), w.to(DEV), dx)
+    _close(dx, base.double() + x64.grad)
+    # weight gradient: fresh, then accumulated; deterministic
+    dw = T.conv1x1s2_wgrad(_cl(x), _cl(dy))
+    _close(dw, w64.grad)
+    assert torch.equal(dw, T.conv1x1s2_wgrad(_cl(x), _cl(dy)))
+    acc = dw.clone()
+    T.conv1x1s2_wgrad(_cl(x), _cl(dy), into=acc)
+    _close(acc, 2 * w64.grad)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 8, 8), (3, 32, 6, 40), (1, 64, 34, 66)])
+def test_stem_planar_matches_channels_last_forms(shape):
+    """NCHW image in / NCHW image gradient out: the same numbers as the channels-last kernels, accumulate forms add."""
+    import t2onet_amd.functional as T
+    N, Co, Ho, Wo = shape
+    x = synth.uniform((N, 3, 2 * Ho, 2 * Wo), 811, 0.0, 1.0).to(DEV)
+    w = _cl(synth.uniform((Co, 3, 3, 3), 812, -1.0, 1.0))
+    dy = _cl(synth.uniform((N, Co, Ho, Wo), 813, -1.0, 1.0))
+    y_ref, st_ref = T.stem_forward(x.contiguous(memory_format=torch.channels_last), w, True)
+    y, st = T.stem_planar(x, w)
+    assert torch.equal(y, y_ref) and torch.equal(st, st_ref)
+    ref64 = F.conv2d(x.double().cpu(), w.double().cpu(), None, 2, 1)
+    _close(y, ref64)
+    dw_ref = T.stem_wgrad(x.contiguous(memory_format=torch.channels_last), dy)
+    dw = T.stem_planar(x, w, dy, 'wgrad')
+    assert torch.equal(dw, dw_ref)
+    acc = dw.clone(memory_format=torch.channels_last)
+    T.stem_planar(x, w, dy, 'wgrad', into=acc)
+    _close(acc, 2 * dw_ref.double())
+    dx_ref = T.conv3x3s2_dgrad(dy, w)                       # (N,3,2Ho,2Wo) channels-last
+    dx = T.stem_planar(None, w, dy, 'dgrad')
+    assert dx.is_contiguous() and torch.equal(dx, dx_ref.contiguous())
+    base = synth.uniform(tuple(dx.shape), 814, -1.0, 1.0).to(DEV)
+    acc = base.clone()
+    T.stem_planar(None, w, dy, 'dgrad', into=acc)
+    _close(acc, base.double() + dx_ref.double())
+
+
+def test_dgrad_with_transformed_weight_and_addend():
+    import t2onet_amd.functional as T
+    N, Co, Ci, H, W = 2, 128, 64, 9, 16
+    dy = _cl(synth.uniform((N, Co, H, W), 821, -1.0, 1.0))
+    w = _cl(synth.uniform((Co, Ci, 3, 3), 822, -1.0, 1.0))
+    add = _cl(synth.uniform((N, Ci, H, W), 823, -1.0, 1.0))
+    ref = T.conv3x3_dgrad(dy, w)
+    wt = T.conv_weight_transform(w, 9, True)
+    assert torch.equal(T.conv3x3_dgrad_pre(dy, wt, Ci), ref)
+    assert torch.equal(T.conv3x3_dgrad_pre(dy, wt, Ci, add), ref + add)
+
+
+def _encoder(seed=5):
+    from t2onet_amd.actor_resnet import ResNet
+    torch.manual_seed(seed)
+    net = ResNet(3, 18, 512)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    return net
+
+
+def _run(net, img, gout):
+    img = img.clone().requires_grad_(True)
+    out = net(img)
+    out.backward(gout)
+    grads = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    return out.detach(), img.grad.detach(), grads
+
+
+def test_trunk_matches_per_layer_path_and_fp64(monkeypatch):
+    """One-node trunk vs the per-layer autograd path (same 3x3 kernels: tight) and vs the fp64 PyTorch module."""
+    import t2onet_amd.actor_resnet as R
+    N, H, W = 4, 64, 256
+    img = synth.images(N, H, W, 31)
+    gout = synth.uniform((N, 512), 32, -1.0, 1.0)
+    cpu = _encoder().double().train()
+    ref_out, ref_dimg, ref_g = _run(cpu, img.double(), gout.double())
+    nets = {}
+    for trunk in (True, False):
+        monkeypatch.setattr(R, '_TRUNK', trunk)
+        net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+        if trunk:
+            assert net.trunk_plan().supported(img.to(DEV))
+        nets[trunk] = (net,) + _run(net, img.to(DEV), gout.to(DEV))
+    _, out1, dimg1, g1 = nets[True]
+    _, out0, dimg0, g0 = nets[False]
+    _close(out1, out0, 2e-5)
+    _close(dimg1, dimg0, 2e-4)
+    for n in g1:
+        _close(g1[n], g0[n], 2e-4)
+
+    def rel_l2(got, ref):
+        ref = ref.float().cpu()
+        return float((got.float().cpu() - ref).norm() / ref.norm())
+
+    # vs fp64: the forward elementwise; gradients in relative L2 (a ReLU whose fp32 pre-activation has the other sign
+    # than the fp64 one switches a whole path on or off: isolated entries differ by more than rounding)
+    for trunk in (True, False):
+        net, out, dimg, g = nets[trunk]
+        _close(out, ref_out, 2e-4)
+        assert rel_l2(dimg, ref_dimg) < 5e-3
+        for n, v in g.items():
+            assert rel_l2(v, ref_g[n]) < 5e-3, n
+        for (n, b), (_, rb) in zip(net.named_buffers(), cpu.named_buffers()):
+            _close(b, rb, 1e-4)                              # running statistics and num_batches_tracked
+
+
+def test_trunk_accumulates_into_persistent_gradients_and_is_deterministic():
+    """Every parameter has a dense .grad (the Trainer's flat buffer): the trunk adds into it inside its kernels, hands
+    autograd nothing, two backward passes give exactly twice one, and repeated runs are bit-identical."""
+    N, H, W = 2, 32, 256
+    img = synth.images(N, H, W, 41).to(DEV)
+    gout = synth.uniform((N, 512), 42, -1.0, 1.0).to(DEV)
+
+    def run(passes):
+        net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)                    # (zeros_like keeps the channels-last strides)
+        keep = [p.grad for p in net.parameters()]
+        for _ in range(passes):
+            x = img.clone().requires_grad_(True)
+            net(x).backward(gout)
+        assert all(p.grad is k for p, k in zip(net.parameters(), keep))
+        return {n: p.grad.clone() for n, p in net.named_parameters()}, x.grad.clone()
+
+    g1, d1 = run(1)
+    g1b, d1b = run(1)
+    assert torch.equal(d1, d1b) and all(torch.equal(g1[n], g1b[n]) for n in g1)
+    fresh = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+    out, dimg, gf = _run(fresh, img, gout)
+    assert torch.equal(dimg, d1)
+    for n in g1:
+        _close(g1[n], gf[n], 1e-6)
+    g2, _ = run(2)
+    trunk_names = [n for n in g1 if not n.startswith('fc.')]
+    for n in trunk_names:                                    # batch statistics do not depend on the running buffers
+        _close(g2[n], 2 * g1[n].double(), 1e-5)
