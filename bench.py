@@ -563,7 +563,8 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     want_graph = os.environ.get('T2O_GRAPH_ENCODER', '1') != '0'
-    tr = Trainer(model, opt, graph_encoder=want_graph)
+    want_step_graph = want_graph and os.environ.get('T2O_GRAPH_STEP', '0') != '0'
+    tr = Trainer(model, opt, graph_encoder=want_graph, graph_step=want_step_graph)
     g = torch.Generator().manual_seed(10 + ctx['rank'])
     img = torch.rand(B, 3, H, W, generator=g).to(device)
     tgt = torch.rand(B, 3, H, W, generator=g).to(device)
@@ -591,6 +592,7 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 2),
             'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()), 'parameters_finite': finite,
             'encoder_hipgraphs': bool(tr.graph_encoder and '_graphed_encoders' in model.__dict__),
+            'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0,
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,
                          'note': 'whole step against the dense fp32 matrix peak: 5 x ResNet-18 forward+backward = '

@@ -131,7 +131,7 @@ class Actor(nn.Module):
         group_inds = [torch.nonzero(ops == u).squeeze(1) for u in unqs]
         return unqs, group_inds, torch.argsort(torch.cat(group_inds))
 
-    def _encode_request(self, x, lengths, img_x, want_feat=True):
+    def _encode_request(self, x, lengths, img_x, want_feat=True, longest=None):
         """Request encoder + decoder initial state, and the image features of call 0.
 
         On a GPU in training mode the request encoder (a 17-step BiLSTM: ~1 ms forward and ~2 ms backward of
@@ -140,7 +140,7 @@ class Actor(nn.Module):
         stream, so the recurrent backward likewise overlaps the last image-encoder backward.  T2O_OVERLAP_LANG=0:
         everything on the caller's stream."""
         if not (img_x.is_cuda and self.training and torch.is_grad_enabled() and _OVERLAP_LANG):
-            enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
+            enc_out, enc_hidden, _ = self.lang_encoder(x, lengths, longest)
             return enc_out, self.decoder._init_state(enc_hidden), (self.image_features(img_x, 0) if want_feat else None)
         dev = img_x.device
         side = _SIDE_STREAMS.get(dev)                          # one per device for the process (module state, not the
@@ -149,7 +149,7 @@ class Actor(nn.Module):
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)                                 # x (and the parameters' last update) come from the caller's stream
         with torch.cuda.stream(side):
-            enc_out, enc_hidden, _ = self.lang_encoder(x, lengths)
+            enc_out, enc_hidden, _ = self.lang_encoder(x, lengths, longest)
             hidden = self.decoder._init_state(enc_hidden)
         feat = self.image_features(img_x, 0) if want_feat else None    # enqueued before the caller's stream waits for the side stream
         main.wait_stream(side)
@@ -195,17 +195,26 @@ class Actor(nn.Module):
         return torch.stack(pred_imgs, 1), torch.stack(pred_params, 1), torch.cat(logprobs, 1)
 
     # ------------------------------------------------------------------ free running
-    def episode_forward(self, x, img_x, mask_dict, reinforce_sample=1, lengths=None):
-        """actor.py:184-284.  Returns (state, pred_imgs (B,T,3,H,W), pred_ops (B,T), pred_params list of T (B,24))."""
-        B = x.shape[0]
+    def episode_forward(self, x, img_x, mask_dict, reinforce_sample=1, lengths=None, longest=None, stack=True):
+        """actor.py:184-284.  Returns (state, pred_imgs (B,T,3,H,W), pred_ops (B,T), pred_params list of T (B,24)).
+        lengths / longest: see RNNEncoder.forward (host-side lengths save a synchronisation; with `longest` given no
+        host value depends on device data and the whole call can be captured in a hipGraph); stack: episode_decode."""
+        enc_out, hidden, feat0 = self._encode_request(x, lengths, img_x, self.opt.decoder_max_len > 0, longest)
+        return self.episode_decode(x, img_x, enc_out, hidden, mask_dict, reinforce_sample, feat0, stack)
+
+    def episode_decode(self, x, img_x, enc_out, hidden, mask_dict=None, reinforce_sample=1, feat0=None, stack=True):
+        """The free-running decode of episode_forward from an encoded request (enc_out (B,L,d), hidden = decoder initial
+        state): everything after the request encoder (actor.py:213-284).  No host synchronisation when mask_dict is None,
+        so a whole train step from here on can be captured in one hipGraph (graphs.GraphedEpisodeStep).
+        stack=False: pred_imgs is returned as the list of T images (no (B,T,3,H,W) copy; `state` is then None)."""
+        B = img_x.shape[0]
         dev = img_x.device
-        enc_out, hidden, feat0 = self._encode_request(x, lengths, img_x, self.opt.decoder_max_len > 0)
         hiddens = [tuple(h.detach() for h in hidden)]
         op_mask = self._op_mask_row.repeat(B, 1)                # device-resident: no host-to-device copy (a sync)
         pred_op = torch.full((B, 1), self.start_id, dtype=torch.long, device=dev)
         pred_ops, pred_params, pred_imgs, pred_masks = [], [], [], []
         for call in range(self.opt.decoder_max_len):
-            feat = feat0 if call == 0 else self.image_features(img_x, call)
+            feat = feat0 if (call == 0 and feat0 is not None) else self.image_features(img_x, call)
             logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
             hiddens.append(tuple(h.detach() for h in hidden))
             probs = torch.exp(logp).squeeze(1)
@@ -228,6 +237,8 @@ class Actor(nn.Module):
         if not pred_ops:
             return {}, img_x.unsqueeze(1), [], pred_params
         pred_ops = torch.stack(pred_ops, 1)
+        if not stack:
+            return None, pred_imgs, pred_ops, pred_params
         pred_imgs = torch.stack(pred_imgs, 1)
         state = {'reqs': x, 'imgs': pred_imgs.detach(), 'ops': pred_ops, 'param': pred_params,
                  'hidden': hiddens, 'masks': torch.stack(pred_masks, 1) if pred_masks else None}

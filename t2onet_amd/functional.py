@@ -62,6 +62,10 @@ def workspace(B, H, W, device):
     need = _ws_need.get((B, H, W))
     if need is None:
         need = _ws_need[(B, H, W)] = _lib.load().t2o_workspace_bytes(B, H, W)
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the buffer's address is baked into the graph: a private allocation from the graph's
+        # pool (a cached buffer could be replaced -- freed -- by a later, larger request on the same stream)
+        return torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
     key = (device.index, _stream(device))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:

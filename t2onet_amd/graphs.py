@@ -69,9 +69,18 @@ class GraphedEncoder:
         self.memsets_replaced = 0                      # memset nodes of the captured graphs turned into kernel nodes
         buffers = list(module.buffers())
         saved = [t.clone() for t in buffers]
+        # every backward graph must carry its own weight transforms (any subset of the slots may be replayed in a step):
+        # no transformed-weight cache across the captured calls
+        plan = module.trunk_plan() if hasattr(module, 'trunk_plan') else None
+        keep_wt = plan.persistent_wt if plan is not None else False
+        if plan is not None:
+            plan.persistent_wt = False
+            plan.weights_changed()
         try:
             self.slots = self._capture(sample_img, calls, warmup)
         finally:
+            if plan is not None:
+                plan.persistent_wt = keep_wt
             with torch.no_grad():                      # warm-up and capture ran real forwards: undo their running statistics
                 for t, keep in zip(buffers, saved):
                     t.copy_(keep)
@@ -131,3 +140,70 @@ class GraphedEncoder:
             raise RuntimeError('GraphedEncoder: a parameter .grad tensor was replaced after capture (use '
                                'zero_grad(set_to_none=False) / the Trainer\'s flat buffer)')
         return _Replay.apply(img, self.anchor, self.slots[call])
+
+
+class GraphedEpisodeStep:
+    """The episode/L1 train step (train_seq2seqL1.py:74-88) -- request encoder, 5 x (image encoder, decoder step,
+    sampling, parameter heads, operator), END select, L1 and the whole backward -- as ONE hipGraph.  Outside stay only
+    the gradient all-reduce and Adam.  Per step the host issues a handful of calls instead of ~3,000 kernel launches; the
+    ~1,500 small launches of the decoder steps between the encoder passes, which ran ~4 us apart when enqueued one by
+    one, are graph nodes, and so is the request encoder (lang_encoder.masked_lstm: static shapes for a given request
+    length), forked onto a second stream inside the capture (Actor._encode_request), i.e. a parallel branch of the
+    graph beside the first image-encoder pass and, in the backward, beside the last one.
+
+    The graph zeroes the flat gradient buffer first.  Sampling (`torch.rand` in actor.sample_categorical) and the
+    request encoder's dropout use the generator's graph-safe state: every replay draws fresh numbers.  One instance
+    per (image shape, request length L, reinforce_sample)."""
+
+    def __init__(self, trainer, x, lengths, longest, img, target, reinforce_sample, warmup=2):
+        model = trainer.model
+        dev = img.device
+        self.trainer = trainer
+        self.reinforce_sample = reinforce_sample
+        self.longest = int(longest)
+        self.s_x = x.detach().clone()
+        self.s_len = lengths.detach().to(dev).clone()
+        self.s_img = img.detach().clone()
+        self.s_target = target.detach().clone()
+        self.memsets_replaced = 0
+        buffers = [t for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for t in m.buffers()]
+        saved = [t.clone() for t in buffers]
+        side = torch.cuda.Stream(device=dev)
+        try:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):                        # lazy initialisation (kernel selection, zero regions) outside the capture
+                    self._body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
+                self.loss = self._body()
+            self.memsets_replaced = _harden(self.graph)
+        finally:
+            with torch.no_grad():                              # warm-up ran real steps: undo their running statistics
+                for t, keep in zip(buffers, saved):
+                    t.copy_(keep)
+            trainer.grads.zero()
+
+    def _body(self):
+        from .train import select_end_images
+        from . import functional as T
+        tr = self.trainer
+        model = tr.model
+        if tr._trunk is not None:
+            tr._trunk.weights_changed()                        # the weights were updated since the last step: transform them again
+        tr.grads.zero()
+        _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, self.s_len, self.longest)
+        loss = T.l1_loss(select_end_images(imgs, ops, tr.opt.end_id), self.s_target)
+        loss.backward()
+        return loss.detach()
+
+    def run(self, x, lengths, img, target):
+        """One step for a batch whose longest request has this instance's length; returns the loss (a fresh tensor)."""
+        self.s_x.copy_(x)
+        self.s_len.copy_(lengths, non_blocking=True)
+        self.s_img.copy_(img)
+        self.s_target.copy_(target)
+        self.graph.replay()
+        return self.loss.clone()

@@ -48,19 +48,33 @@ class RNNEncoder(nn.Module):
         self.rnn = rnn_cls(word_embedding_size, hidden_size, n_layers, batch_first=True, bidirectional=bidirectional,
                            dropout=dropout_p)
 
-    def forward(self, input_labels, lengths=None):
+    def forward(self, input_labels, lengths=None, longest=None):
         """(B,L) ids -> (outputs (B,max_len,h*dirs), final state, embedded tokens).
 
         `lengths`: CPU tensor of request lengths when the caller has it on the host already (the
         data loader does) -- saves this module's one device-to-host sync.  The reference hands a
-        DEVICE tensor to pack_padded_sequence (lang_encoder.py:94), which current torch rejects."""
+        DEVICE tensor to pack_padded_sequence (lang_encoder.py:94), which current torch rejects.
+        `longest`: the batch's maximal length as a python int when the caller knows it (a captured hipGraph:
+        no host value may depend on device data); `lengths` may then be a device tensor or None."""
         if not self.variable_lengths:
             embedded = self.input_dropout(self.embedding(input_labels))
             outputs, state = self.rnn(embedded)
             return outputs, state, embedded
         dev = input_labels.device
+        if dev.type == 'cuda' and longest is not None and isinstance(self.rnn, nn.LSTM) and self.rnn.proj_size == 0 and self.rnn.batch_first:
+            # `longest` given (a hipGraph capture): the same arithmetic as the packed library call, unrolled with
+            # per-sample masks -- static shapes, no host-side lengths.  (The library's sequence entry point, MIOpen,
+            # blocks the host until its stream has drained: 16 ms forward and 21 ms backward of host stall per train
+            # step.  As ~2,000 torch launches per step this form costs 6 ms of GPU time, though: in-graph nodes still
+            # run ~6 us apart.)
+            dev_lengths = lengths if (lengths is not None and lengths.device == dev) else (input_labels != self.pad_id).sum(dim=1)
+            tokens = input_labels[:, :longest]
+            embedded = self.input_dropout(self.embedding(tokens))
+            outputs, state = masked_lstm(self.rnn, embedded, dev_lengths, self.training)
+            return outputs, state, embedded
         if lengths is None:
             lengths = (input_labels != self.pad_id).sum(dim=1).cpu()
+        lengths = lengths.cpu()
         # the same STABLE descending order computed twice -- on the host for pack_padded_sequence's lengths,
         # on the device for the gathers -- instead of copying the permutation to the device (a blocking copy
         # that drains the GPU queue at the top of every step)
@@ -79,3 +93,39 @@ class RNNEncoder(nn.Module):
         else:
             state = state[:, undo]
         return outputs, state, embedded
+
+
+def masked_lstm(rnn, x, lengths, training):
+    """nn.LSTM (batch_first, uni- or bidirectional, any depth) over zero-padded rows x (B,L,E) with per-sample lengths
+    (B,) on x's device: what pack_padded_sequence -> rnn -> pad_packed_sequence computes (lang_encoder.py:94-104 of the
+    reference), as L unrolled steps per layer and direction.  A sample's state stops changing after its last token
+    (forward direction) / starts from zero at its last token (reverse direction); outputs are zero at pads; the final
+    state is each sample's own.  Per layer and direction: ONE input GEMM for all steps, then per step one recurrent
+    GEMM and the fused gate kernel.  GPU tensors only (aten::_thnn_fused_lstm_cell, the gate kernel of torch.lstm_cell)."""
+    B, L, _ = x.shape
+    H, D = rnn.hidden_size, 2 if rnn.bidirectional else 1
+    valid = (torch.arange(L, device=x.device).unsqueeze(0) < lengths.unsqueeze(1)).unsqueeze(2)      # (B,L,1)
+    zero = x.new_zeros(B, H)
+    layer_in = x
+    hs, cs = [], []
+    for layer in range(rnn.num_layers):
+        outs = []
+        for d in range(D):
+            sfx = '_l%d%s' % (layer, '_reverse' if d else '')
+            w_ih, w_hh = getattr(rnn, 'weight_ih' + sfx), getattr(rnn, 'weight_hh' + sfx)
+            b_ih, b_hh = (getattr(rnn, 'bias_ih' + sfx), getattr(rnn, 'bias_hh' + sfx)) if rnn.bias else (None, None)
+            gi = F.linear(layer_in, w_ih)                      # (B,L,4H): every step's input gates in one GEMM
+            h, c = zero, zero
+            out_t = [None] * L
+            for t in (range(L - 1, -1, -1) if d else range(L)):
+                h2, c2, _ = torch.ops.aten._thnn_fused_lstm_cell(gi[:, t], F.linear(h, w_hh), c, b_ih, b_hh)
+                m = valid[:, t]
+                h, c = torch.where(m, h2, h), torch.where(m, c2, c)
+                out_t[t] = torch.where(m, h2, zero)
+            outs.append(torch.stack(out_t, 1))
+            hs.append(h)
+            cs.append(c)
+        layer_in = torch.cat(outs, 2) if D == 2 else outs[0]
+        if layer + 1 < rnn.num_layers and rnn.dropout > 0 and training:
+            layer_in = F.dropout(layer_in, rnn.dropout, True)
+    return layer_in, (torch.stack(hs, 0), torch.stack(cs, 0))

@@ -107,9 +107,12 @@ class FlatAdam:
 class Trainer:
     """Drives the reference's alternation: odd iterations supervised, even iterations episode/L1."""
 
-    def __init__(self, model, opt, lr=None, graph_encoder=False):
+    def __init__(self, model, opt, lr=None, graph_encoder=False, graph_step=False):
         """graph_encoder: capture the image encoder's forward/backward as hipGraphs on the first step (fixed
-        batch and image size from then on; other shapes run eagerly) -- see Actor.graph_image_encoder."""
+        batch and image size from then on; other shapes run eagerly) -- see Actor.graph_image_encoder.
+        graph_step: capture the WHOLE episode step behind the request encoder (all encoder passes, decoder steps,
+        sampling, operators, L1, backward) as one hipGraph per (image shape, request length) --
+        graphs.GraphedEpisodeStep; takes precedence over graph_encoder for the episode step."""
         self.model, self.opt = model, opt
         self.grads = FlatGradients(model.parameters())
         lr = lr if lr is not None else opt.learning_rate
@@ -119,6 +122,14 @@ class Trainer:
             self.optimizer = torch.optim.Adam(self.grads.params, lr=lr)
         self.itr = 0
         self.graph_encoder = graph_encoder
+        self.graph_step = graph_step
+        self._step_graphs = {}
+        self.max_step_graphs = 4                            # distinct (shape, request length) keys kept; others run eagerly
+        # transformed convolution weights of the encoder trunk live for a whole optimiser step (encoder.TrunkPlan)
+        enc = getattr(model, 'vis_encoder', None)
+        self._trunk = enc.trunk_plan() if (enc is not None and self.grads.flat.is_cuda and hasattr(enc, 'trunk_plan')) else None
+        if self._trunk is not None:
+            self._trunk.persistent_wt = True
         # the parameter heads add their gradients into the flat buffer inside their backward kernel (this trainer
         # zeroes it before every backward): 28 tensors x 5 decoder steps of autograd accumulation launches less
         executor = getattr(model, 'executor', None)
@@ -141,8 +152,51 @@ class Trainer:
     def _finish(self, loss):
         self.grads.zero()
         loss.backward()
+        self._update()
+
+    def _update(self):
         self.grads.all_reduce_mean()
         self.optimizer.step()
+        if self._trunk is not None:
+            self._trunk.weights_changed()
+
+    def _request_length(self, x, lengths):
+        """Length the request encoder truncates this batch to (lang_encoder.py:70-113: the batch maximum of the non-pad
+        counts); from the host-side `lengths` when the caller has them -- no device synchronisation."""
+        if not self.model.variable_lengths:
+            return int(x.shape[1])
+        if lengths is not None and not (torch.is_tensor(lengths) and lengths.is_cuda):
+            return int(max(lengths)) if not torch.is_tensor(lengths) else int(lengths.max())
+        return int((x != self.opt.null_id).sum(1).max())
+
+    def _graphed_episode_step(self, x, img_x, target, reinforce_sample, lengths):
+        """The step through graphs.GraphedEpisodeStep, or None when this batch cannot take it (capture failed, too many
+        distinct shapes): the caller then runs the eager step."""
+        model = self.model
+        if not (img_x.is_cuda and model.training and self.opt.decoder_max_len > 0):
+            return None
+        if lengths is None:
+            lengths = (x != self.opt.null_id).sum(1)
+        L = self._request_length(x, lengths)
+        key = (tuple(img_x.shape), L, bool(reinforce_sample))
+        sg = self._step_graphs.get(key)
+        if sg is None:
+            if len(self._step_graphs) >= self.max_step_graphs:
+                return None
+            from .graphs import GraphedEpisodeStep
+            try:
+                sg = GraphedEpisodeStep(self, x, lengths, L, img_x, target, reinforce_sample)
+            except Exception as e:                         # noqa: BLE001 -- an optimisation only: run eagerly instead
+                import warnings
+                warnings.warn('episode-step graph capture failed (%s: %s); continuing without it' % (type(e).__name__, e))
+                self.graph_step = False
+                return None
+            self._step_graphs[key] = sg
+            if self._trunk is not None:
+                self._trunk.weights_changed()              # (the capture's transformed weights belong to the graph's pool)
+        loss = sg.run(x, lengths, img_x, target)
+        self._update()
+        return loss
 
     def supervised_step(self, x, y, img_x, img_y, gt_params, lengths=None):
         """train_seq2seqL1.py:51-65: NLL (mean, no ignore_index) + MSE(sum)/count_nonzero."""
@@ -158,6 +212,10 @@ class Trainer:
 
     def episode_step(self, x, img_x, target, reinforce_sample=1, lengths=None):
         """train_seq2seqL1.py:74-88: free-running episode, L1 between the END image and the target."""
+        if self.graph_step:
+            loss = self._graphed_episode_step(x, img_x, target, reinforce_sample, lengths)
+            if loss is not None:
+                return loss
         self._maybe_graph(img_x)
         _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths)
         pred = select_end_images(pred_imgs, pred_ops, self.opt.end_id)

@@ -464,3 +464,76 @@ def test_graph_memset_nodes_become_kernel_nodes():
         expect[1024:2048] = int(np.array([0xABABABAB], dtype=np.uint32).view(np.int32)[0]) + 1
         expect[3072:3584] = 6
         assert torch.equal(buf.cpu(), expect)
+
+
+@pytest.mark.gpu
+def test_graphed_steps_stay_on_the_eager_trajectory_without_sampling():
+    """reinforce_sample=0 (arg-max operators: no random draw anywhere, request-encoder dropout off): five train steps
+    through (a) eager execution, (b) the per-call encoder hipGraphs, (c) ONE hipGraph for the whole step behind the
+    request encoder (graphs.GraphedEpisodeStep) must give the same losses step by step -- a graph that only perturbed
+    a gradient would drift within a step or two at this tolerance."""
+    import copy
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    opt = t2onet_amd.default_options()
+    opt.input_dropout_p = opt.dropout_p = 0.0
+    torch.manual_seed(31)
+    base = Actor(opt).to(dev).train()
+    base.use_channels_last()
+    B, H, W = 8, 256, 256
+    img = synth.images(B, H, W, 95).to(dev)
+    tgt = synth.images(B, H, W, 96).to(dev)
+    x = synth.requests(B, 17, 97).to(dev)
+    lengths = (x != 0).sum(1).cpu()
+    runs = {}
+    for mode in ('eager', 'encoder_graphs', 'step_graph'):
+        model = copy.deepcopy(base)
+        tr = Trainer(model, opt, graph_encoder=mode != 'eager', graph_step=mode == 'step_graph')
+        losses = []
+        for step in range(5):
+            losses.append(float(tr.episode_step(x, img, tgt, reinforce_sample=0, lengths=lengths)))
+        assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), (mode, losses)
+        if mode == 'step_graph':
+            assert tr.graph_step and len(tr._step_graphs) == 1, 'the whole-step graph was not used'
+            assert '_graphed_encoders' not in model.__dict__
+        if mode == 'encoder_graphs':
+            assert '_graphed_encoders' in model.__dict__
+        runs[mode] = (losses, [p.detach().clone() for p in model.parameters()])
+    for mode in ('encoder_graphs', 'step_graph'):
+        np.testing.assert_allclose(runs[mode][0], runs['eager'][0], rtol=0, atol=2e-3, err_msg=mode)
+    assert runs['eager'][0][-1] < runs['eager'][0][0]
+
+
+@pytest.mark.gpu
+def test_step_graph_draws_fresh_samples_and_trains():
+    """The whole-step hipGraph with sampled operators: every replay draws new random numbers (the losses of repeated
+    steps from FROZEN weights differ), parameters stay finite, and with a learning rate the loss goes down."""
+    import copy
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    opt = t2onet_amd.default_options()
+    torch.manual_seed(41)
+    base = Actor(opt).to(dev).train()
+    base.use_channels_last()
+    B, H, W = 8, 256, 256
+    img = synth.images(B, H, W, 101).to(dev)
+    tgt = synth.images(B, H, W, 102).to(dev)
+    x = synth.requests(B, 17, 103).to(dev)
+    lengths = (x != 0).sum(1).cpu()
+    frozen = Trainer(copy.deepcopy(base), opt, lr=0.0, graph_step=True)
+    seen = {round(float(frozen.episode_step(x, img, tgt, lengths=lengths)), 7) for _ in range(6)}
+    assert len(frozen._step_graphs) == 1 and len(seen) > 1, seen
+    # a second request length: its own graph
+    x2 = x.clone()
+    x2[:, 9:] = 0
+    x2[:, 8] = 2
+    frozen.episode_step(x2, img, tgt, lengths=(x2 != 0).sum(1).cpu())
+    assert len(frozen._step_graphs) == 2
+    tr = Trainer(copy.deepcopy(base), opt, graph_step=True)
+    losses = [float(tr.episode_step(x, img, tgt, lengths=lengths)) for _ in range(12)]
+    assert all(bool(torch.isfinite(p).all()) for p in tr.model.parameters())
+    assert min(losses[-4:]) < losses[0], losses

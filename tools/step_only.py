@@ -1,0 +1,39 @@
+"""N graphed episode train steps and nothing else (for rocprofv3 --kernel-trace): python tools/step_only.py [steps] [graph_step 0|1]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import t2onet_amd
+from t2onet_amd.actor import Actor
+from t2onet_amd.train import Trainer
+import bench
+
+dev = torch.device('cuda:0')
+opt = t2onet_amd.default_options()
+torch.manual_seed(10)
+model = Actor(opt).to(dev).train()
+model.use_channels_last()
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+tr = Trainer(model, opt, graph_encoder=True, graph_step=(sys.argv[2] != '0') if len(sys.argv) > 2 else True)
+g = torch.Generator().manual_seed(10)
+B, H, W = 64, 256, 256
+img = torch.rand(B, 3, H, W, generator=g).to(dev)
+tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
+x = bench.synthetic_requests(B, g)
+lengths = (x != 0).sum(1)
+x = x.to(dev)
+for _ in range(4):
+    tr.episode_step(x, img, tgt, lengths=lengths)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+host = 0.0
+for _ in range(steps):
+    h0 = time.perf_counter()
+    tr.episode_step(x, img, tgt, lengths=lengths)
+    host += time.perf_counter() - h0
+torch.cuda.synchronize()
+print('ms/step %.2f host enqueue %.2f' % ((time.perf_counter() - t0) / steps * 1e3, host / steps * 1e3))
+if tr._step_graphs:
+    sg = next(iter(tr._step_graphs.values()))
+    torch.cuda.synchronize()
+    h0 = time.perf_counter(); sg.graph.replay(); h1 = time.perf_counter(); torch.cuda.synchronize(); h2 = time.perf_counter()
+    print('graph: host launch %.2f ms, until done %.2f ms, memset nodes replaced %d' % ((h1 - h0) * 1e3, (h2 - h0) * 1e3, sg.memsets_replaced))
