@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 CFG2_OPS = [0, 1, 2, 3, 5, 6]
 CFG5_OPS = [5, 3, 5, 3, 0, 1, 2, 6]
+CFG2_GENERIC_OPS = [2, 0, 3, 1, 5, 6]        # configs[1]'s six operators in another order: no benchmark-specific code path
 OP_NAMES = {0: 'brightness', 1: 'contrast', 2: 'saturation', 3: 'color', 5: 'tone', 6: 'sharpness'}
 PARAM_RANGES = {0: (1, -0.3, 0.3), 1: (1, -0.3, 0.3), 2: (1, -0.3, 0.3), 3: (24, 0.5, 1.5), 5: (8, 0.5, 1.5), 6: (1, 0.0, 1.0)}
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -582,7 +583,25 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    dt = ctx['max_over_ranks'](time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    dt = ctx['max_over_ranks'](dt_local)
+    spread = {'min': round(dt_local / steps * 1e3, 3), 'max': round(dt_local / steps * 1e3, 3)}
+    allreduce_ms = None
+    if dist is not None:
+        t = torch.tensor([dt_local, -dt_local], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        spread = {'min': round(-float(t[1]) / steps * 1e3, 3), 'max': round(float(t[0]) / steps * 1e3, 3)}
+        # the step's one collective on its own: HIP events around the flat-buffer all-reduce (RCCL) on this rank
+        evs = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist.barrier()
+            e0.record()
+            tr.grads.all_reduce_mean()
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        allreduce_ms = round(ctx['max_over_ranks'](sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]), 4)
     flop = TRAIN_FLOP_PER_IMAGE * (H * W) / (256.0 * 256.0) * B
     tf = flop / (dt / steps) / 1e12                        # per GPU
     finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())   # (a step that produced inf/nan gradients is no measurement)
@@ -593,12 +612,63 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()), 'parameters_finite': finite,
             'encoder_hipgraphs': bool(tr.graph_encoder and '_graphed_encoders' in model.__dict__),
             'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0,
+            'ms_per_step_over_ranks': spread, 'allreduce_ms': allreduce_ms, 'allreduce_bytes': tr.grads.flat.numel() * 4,
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,
                          'note': 'whole step against the dense fp32 matrix peak: 5 x ResNet-18 forward+backward = '
                                  '67.8 GFLOP/image at 256x256 (SURVEY 8(d)); per GPU'},
             'workload': 'episode/L1 train step (train_seq2seqL1.py:74-88), bs=%d/GPU %dx%d fp32, sampled ops, '
                         'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world)}
+
+
+def conv_kernel_table(B, H, W, device, reps=20):
+    """HIP-event timings (on the launch stream) of the train step's dominant kernel, k_conv3x3_fwd<2,1>: the forward
+    and the data gradient of the stride-1 3x3 convolutions of the encoder's 64-, 128- and 256-channel stages
+    (models/actor_resnet.py:27-44) at this batch / image size -- 3 + 3 launches per stage and encoder pass, each
+    2 * 9 * C * C * pixels FLOP (19.33 GFLOP at bs=64 256x256 in every stage).  The 512-channel stage runs the
+    128-pixel-tile template <1,1> and is listed beside it."""
+    import torch
+    from t2onet_amd import _lib
+    import t2onet_amd.functional as T
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows = {}
+    g = torch.Generator().manual_seed(3)
+    for C, div in ((64, 4), (128, 8), (256, 16), (512, 32)):
+        h, w = H // div, W // div
+        x = torch.rand(B, h, w, C, generator=g).to(device) - 0.5
+        wt = (torch.rand(C, 3, 3, C, generator=g).to(device) - 0.5) * 0.05
+        y = torch.empty_like(x)
+        ws = T._conv_workspace(device, 64 << 10)
+        flop = 2.0 * 9 * C * C * B * h * w
+        for name, fn in (('fwd', lambda: lib.t2o_conv3x3_fwd_nhwc(x.data_ptr(), wt.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                                 B, h, w, C, C, st)),
+                         ('dgrad', lambda: lib.t2o_conv3x3_dgrad_pre_nhwc(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), ws.data_ptr(),
+                                                                         ws.numel(), B, h, w, C, C, st))):
+            for _ in range(3):
+                _lib.check(fn(), 'conv table')
+            evs = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(fn(), 'conv table')
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            rows['%s_c%d_%dx%d' % (name, C, h, w)] = {'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2),
+                                                   'kernel': 'k_conv3x3_fwd<2,1>' if C < 512 else 'k_conv3x3_fwd<1,1>'}
+    dom = [v for v in rows.values() if v['kernel'] == 'k_conv3x3_fwd<2,1>']
+    avg_ms = sum(v['ms'] for v in dom) / len(dom)
+    flop = dom[0]['GFLOP'] * 1e9
+    tf = flop / avg_ms / 1e9
+    return rows, {'bound': 'mfma', 'kernel': 'k_conv3x3_fwd<2,1>', 'of': 'train step (encoder 3x3 stride-1 convolutions, forward + data gradient, stages 1-3)',
+                  'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(tf / FP32_MATRIX_PEAK_TF, 4),
+                  'traffic': None, 'algorithmic_flop_per_launch': flop, 'avg_launch_ms': round(avg_ms, 5),
+                  'launches_per_step': 90,
+                  'note': 'dominant kernel of the train step (about a quarter of its GPU time): algorithmic FLOP per launch = '
+                          '2 x 9 x C^2 x pixels (SURVEY 8(d)), duration = mean of HIP-event timed launches over the six '
+                          '(stage, direction) shapes it runs with, equally often; v_mfma_f32_32x32x2_f32 dense peak'}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -722,18 +792,20 @@ def worker(args):
         if not args.quick:
             executor['bs256'] = executor_leg(ctx, CFG2_OPS, 4 * B, H, W, max(args.exec_steps // 4, 10), max(args.exec_warmup // 2, 3))
             executor['cfg5_16x512'] = executor_leg(ctx, CFG5_OPS, max(B // 4, 1), 2 * H, 2 * W, args.exec_steps, args.exec_warmup)
+        executor['cfg2_generic'] = executor_leg(ctx, CFG2_GENERIC_OPS, B, H, W, args.exec_steps, args.exec_warmup)
         fk = executor['cfg2_bs64']['fused']['kernels']
         dom = max(fk, key=lambda n: fk[n]['ms'])
-        line['roofline'] = {
-            'bound': 'hbm', 'kernel': dom, 'of': 'executor.cfg2_bs64.fused', 'achieved': fk[dom]['GBps'], 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(fk[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, P),
-            'algorithmic_bytes_per_launch': algorithmic_bytes(dom, P), 'avg_launch_ms': fk[dom]['ms'],
-            'note': 'dominant hand-written kernel of the op pipeline. algorithmic bytes = SURVEY 8(d) per-operator figure x '
-                    'operator applications in the launch (materialised accounting); a fused launch moves only hbm_min '
-                    'bytes, so frac includes fusion credit: fused_min_* give the fraction on the bytes it must move; '
-                    'traffic = PMC bytes when profiles/pmc_traffic.json was measured on this very library, else null',
-            'fused_min_bytes_per_launch': hbm_min_bytes(dom, P), 'fused_min_achieved': fk[dom]['hbm_min_GBps'],
-            'fused_min_frac': round(fk[dom]['hbm_min_GBps'] / HBM_PEAK_GBS, 4)}
+        line['executor_roofline'] = {
+            'bound': 'hbm', 'kernel': dom, 'of': 'executor.cfg2_bs64.fused', 'achieved': fk[dom]['hbm_min_GBps'], 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(fk[dom]['hbm_min_GBps'] / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom, P),
+            'moved_bytes_per_launch': hbm_min_bytes(dom, P), 'avg_launch_ms': fk[dom]['ms'],
+            'credited_bytes_per_launch': algorithmic_bytes(dom, P), 'credited_achieved': fk[dom]['GBps'],
+            'credited_frac': round(fk[dom]['GBps'] / HBM_PEAK_GBS, 4),
+            'note': 'dominant hand-written kernel of the op pipeline.  frac = bytes the launch MOVES (read image + gradient, '
+                    'write gradient: 36 B/pixel whatever the fusion) / time / 8 TB/s -- a physical fraction, <= 1.  credited_* '
+                    'uses SURVEY 8(d)\'s materialised accounting (36 B/pixel per operator application the fused launch '
+                    'performs) and may exceed 1.  traffic = PMC bytes when profiles/pmc_traffic.json was measured on this '
+                    'very library, else null'}
     except Exception as e:                     # noqa: BLE001
         executor['error'] = '%s: %s' % (type(e).__name__, e)
     line['executor'] = executor
@@ -770,6 +842,10 @@ def worker(args):
         line['ms_per_step'] = train['ms_per_step']
         line['train_step'] = train
         line['train_roofline'] = train['roofline']
+        try:
+            line['conv_kernels'], line['roofline'] = conv_kernel_table(B, H, W, device)
+        except Exception as e:             # noqa: BLE001
+            line['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     except Exception as e:                 # noqa: BLE001
         import traceback
         traceback.print_exc()

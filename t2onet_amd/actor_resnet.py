@@ -59,6 +59,8 @@ def _bn_relu(bn, x, residual=None, counted=False, partial=None):
     producing convolution's statistics (see _conv)."""
     if _FUSED and bn.training and x.is_cuda:
         return T.batch_norm_relu(x, bn, residual, count=not counted, partial=partial if T._is_nhwc(x) else None)
+    if counted and bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.sub_(1)                       # ResNet.forward advanced it already; bn(x) does so again
     out = bn(x)
     return F.relu(out if residual is None else out + residual)
 
@@ -67,6 +69,8 @@ def _bn_plain(bn, x, counted=False):
     """bn(x) of the shortcut branch: the fused kernels without the activation on channels-last activations."""
     if _FUSED and bn.training and x.is_cuda and T._is_nhwc(x):
         return T.batch_norm_relu(x, bn, None, relu=False, count=not counted)
+    if counted and bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.sub_(1)                       # ResNet.forward advanced it already; bn(x) does so again
     return bn(x)
 
 
@@ -106,10 +110,14 @@ class ResNet(nn.Module):
         self.fc = nn.Linear(512, num_outputs)
 
     def _batch_counters(self):
+        """num_batches_tracked of the batch norms that are in training mode (a layer frozen with bn.eval() keeps its count)."""
         cached = self.__dict__.get('_nbt')
-        if cached is None or cached[0] is not self.bn1.num_batches_tracked:      # (.to() replaces the buffer tensors)
-            cached = self.__dict__['_nbt'] = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
-        return cached
+        key = tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        if cached is None or cached[0] is not self.bn1.num_batches_tracked or cached[1] != key:      # (.to() replaces the buffer tensors)
+            cached = self.__dict__['_nbt'] = (self.bn1.num_batches_tracked, key,
+                                              [m.num_batches_tracked for m in self.modules()
+                                               if isinstance(m, nn.BatchNorm2d) and m.training and m.track_running_stats])
+        return cached[2]
 
     def _make_layer(self, planes, num_blocks, stride):
         blocks = []

@@ -1145,6 +1145,11 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
   }
 }
 
+// 16-byte accesses (LDS-DMA pieces, float4 loads) straight from caller storage: every tensor base must be 16-byte aligned
+bool misaligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(c) | reinterpret_cast<size_t>(d)) & 15) != 0;
+}
+
 int conv_env(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -1293,7 +1298,7 @@ int t2o_conv3x3_wgrad_nhwc(const float* x, const float* dy, float* dw, void* wor
 
 int t2o_conv3x3_wgrad_acc_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                                int N, int Ho, int Wo, int Ci, int Co, int stride, int accumulate, void* stream) {
-  if (!x || !dy || !dw) return set_error(T2O_EINVAL, "conv3x3_wgrad: null pointer");
+  if (!x || !dy || !dw || misaligned16(x, dy, dw)) return set_error(T2O_EINVAL, "conv3x3_wgrad: null or not 16-byte aligned pointer");
   if (stride != 1 && stride != 2) return set_error(T2O_EUNSUPPORTED, "conv3x3_wgrad: stride 1 or 2");
   const size_t need = stride == 1 ? t2o_conv3x3_wgrad_workspace_bytes(N, Ho, Wo, Ci, Co) : t2o_conv3x3s2_wgrad_workspace_bytes(N, Ho, Wo, Ci, Co);
   if (need == 0)
@@ -1310,7 +1315,7 @@ size_t t2o_conv3x3s2_wgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co
 
 int t2o_conv3x3s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                              int N, int Ho, int Wo, int Ci, int Co, void* stream) {
-  if (!x || !dy || !dw) return set_error(T2O_EINVAL, "conv3x3s2_wgrad: null pointer");
+  if (!x || !dy || !dw || misaligned16(x, dy, dw)) return set_error(T2O_EINVAL, "conv3x3s2_wgrad: null or not 16-byte aligned pointer");
   const size_t need = t2o_conv3x3s2_wgrad_workspace_bytes(N, Ho, Wo, Ci, Co);
   if (need == 0)
     return set_error(T2O_EUNSUPPORTED, "conv3x3s2_wgrad: channel counts must be multiples of 64 and the output-gradient width a multiple of 4");
@@ -1332,7 +1337,7 @@ size_t t2o_conv3x3_fwd_workspace_bytes(int N, int H, int W, int Ci, int Co) {
 
 int t2o_conv3x3_fwd_nhwc(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes,
                          int N, int H, int W, int Ci, int Co, void* stream) {
-  if (!x || !w || !y) return set_error(T2O_EINVAL, "conv3x3_fwd: null pointer");
+  if (!x || !w || !y || misaligned16(x, w, y)) return set_error(T2O_EINVAL, "conv3x3_fwd: null or not 16-byte aligned pointer");
   if (!fwd_supported(N, H, W, Ci, Co))
     return set_error(T2O_EUNSUPPORTED, "conv3x3_fwd: Ci must be a multiple of 32, Co of 64, the image width of 8");
   if (!workspace || workspace_bytes < fwd_zero_bytes(Ci)) return set_error(T2O_EWORKSPACE, "conv3x3_fwd: workspace too small");
@@ -1349,7 +1354,7 @@ int t2o_conv3x3_fwd_stats_rows(int N, int Ho, int Wo, int Co, int stride) {
 
 int t2o_conv3x3_fwd_stats_nhwc(const float* x, const float* w, float* y, float* stats, void* workspace, size_t workspace_bytes,
                                int N, int Ho, int Wo, int Ci, int Co, int stride, void* stream) {
-  if (!x || !w || !y || !stats) return set_error(T2O_EINVAL, "conv3x3_fwd_stats: null pointer");
+  if (!x || !w || !y || !stats || misaligned16(x, w, y)) return set_error(T2O_EINVAL, "conv3x3_fwd_stats: null or not 16-byte aligned pointer");
   if (stride != 1 && stride != 2) return set_error(T2O_EUNSUPPORTED, "conv3x3_fwd_stats: stride 1 or 2");
   const size_t need = stride == 1 ? t2o_conv3x3_fwd_workspace_bytes(N, Ho, Wo, Ci, Co) : t2o_conv3x3s2_fwd_workspace_bytes(N, Ho, Wo, Ci, Co);
   if (need == 0) return set_error(T2O_EUNSUPPORTED, "conv3x3_fwd_stats: Ci must be a multiple of 32, Co of 64, the output width of 8");
@@ -1416,7 +1421,7 @@ size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) 
 
 int t2o_conv3x3s2_fwd_nhwc(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes,
                            int N, int Ho, int Wo, int Ci, int Co, void* stream) {
-  if (!x || !w || !y) return set_error(T2O_EINVAL, "conv3x3s2_fwd: null pointer");
+  if (!x || !w || !y || misaligned16(x, w, y)) return set_error(T2O_EINVAL, "conv3x3s2_fwd: null or not 16-byte aligned pointer");
   const size_t need = t2o_conv3x3s2_fwd_workspace_bytes(N, Ho, Wo, Ci, Co);
   if (need == 0) return set_error(T2O_EUNSUPPORTED, "conv3x3s2_fwd: Ci must be a multiple of 32, Co of 64, the output width of 8");
   if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "conv3x3s2_fwd: workspace too small");
@@ -1432,7 +1437,7 @@ size_t t2o_conv3x3_dgrad_workspace_bytes(int N, int H, int W, int Ci, int Co) {
 
 int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                            int N, int H, int W, int Ci, int Co, void* stream) {
-  if (!dy || !w || !dx) return set_error(T2O_EINVAL, "conv3x3_dgrad: null pointer");
+  if (!dy || !w || !dx || misaligned16(dy, w, dx)) return set_error(T2O_EINVAL, "conv3x3_dgrad: null or not 16-byte aligned pointer");
   if (!fwd_supported(N, H, W, Co, Ci) || Co % 32 != 0 || Ci % 32 != 0)
     return set_error(T2O_EUNSUPPORTED, "conv3x3_dgrad: Co must be a multiple of 32, Ci of 64, the image width of 8");
   if (!workspace || workspace_bytes < t2o_conv3x3_dgrad_workspace_bytes(N, H, W, Ci, Co))
@@ -1448,7 +1453,7 @@ int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* wor
 
 int t2o_conv3x3_dgrad_pre_nhwc(const float* dy, const float* wt, const float* addend, float* dx, void* workspace, size_t workspace_bytes,
                                int N, int H, int W, int Ci, int Co, void* stream) {
-  if (!dy || !wt || !dx) return set_error(T2O_EINVAL, "conv3x3_dgrad_pre: null pointer");
+  if (!dy || !wt || !dx || misaligned16(dy, wt, dx, addend)) return set_error(T2O_EINVAL, "conv3x3_dgrad_pre: null or not 16-byte aligned pointer");
   if (!fwd_supported(N, H, W, Co, Ci) || Co % 32 != 0 || Ci % 32 != 0)
     return set_error(T2O_EUNSUPPORTED, "conv3x3_dgrad_pre: Co must be a multiple of 32, Ci of 64, the image width of 8");
   if (!workspace || workspace_bytes < fwd_zero_bytes(Co)) return set_error(T2O_EWORKSPACE, "conv3x3_dgrad_pre: workspace too small");
@@ -1468,7 +1473,7 @@ size_t t2o_conv3x3s2_dgrad_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co
 
 int t2o_conv3x3s2_dgrad_nhwc(const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
                              int N, int Ho, int Wo, int Ci, int Co, void* stream) {
-  if (!dy || !w || !dx) return set_error(T2O_EINVAL, "conv3x3s2_dgrad: null pointer");
+  if (!dy || !w || !dx || misaligned16(dy, w, dx)) return set_error(T2O_EINVAL, "conv3x3s2_dgrad: null or not 16-byte aligned pointer");
   if (stem_dgrad_supported(N, Ho, Wo, Ci, Co)) {                     // the 3-channel stem: streaming kernel, no workspace
     const unsigned grid = (unsigned)(N * ((Ho + kStemTH - 1) / kStemTH) * ((Wo + kStemTW - 1) / kStemTW));
     if (Co == 64) k_stem_dgrad<64, false><<<grid, 256, 0, (hipStream_t)stream>>>(dy, w, dx, N, Ho, Wo, 0);
@@ -1489,7 +1494,7 @@ int t2o_conv3x3s2_dgrad_nhwc(const float* dy, const float* w, float* dx, void* w
 
 int t2o_conv3x3s2_dgrad_pre_nhwc(const float* dy, const float* wt, float* dx, void* workspace, size_t workspace_bytes,
                                  int N, int Ho, int Wo, int Ci, int Co, void* stream) {
-  if (!dy || !wt || !dx) return set_error(T2O_EINVAL, "conv3x3s2_dgrad_pre: null pointer");
+  if (!dy || !wt || !dx || misaligned16(dy, wt, dx)) return set_error(T2O_EINVAL, "conv3x3s2_dgrad_pre: null or not 16-byte aligned pointer");
   if (!fwd_supported(N, Ho, Wo, Co, Ci) || (size_t)N * Ho * Wo * 4 + 1024 >= ((size_t)1 << 31))
     return set_error(T2O_EUNSUPPORTED, "conv3x3s2_dgrad_pre: Co must be a multiple of 32, Ci of 64 and the output-gradient width of 8");
   if (!workspace || workspace_bytes < fwd_zero_bytes(Co)) return set_error(T2O_EWORKSPACE, "conv3x3s2_dgrad_pre: workspace too small");

@@ -195,6 +195,10 @@ __global__ __launch_bounds__(kThreads) void k_sc_wgrad(WgArgs g) {
   for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * g.Ci] = acc[r];
 }
 
+bool misaligned16(const void* a, const void* b, const void* c) {
+  return ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(c)) & 15) != 0;
+}
+
 bool sc_supported(int N, int H, int W, int Ci, int Co) {
   return N > 0 && H > 0 && W > 0 && Ci >= 64 && Co >= 64 && Ci % 64 == 0 && Co % 64 == 0 && (size_t)N * H * W < ((size_t)1 << 30);
 }
@@ -232,7 +236,7 @@ WgPlan wg_plan(int Q, int Ci, int Co) {
 extern "C" {
 
 int t2o_conv1x1s2_fwd_nhwc(const float* x, const float* w, float* y, int N, int H, int W, int Ci, int Co, void* stream) {
-  if (!x || !w || !y) return set_error(T2O_EINVAL, "conv1x1s2_fwd: null pointer");
+  if (!x || !w || !y || misaligned16(x, w, y)) return set_error(T2O_EINVAL, "conv1x1s2_fwd: null or not 16-byte aligned pointer");
   if (!sc_supported(N, H, W, Ci, Co)) return set_error(T2O_EUNSUPPORTED, "conv1x1s2_fwd: channel counts must be multiples of 64");
   const RowMap m = row_map(H, W);
   const int rc = launch_gemm(x, w, y, N * m.Ho * m.Wo, Ci, Co, m, 1, 0, (hipStream_t)stream);
@@ -240,7 +244,7 @@ int t2o_conv1x1s2_fwd_nhwc(const float* x, const float* w, float* y, int N, int 
 }
 
 int t2o_conv1x1s2_dgrad_acc_nhwc(const float* dy, const float* wt, float* dx, int N, int H, int W, int Ci, int Co, void* stream) {
-  if (!dy || !wt || !dx) return set_error(T2O_EINVAL, "conv1x1s2_dgrad_acc: null pointer");
+  if (!dy || !wt || !dx || misaligned16(dy, wt, dx)) return set_error(T2O_EINVAL, "conv1x1s2_dgrad_acc: null or not 16-byte aligned pointer");
   if (!sc_supported(N, H, W, Ci, Co)) return set_error(T2O_EUNSUPPORTED, "conv1x1s2_dgrad_acc: channel counts must be multiples of 64");
   const RowMap m = row_map(H, W);
   const int rc = launch_gemm(dy, wt, dx, N * m.Ho * m.Wo, Co, Ci, m, 0, 1, (hipStream_t)stream);
@@ -256,7 +260,7 @@ size_t t2o_conv1x1s2_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co) 
 
 int t2o_conv1x1s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                              int N, int H, int W, int Ci, int Co, int accumulate, void* stream) {
-  if (!x || !dy || !dw) return set_error(T2O_EINVAL, "conv1x1s2_wgrad: null pointer");
+  if (!x || !dy || !dw || misaligned16(x, dy, dw)) return set_error(T2O_EINVAL, "conv1x1s2_wgrad: null or not 16-byte aligned pointer");
   const size_t need = t2o_conv1x1s2_wgrad_workspace_bytes(N, H, W, Ci, Co);
   if (need == 0) return set_error(T2O_EUNSUPPORTED, "conv1x1s2_wgrad: channel counts must be multiples of 64");
   if (!workspace || workspace_bytes < need) return set_error(T2O_EWORKSPACE, "conv1x1s2_wgrad: workspace too small");

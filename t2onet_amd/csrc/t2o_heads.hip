@@ -265,6 +265,8 @@ bool fill(HeadArgs& a, const float* const* w1, const float* const* b1, const flo
   for (int k = 0; k < kOps; ++k) {
     a.w1[k] = w1[k]; a.b1[k] = b1[k]; a.w2[k] = w2[k]; a.b2[k] = b2[k];
     if (k != 4 && (!w1[k] || !b1[k] || !w2[k] || !b2[k])) return false;
+    // the weight matrices are read with 16-byte accesses (row_dot: 512-float rows)
+    if (k != 4 && ((reinterpret_cast<size_t>(w1[k]) | reinterpret_cast<size_t>(w2[k])) & 15) != 0) return false;
   }
   return true;
 }
@@ -279,7 +281,7 @@ int t2o_param_heads_fwd(const int* op_id, const float* ctx, const float* const* 
   if (!op_id || !ctx || !w1 || !b1 || !w2 || !b2 || !hidden || !raw || !param) return set_error(T2O_EINVAL, "param_heads_fwd: null pointer");
   if (B <= 0 || D != kD) return set_error(T2O_EINVAL, "param_heads_fwd: B must be positive and the feature width 512");
   HeadArgs a = {};
-  if (!fill(a, w1, b1, w2, b2)) return set_error(T2O_EINVAL, "param_heads_fwd: a head's weight pointer is null");
+  if (!fill(a, w1, b1, w2, b2)) return set_error(T2O_EINVAL, "param_heads_fwd: a head's weight pointer is null or its matrix not 16-byte aligned");
   a.op_id = op_id; a.ctx = ctx; a.hidden = hidden; a.raw = raw; a.param = param; a.B = B;
   a.brightness_range = brightness_range; a.sat_lo = sat_lo; a.sat_hi = sat_hi; a.sharpness_range = sharpness_range;
   k_heads_fc1<<<dim3(B, kSlices), kHT, 0, (hipStream_t)stream>>>(a);
@@ -296,10 +298,12 @@ int t2o_param_heads_bwd_acc(const int* op_id, const float* ctx, const float* con
     return set_error(T2O_EINVAL, "param_heads_bwd: null pointer");
   if (B <= 0 || D != kD) return set_error(T2O_EINVAL, "param_heads_bwd: B must be positive and the feature width 512");
   HeadArgs a = {};
-  if (!fill(a, w1, b1, w2, b2)) return set_error(T2O_EINVAL, "param_heads_bwd: a head's weight pointer is null");
+  if (!fill(a, w1, b1, w2, b2)) return set_error(T2O_EINVAL, "param_heads_bwd: a head's weight pointer is null or its matrix not 16-byte aligned");
   for (int k = 0; k < kOps; ++k) {
     a.gw1[k] = gw1[k]; a.gb1[k] = gb1[k]; a.gw2[k] = gw2[k]; a.gb2[k] = gb2[k];
     if (k != 4 && (!gw1[k] || !gb1[k] || !gw2[k] || !gb2[k])) return set_error(T2O_EINVAL, "param_heads_bwd: a gradient pointer is null");
+    if (k != 4 && ((reinterpret_cast<size_t>(gw1[k]) | reinterpret_cast<size_t>(gw2[k])) & 15) != 0)
+      return set_error(T2O_EINVAL, "param_heads_bwd: a weight-gradient matrix is not 16-byte aligned");
   }
   a.op_id = op_id; a.ctx = ctx; a.hidden = const_cast<float*>(hidden); a.raw = const_cast<float*>(raw);
   a.gparam = gparam; a.gctx = gctx; a.dpre = dpre; a.B = B; a.accumulate = accumulate ? 1 : 0;

@@ -143,6 +143,28 @@ class FiveKAct(Dataset):
         return img_x, imgs, np.array(dic['request_idx']), ops, params, dic['request']
 
 
+class FiveK(Dataset):
+    """(img_x, img_y, req_idx, req) per item with NO planned actions, like datasets/FiveKdataset.py:24-52: the split the
+    reference validates and tests on (train_seq2seqL1.py:155-156, batch_size=1).  phase 'train': square training size;
+    any other phase: full resolution with the short side scaled to 600 pixels (load_infer_img_short_size_bounded)."""
+
+    def __init__(self, img_dir, anno_dir, phase='val', session=1, train_img_size=128, short_size=600):
+        self.img_dir, self.phase, self.size, self.short_size = img_dir, phase, train_img_size, short_size
+        with open(os.path.join(anno_dir, '{}_sess_{}.json'.format(phase, session))) as f:
+            self.data = json.load(f)
+
+    def __len__(self):
+        return len(self.data)
+
+    def _load(self, name):
+        path = os.path.join(self.img_dir, name)
+        return load_image(path, self.size) if self.phase == 'train' else load_image_short_side(path, self.short_size)
+
+    def __getitem__(self, item):
+        dic = self.data[item]
+        return self._load(dic['input']), self._load(dic['output']), np.array(dic['request_idx']), dic['request']
+
+
 class SyntheticFiveK(Dataset):
     """FiveK-shaped random items: what bench.py and the tests train on."""
 

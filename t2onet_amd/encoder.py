@@ -64,7 +64,7 @@ class TrunkPlan:
         for p in self.params:
             if p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last):
                 return False
-        return all(bn.momentum is not None and bn.affine and bn.track_running_stats for bn in self.bns)
+        return all(bn.training and bn.momentum is not None and bn.affine and bn.track_running_stats for bn in self.bns)
 
     def transformed(self, lib, st):
         """{id(conv): wt}: 3x3 stride-1 -> tap-mirrored transpose, 3x3 stride-2 -> plain transpose per tap, 1x1 -> transpose."""

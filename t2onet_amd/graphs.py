@@ -63,7 +63,8 @@ class GraphedEncoder:
         if any(p.grad is None for p in self.params):
             raise RuntimeError('GraphedEncoder: every parameter needs a persistent .grad tensor before capture')
         self.grads = [p.grad for p in self.params]
-        self._grad_ptrs = (self.grads[0].data_ptr(), self.grads[-1].data_ptr())
+        self._grad_ptrs = [g.data_ptr() for g in self.grads]
+        self._param_ptrs = [p.data_ptr() for p in self.params]
         # a grad-requiring scalar keeps the replay node in the autograd graph when the image itself needs no gradient
         self.anchor = torch.zeros((), device=sample_img.device, requires_grad=True)
         self.memsets_replaced = 0                      # memset nodes of the captured graphs turned into kernel nodes
@@ -135,10 +136,13 @@ class GraphedEncoder:
                 and self.module.training and torch.is_grad_enabled())
 
     def __call__(self, img, call):
-        if (self.params[0].grad is None or self.params[0].grad.data_ptr() != self._grad_ptrs[0]
-                or self.params[-1].grad is None or self.params[-1].grad.data_ptr() != self._grad_ptrs[1]):
-            raise RuntimeError('GraphedEncoder: a parameter .grad tensor was replaced after capture (use '
-                               'zero_grad(set_to_none=False) / the Trainer\'s flat buffer)')
+        for p, pp, gp in zip(self.params, self._param_ptrs, self._grad_ptrs):     # (62 integer compares per call)
+            if p.data_ptr() != pp:
+                raise RuntimeError('GraphedEncoder: a parameter was re-allocated after capture (module.to(...), '
+                                   'use_channels_last() ...): the captured graphs still read the old storage')
+            if p.grad is None or p.grad.data_ptr() != gp:
+                raise RuntimeError('GraphedEncoder: a parameter .grad tensor was replaced after capture (use '
+                                   'zero_grad(set_to_none=False) / the Trainer\'s flat buffer)')
         return _Replay.apply(img, self.anchor, self.slots[call])
 
 

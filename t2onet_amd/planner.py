@@ -140,6 +140,10 @@ def beam_search(I_0, I_gt, txt, executor, discriminator, beam_size, operations, 
                 dist_type='L1', optimizer='sweep', replace=False):
     """Beam search over operator sequences (beam_search.py:196-264).  Returns (actions, Is):
     per surviving sequence the list of (name, param list, dist) and the list of intermediate images."""
+    if dist_type != 'L1' or discriminator is not None:
+        # (checked here, before any fit: the batched sweep below scores candidates with the L1 kernels directly and
+        # would otherwise answer a non-L1 request with L1 distances for the one-parameter operators)
+        raise NotImplementedError('beam_search: L1 distance without a discriminator only (the FiveK planner, beam_search.py:196-264)')
     min_dist = float('inf')
     sequences = [[[], float('inf')]]
     I_buff = [I_0]

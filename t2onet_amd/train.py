@@ -29,16 +29,20 @@ def select_end_images(pred_imgs, pred_ops, end_id):
 class FlatGradients:
     """All trainable parameters' .grad as views of one flat fp32 buffer."""
 
+    ALIGN = 64          # floats: every segment starts on a 256-byte boundary (kernels read parameters and gradients
+                        # with 16-byte accesses and LDS-DMA straight from this storage)
+
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        off = 0
+        self.offsets, n = [], 0
         for p in self.params:
+            self.offsets.append(n)
+            n += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        for p, off in zip(self.params, self.offsets):
             # same strides as the parameter (channels-last convolution weights stay channels-last): optimiser and
             # gradient accumulation then run their dense fast paths; the flat all-reduce does not care about layout
             p.grad = _view_like(self.flat[off:off + p.numel()], p)
-            off += p.numel()
 
     def zero(self):
         self.flat.zero_()
@@ -68,25 +72,30 @@ class FlatAdam:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.step_count = 0
         dev = grads.flat.device
-        self.flat_param = torch.empty_like(grads.flat)
-        off = 0
+        self.flat_param = torch.zeros_like(grads.flat)       # (same segment layout as the gradients: padding stays zero)
         with torch.no_grad():
-            for p in grads.params:
+            for p, off in zip(grads.params, grads.offsets):
                 seg = self.flat_param[off:off + p.numel()]
                 view = _view_like(seg, p)
                 view.copy_(p.data)
                 p.data = view                               # the module's parameter now IS a slice of the flat buffer
-                off += p.numel()
         self.exp_avg = torch.zeros_like(grads.flat)
         self.exp_avg_sq = torch.zeros_like(grads.flat)
-        self._ptr0 = grads.params[0].data_ptr()
+        self._ptrs = [p.data_ptr() for p in grads.params]
         assert dev.type == 'cuda'
+
+    def check_homes(self):
+        """Every parameter must still live in the flat buffer: module.to(...), use_channels_last() after the Trainer was
+        built re-allocate parameters (only the 4-D ones for a memory-format change), and the update would then go to
+        an orphaned copy."""
+        for p, ptr in zip(self.grads.params, self._ptrs):
+            if p.data_ptr() != ptr:
+                raise RuntimeError('FlatAdam: a parameter was re-allocated after the optimiser was built (module.to(...), '
+                                   'use_channels_last() ...): build the Trainer afterwards')
 
     def step(self):
         from . import _lib, functional as T
-        if self.grads.params[0].data_ptr() != self._ptr0:
-            raise RuntimeError('FlatAdam: a parameter was re-allocated after the optimiser was built (module.to(...), '
-                               'use_channels_last() ...): build the Trainer afterwards')
+        self.check_homes()
         self.step_count += 1
         rc = _lib.load().t2o_adam_step(self.flat_param.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr, self.betas[0],

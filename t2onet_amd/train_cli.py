@@ -23,7 +23,7 @@ from torch.utils.data import DataLoader, DistributedSampler
 from . import default_options
 from .actor import Actor
 from . import evaluate
-from .data import FiveKAct, SyntheticFiveK
+from .data import FiveK, FiveKAct, SyntheticFiveK
 from .train import Trainer
 
 
@@ -109,9 +109,13 @@ def main(argv=None):
     sampler = DistributedSampler(dataset, world, rank, shuffle=True) if world > 1 else None
     loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
                         num_workers=args.num_workers, drop_last=True)
-    val_set = SyntheticFiveK(n=args.val_items, size=args.img_size, seed=args.manual_seed + 1) if args.synthetic else \
-        FiveKAct(args.img_dir, args.anno_dir, args.act_dir, 'val', 1, args.img_size)
-    val_loader = DataLoader(_EvalView(val_set), batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
+    if args.synthetic:
+        val_loader = DataLoader(_EvalView(SyntheticFiveK(n=args.val_items, size=args.img_size, seed=args.manual_seed + 1)),
+                                batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
+    else:
+        # the reference validates on FiveK(..., 'val'): no planned actions needed, full resolution (short side 600), one
+        # image per batch (train_seq2seqL1.py:155-156) -- the validation L1 and checkpoint_best follow that
+        val_loader = DataLoader(FiveK(args.img_dir, args.anno_dir, 'val', 1), batch_size=1, shuffle=False, num_workers=1)
     ckpt_dir = os.path.join(args.run_dir, 'seq2seqL1_model')
     stats = {'train_iter': [], 'val_dist': [], 'best_val_dist': float('inf'), 'best_iter': 0}
     itr, epoch = 0, 0

@@ -146,3 +146,30 @@ def test_decoder_single_step_equals_nn_lstm():
     g1, = torch.autograd.grad(out.sum() + c.sum(), x, retain_graph=True)
     g2, = torch.autograd.grad(ref_out.sum() + rc.sum(), x)
     np.testing.assert_allclose(g1.numpy(), g2.numpy(), rtol=0, atol=5e-6)
+
+
+def test_flat_gradient_segments_are_aligned():
+    """Every parameter's gradient (and, on the GPU, its re-homed storage) starts on a 256-byte boundary of the flat
+    buffer: kernels read them with 16-byte accesses and LDS-DMA (head / bn1 tensors used to sit at odd offsets)."""
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import FlatGradients
+    model = Actor(t2onet_amd.default_options())
+    fg = FlatGradients(model.parameters())
+    base = fg.flat.data_ptr()
+    assert all((p.grad.data_ptr() - base) % 256 == 0 for p in fg.params)
+    assert all(p.grad.shape == p.shape and p.grad.stride() == p.stride() for p in fg.params)
+    assert fg.flat.numel() >= sum(p.numel() for p in fg.params) and float(fg.flat.abs().sum()) == 0.0
+    # segments do not overlap
+    spans = sorted((p.grad.data_ptr(), p.grad.data_ptr() + 4 * p.numel()) for p in fg.params)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_beam_search_rejects_non_l1_requests_before_any_fit():
+    """the batched sweep scored one-parameter operators with the L1 kernels whatever dist_type said."""
+    import pytest
+    from t2onet_amd import planner
+    with pytest.raises(NotImplementedError):
+        planner.beam_search(None, None, None, None, None, 2, [0, 1], ['brightness', 'contrast'], 1, 1e-3, dist_type='L2')
+    with pytest.raises(NotImplementedError):
+        planner.beam_search(None, None, None, None, object(), 2, [0, 1], ['brightness', 'contrast'], 1, 1e-3)

@@ -9,8 +9,15 @@ if t:
     print('   host enqueue %.1f ms, graphs %s, mfma frac %.3f (%.1f TF/s), loss %.5f' % (
         t['host_enqueue_ms_per_step'], t.get('encoder_hipgraphs'), t['roofline']['frac'], t['roofline']['achieved'], t['loss']))
 r = d.get('roofline')
+if r and 'kernel' in r:
+    print('roofline: %s %.1f %s frac %.3f (%.4f ms/launch) traffic %s' % (r['kernel'], r['achieved'], r['unit'], r['frac'], r['avg_launch_ms'], r['traffic']))
+elif r:
+    print('roofline:', r)
+for k, v in (d.get('conv_kernels') or {}).items():
+    print('      %-22s %8.2f us  %6.1f TF/s  %s' % (k, v['ms'] * 1e3, v['TFLOPs'], v['kernel']))
+r = d.get('executor_roofline')
 if r:
-    print('roofline: %s %.0f GB/s frac %.3f (moved-bytes frac %.3f) traffic %s' % (r['kernel'], r['achieved'], r['frac'], r['fused_min_frac'], r['traffic']))
+    print('executor_roofline: %s %.0f GB/s moved, frac %.3f (credited %.3f) traffic %s' % (r['kernel'], r['achieved'], r['frac'], r['credited_frac'], r['traffic']))
 for name, leg in d.get('executor', {}).items():
     if not isinstance(leg, dict):
         print('executor', name, leg)
