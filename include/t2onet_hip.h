@@ -364,6 +364,26 @@ size_t t2o_conv1x1s2_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv1x1s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                              int N, int H, int W, int Ci, int Co, int accumulate, void* stream);
 
+/* ---- LSTM layers of the request encoder (models/lang_encoder.py:70-113: 2-layer bidirectional LSTM over packed, i.e.
+ * per-sample-length, sequences; nn.LSTM gate order i, f, g, o), one launch per time step for both directions (t2o_rnn.hip).
+ *   gi    (B, L, D*4H)  x W_ih^T for every step and direction (a library GEMM), no bias
+ *   whh_t (D, H, H, 4)  whh_t[d][k][j][g] = W_hh[d][g*H + j][k]  (forward);   whh (D, H, H, 4): whh[d][c][k][q] =
+ *                       W_hh[d][4*c + q][k]  (backward) -- both 16-byte-load repackings of nn.LSTM's (4H, H) weight;
+ *                       b_ih / b_hh (D, 4H) nullable
+ *   len   (B) int64     valid lengths on the DEVICE: a sample's state stops changing at its last token (direction 0) /
+ *                       starts from zero there (direction 1), outputs are zero at pads -- what pack_padded_sequence ->
+ *                       LSTM -> pad_packed_sequence computes, without the length sort and without host-side lengths
+ *   out   (B, L, D*H);  hnew, cnew (L, D, B, H): state after processing time t (final state: t = L-1 for direction 0,
+ *                       t = 0 for direction 1);  gates (L, D, B, 4H): post-activation gates, kept for the backward.
+ * Backward: dout (B, L, D*H), dhn / dcn (D, B, H) nullable -> dgates (L, D, B, 4H) = gradients of the gate pre-activations
+ * (weight, bias and input gradients are GEMMs / sums over them: host side); carry_h, dc (D, B, H): scratch.
+ * H % 64 == 0, H <= 256, D in {1, 2}. */
+int t2o_lstm_layer_fwd(const float* gi, const float* whh_t, const float* b_ih, const float* b_hh, const long long* len,
+                       float* out, float* hnew, float* cnew, float* gates, int B, int L, int H, int D, void* stream);
+int t2o_lstm_layer_bwd(const float* whh, const long long* len, const float* cnew, const float* gates, const float* dout,
+                       const float* dhn, const float* dcn, float* dgates, float* carry_h, float* dc,
+                       int B, int L, int H, int D, void* stream);
+
 /* Rewrites a captured, not yet instantiated hipGraph (hipGraph_t) in place: every memset node becomes a kernel node
  * doing the same fill, with the same dependencies and dependents; *replaced = how many.  Memset nodes were seen to
  * run out of order with neighbouring kernel nodes on replay (ROCm 7.2 / gfx950): t2onet_amd/graphs.py calls this on

@@ -90,6 +90,8 @@ SIGNATURES = {
     't2o_conv1x1s2_dgrad_acc_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_conv1x1s2_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv1x1s2_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    't2o_lstm_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

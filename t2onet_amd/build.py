@@ -19,7 +19,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libt2onet_hip.so')
-SOURCES = ['t2o_kernels.hip', 't2o_norm.hip', 't2o_conv.hip', 't2o_conv1x1.hip', 't2o_heads.hip', 't2o_optim.hip']
+SOURCES = ['t2o_kernels.hip', 't2o_norm.hip', 't2o_conv.hip', 't2o_conv1x1.hip', 't2o_rnn.hip', 't2o_heads.hip', 't2o_optim.hip']
 HEADERS = ['t2o_pixel_math.h', 't2o_block_programs.h', os.path.join(ROOT, 'include', 't2onet_hip.h')]
 # -ffp-contract=off: one rounding per arithmetic step, like the reference's eager fp32 ops
 FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17', '-fPIC', '-shared',

@@ -949,3 +949,82 @@ def stem_planar(x, weight, dy=None, want='fwd', into=None):
     _lib.check(lib.t2o_stem_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), need, N, Ho, Wo, Co, 1, 1 if into is not None else 0,
                                   _stream(x.device)), 't2o_stem_wgrad')
     return dw
+
+
+class _LstmLayerFn(torch.autograd.Function):
+    """One (bi)directional LSTM layer over zero-padded rows with per-sample lengths (t2o_lstm_layer_fwd / _bwd): the
+    input GEMM for all steps and directions, the step kernels, and -- backward -- the weight / bias / input gradients as
+    GEMMs over all steps.  Weights in nn.LSTM's layout; `dirs` tuples of (w_ih, w_hh, b_ih, b_hh) flattened."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, has_bias, *w):
+        _need_gpu(x, *w)
+        D = len(w) // (4 if has_bias else 2)
+        per = 4 if has_bias else 2
+        w_ih = [w[per * d] for d in range(D)]
+        w_hh = [w[per * d + 1] for d in range(D)]
+        B, L, E = x.shape
+        H = w_hh[0].shape[1]
+        dev = x.device
+        x = x.contiguous()
+        wih_cat = torch.cat(w_ih, 0) if D > 1 else w_ih[0]                     # (D*4H, E)
+        gi = torch.nn.functional.linear(x, wih_cat)                            # (B, L, D*4H)
+        whh_t = torch.stack([t.view(4, H, H).permute(2, 1, 0) for t in w_hh], 0).contiguous()     # (D, H(k), H(j), 4 gates)
+        b_ih = torch.stack([w[per * d + 2] for d in range(D)], 0).contiguous() if has_bias else None
+        b_hh = torch.stack([w[per * d + 3] for d in range(D)], 0).contiguous() if has_bias else None
+        out = torch.empty(B, L, D * H, dtype=torch.float32, device=dev)
+        hnew = torch.empty(L, D, B, H, dtype=torch.float32, device=dev)
+        cnew = torch.empty(L, D, B, H, dtype=torch.float32, device=dev)
+        gates = torch.empty(L, D, B, 4 * H, dtype=torch.float32, device=dev)
+        lengths = lengths.to(device=dev, dtype=torch.int64).contiguous()
+        rc = _lib.load().t2o_lstm_layer_fwd(_ptr(gi), _ptr(whh_t), _ptr(b_ih), _ptr(b_hh), _ptr(lengths), _ptr(out), _ptr(hnew),
+                                            _ptr(cnew), _ptr(gates), B, L, H, D, _stream(dev))
+        _lib.check(rc, 't2o_lstm_layer_fwd')
+        last = [L - 1, 0]
+        h_n = torch.stack([hnew[last[d], d] for d in range(D)], 0)
+        c_n = torch.stack([cnew[last[d], d] for d in range(D)], 0)
+        ctx.save_for_backward(x, lengths, wih_cat, hnew, cnew, gates, *w_hh)
+        ctx.meta = (B, L, E, H, D, has_bias)
+        return out, h_n, c_n
+
+    @staticmethod
+    def backward(ctx, dout, dhn, dcn):
+        x, lengths, wih_cat, hnew, cnew, gates = ctx.saved_tensors[:6]
+        w_hh = ctx.saved_tensors[6:]
+        B, L, E, H, D, has_bias = ctx.meta
+        dev = x.device
+        whh = torch.stack([t.view(H, 4, H).permute(0, 2, 1) for t in w_hh], 0).contiguous()       # (D, 4H/4, H(k), 4 columns)
+        dgates = torch.empty(L, D, B, 4 * H, dtype=torch.float32, device=dev)
+        carry = torch.empty(D, B, H, dtype=torch.float32, device=dev)
+        dc = torch.empty(D, B, H, dtype=torch.float32, device=dev)
+        dout = None if dout is None else dout.contiguous()
+        dhn = None if dhn is None else dhn.contiguous()
+        dcn = None if dcn is None else dcn.contiguous()
+        rc = _lib.load().t2o_lstm_layer_bwd(_ptr(whh), _ptr(lengths), _ptr(cnew), _ptr(gates), _ptr(dout), _ptr(dhn), _ptr(dcn),
+                                            _ptr(dgates), _ptr(carry), _ptr(dc), B, L, H, D, _stream(dev))
+        _lib.check(rc, 't2o_lstm_layer_bwd')
+        dgi = dgates.permute(2, 0, 1, 3).reshape(B * L, D * 4 * H)             # rows (b, t), columns (d, gate): gi's layout
+        dx = (dgi @ wih_cat).view(B, L, E) if ctx.needs_input_grad[0] else None
+        dwih = dgi.t() @ x.reshape(B * L, E)                                   # (D*4H, E)
+        dbias = dgi.sum(0) if has_bias else None
+        grads = []
+        for d in range(D):
+            # dW_hh = sum_t dgates[t]^T h_prev(t): h_prev of time t is the state after t-1 (direction 0) / t+1 (direction 1)
+            if L > 1:
+                dg = (dgates[1:, d] if d == 0 else dgates[:-1, d]).reshape((L - 1) * B, 4 * H)
+                hp = (hnew[:-1, d] if d == 0 else hnew[1:, d]).reshape((L - 1) * B, H)
+                dwhh = dg.t() @ hp
+            else:
+                dwhh = torch.zeros_like(w_hh[d])
+            grads += [dwih[d * 4 * H:(d + 1) * 4 * H], dwhh]
+            if has_bias:
+                grads += [dbias[d * 4 * H:(d + 1) * 4 * H], dbias[d * 4 * H:(d + 1) * 4 * H]]
+        return (dx, None, None) + tuple(grads)
+
+
+def lstm_layer(x, lengths, dirs):
+    """x (B,L,E) zero-padded rows, lengths (B) on any device, dirs = [(w_ih, w_hh, b_ih, b_hh) or (w_ih, w_hh)] per
+    direction (nn.LSTM's parameters of one layer).  Returns (out (B,L,D*H) zero at pads, h_n (D,B,H), c_n (D,B,H))."""
+    has_bias = len(dirs[0]) == 4
+    flat = [t for d in dirs for t in d]
+    return _LstmLayerFn.apply(x, lengths, has_bias, *flat)

@@ -166,7 +166,6 @@ class GraphedEpisodeStep:
         self.reinforce_sample = reinforce_sample
         self.longest = int(longest)
         self.s_x = x.detach().clone()
-        self.s_len = lengths.detach().to(dev).clone()
         self.s_img = img.detach().clone()
         self.s_target = target.detach().clone()
         self.memsets_replaced = 0
@@ -198,15 +197,15 @@ class GraphedEpisodeStep:
         if tr._trunk is not None:
             tr._trunk.weights_changed()                        # the weights were updated since the last step: transform them again
         tr.grads.zero()
-        _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, self.s_len, self.longest)
+        lengths = (self.s_x != tr.opt.null_id).sum(1)         # on the device, inside the graph: no host-side lengths to copy
+        _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, lengths, self.longest)
         loss = T.l1_loss(select_end_images(imgs, ops, tr.opt.end_id), self.s_target)
         loss.backward()
         return loss.detach()
 
-    def run(self, x, lengths, img, target):
+    def run(self, x, img, target):
         """One step for a batch whose longest request has this instance's length; returns the loss (a fresh tensor)."""
         self.s_x.copy_(x)
-        self.s_len.copy_(lengths, non_blocking=True)
         self.s_img.copy_(img)
         self.s_target.copy_(target)
         self.graph.replay()

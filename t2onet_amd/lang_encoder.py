@@ -10,6 +10,12 @@ import torch.nn.functional as F
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 
+import os
+
+# T2O_OWN_LSTM=0: the library's packed sequence call (MIOpen) on the GPU too (A/B timing, and what the tests compare with)
+_OWN_LSTM = os.environ.get('T2O_OWN_LSTM', '1') != '0'
+
+
 class Embedding(nn.Embedding):
     """Word table whose first `num_spec` rows (NULL/START/END/UNK) always train; with
     `fix_embedding` the remaining (GloVe) rows receive no gradient (lang_encoder.py:7-31)."""
@@ -61,6 +67,30 @@ class RNNEncoder(nn.Module):
             outputs, state = self.rnn(embedded)
             return outputs, state, embedded
         dev = input_labels.device
+        if dev.type == 'cuda' and _OWN_LSTM and isinstance(self.rnn, nn.LSTM) and self.rnn.proj_size == 0 \
+                and self.rnn.batch_first and self.rnn.hidden_size % 64 == 0 and self.rnn.hidden_size <= 256 and input_labels.shape[0] > 0:
+            # GPU: this library's LSTM step kernels (functional.lstm_layer): one input GEMM + one launch per time step
+            # and layer for both directions, lengths stay on the device (no sort, no packing), static shapes for a
+            # given `longest` (hipGraph-capturable).  The library's sequence call is ~450 launches per train step.
+            dev_lengths = lengths if (lengths is not None and lengths.device == dev) else (input_labels != self.pad_id).sum(dim=1)
+            if longest is None:
+                longest = int(lengths.max()) if lengths is not None else int(dev_lengths.max())
+            embedded = self.input_dropout(self.embedding(input_labels[:, :longest]))
+            from . import functional as T
+            rnn, D = self.rnn, self.num_dirs
+            layer_in, hs, cs = embedded, [], []
+            for layer in range(rnn.num_layers):
+                dirs = []
+                for d in range(D):
+                    sfx = '_l%d%s' % (layer, '_reverse' if d else '')
+                    names = ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh') if rnn.bias else ('weight_ih', 'weight_hh')
+                    dirs.append(tuple(getattr(rnn, n + sfx) for n in names))
+                layer_in, h, c = T.lstm_layer(layer_in, dev_lengths, dirs)
+                hs.append(h)
+                cs.append(c)
+                if layer + 1 < rnn.num_layers and rnn.dropout > 0 and self.training:
+                    layer_in = F.dropout(layer_in, rnn.dropout, True)
+            return layer_in, (torch.cat(hs, 0), torch.cat(cs, 0)), embedded
         if dev.type == 'cuda' and longest is not None and isinstance(self.rnn, nn.LSTM) and self.rnn.proj_size == 0 and self.rnn.batch_first:
             # `longest` given (a hipGraph capture): the same arithmetic as the packed library call, unrolled with
             # per-sample masks -- static shapes, no host-side lengths.  (The library's sequence entry point, MIOpen,

@@ -203,7 +203,7 @@ class Trainer:
             self._step_graphs[key] = sg
             if self._trunk is not None:
                 self._trunk.weights_changed()              # (the capture's transformed weights belong to the graph's pool)
-        loss = sg.run(x, lengths, img_x, target)
+        loss = sg.run(x, img_x, target)
         self._update()
         return loss
 
