@@ -76,3 +76,32 @@ def test_resize_restates_cv2_inter_linear_properties(tmp_path):
     np.testing.assert_array_equal((x * 255).round().numpy().astype(np.uint8), data.resize_linear_u8(img, 128, 128).transpose(2, 0, 1))
     y = data.load_image_short_side(str(path), 100)
     assert min(y.shape[1:]) == 100 and tuple(y.shape[1:]) == (100, int(np.round(W * 100 / H)))
+
+
+def test_fivek_datasets_on_a_generated_tree(tmp_path):
+    """FiveKAct.__getitem__ / FiveK.__getitem__ (datasets/FiveKdataset.py:42-52, :118-135) on a tree written here in the
+    reference's layout: JPEG decode + resize, planner records, the validation split at full resolution (short side 600)."""
+    from t2onet_amd import data
+    from tests import fivek_tree
+    img_dir, anno_dir, act_dir, _ = fivek_tree.write_tree(str(tmp_path), n_train=4, n_val=2)
+    ds = data.FiveKAct(img_dir, anno_dir, act_dir, 'train', 1, 64)
+    assert len(ds) == 4
+    for i in range(4):
+        img_x, imgs, x, ops, params, req = ds[i]
+        assert img_x.shape == (3, 64, 64) and imgs.shape == (6, 3, 64, 64) and x.shape == (17,) and req == 'make it %d' % i
+        n = int((ops > 2).sum())
+        assert ops[0] == 1 and ops[n + 1] == 2 and (ops[n + 2:] == 0).all() and 1 <= n <= 5
+        assert float(imgs[n:5].abs().sum()) == 0.0 and float(imgs[5].sum()) > 0          # unused steps stay zero, the target is last
+        assert float(np.abs(params[n:]).sum()) == 0.0 and np.abs(params[:n]).max() <= 5.0
+        import json
+        rec = json.load(open(os.path.join(act_dir, 'train%d' % i, '%05d.json' % i)))
+        np.testing.assert_array_equal(ops, data.parse_action_record(rec)[0])
+        np.testing.assert_array_equal(imgs[0].numpy(), data.load_image(os.path.join(act_dir, 'train%d' % i, 'edit0.jpg'), 64).numpy())
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))
+    assert batch[1].shape == (2, 6, 3, 64, 64) and batch[3].shape == (2, 7) and batch[4].shape == (2, 5, 24)
+    val = data.FiveK(img_dir, anno_dir, 'val', 1)
+    img_x, img_y, x, req = val[1]
+    assert min(img_x.shape[1:]) == 600 and img_x.shape == img_y.shape and x.shape == (17,)
+    assert img_x.shape[1:] == (600, 900)                                                  # 96 x 144 source
+    tr = data.FiveK(img_dir, anno_dir, 'train', 1, train_img_size=32)
+    assert tr[0][0].shape == (3, 32, 32)

@@ -163,6 +163,62 @@ def test_train_cli_runs_and_checkpoints(tmp_path):
         train_cli.main(['--batch_size', '4', '--num_iters', '1', '--run_dir', str(tmp_path)])
 
 
+def test_train_cli_on_a_fivek_layout_tree(tmp_path):
+    """The reference-shaped loop on REAL-data plumbing (no --synthetic): a FiveK-layout tree written here (JPEGs, planner
+    records, annotation JSONs, a GloVe table), FiveKAct for training, the FiveK validation split at full resolution
+    (short side 600, one image per batch: train_seq2seqL1.py:155-156), checkpoint + checkpoint_best."""
+    from t2onet_amd import train_cli
+    from tests import fivek_tree
+    img_dir, anno_dir, act_dir, glove = fivek_tree.write_tree(str(tmp_path / 'data'), n_train=8, n_val=2)
+    avg = train_cli.main(['--img_dir', img_dir, '--anno_dir', anno_dir, '--act_dir', act_dir, '--word2vec', glove,
+                          '--batch_size', '4', '--img_size', '64', '--num_iters', '4', '--print_every', '2',
+                          '--checkpoint_every', '4', '--run_dir', str(tmp_path / 'run'), '--num_workers', '0'])
+    st = avg['stats']
+    assert st['train_iter'] == [4] and len(st['val_dist']) == 1 and 0 < st['best_val_dist'] < 1
+    sd = torch.load(str(tmp_path / 'run' / 'seq2seqL1_model' / 'checkpoint_best' / 'model.pth'))
+    assert len(sd) == 199
+    # the GloVe rows are frozen (fix_input_embedding=1, lang_encoder.py:22-31): still the table's values after 4 steps
+    import numpy as np
+    table = torch.from_numpy(np.load(glove))
+    assert torch.equal(sd['lang_encoder.embedding.weight'][4:].cpu(), table)
+
+
+def test_one_rank_nccl_group_gives_the_ungrouped_run(tmp_path):
+    """The N > 1 code path that can run on one GPU: a 1-rank `nccl` (RCCL) process group with the encoder hipGraphs ON.
+    Three episode steps (arg-max operators, no dropout) inside the group must give bit-identical losses to the same
+    steps without a group: the flat all-reduce is skipped at world size 1, and neither the communicator's watchdog
+    thread nor its stream may disturb the captured graphs."""
+    import copy
+    import torch.distributed as dist
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    opt = t2onet_amd.default_options(input_dropout_p=0.0, dropout_p=0.0)
+    torch.manual_seed(51)
+    base = Actor(opt).to(dev).train()
+    base.use_channels_last()
+    Bn = 8
+    img = synth.images(Bn, 256, 256, 111).to(dev)
+    tgt = synth.images(Bn, 256, 256, 112).to(dev)
+    x = synth.requests(Bn, 17, 113).to(dev)
+    lengths = (x != 0).sum(1).cpu()
+
+    def run():
+        tr = Trainer(copy.deepcopy(base), opt, graph_encoder=True)
+        return [float(tr.episode_step(x, img, tgt, reinforce_sample=0, lengths=lengths)) for _ in range(3)]
+    plain = run()
+    dist.init_process_group('nccl', init_method='file://%s' % (tmp_path / 'rdv'), rank=0, world_size=1, device_id=dev)
+    try:
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                                   # the communicator exists and works
+        assert float(t.sum()) == 4.0
+        grouped = run()
+    finally:
+        dist.destroy_process_group()
+    assert grouped == plain, (grouped, plain)
+
+
 def test_episode_with_local_edit_masks():
     """mask_dict path (actor.py:78-98, :238-239): samples with a mask for the chosen operator are
     edited only inside it; others globally.  Checked against the unmasked run and the blend identity."""

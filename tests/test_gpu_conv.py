@@ -113,6 +113,35 @@ def test_encoder_layer_shapes_at_batch_64_match_the_library(layer):
     assert torch.equal(dw, T.conv3x3_wgrad(x, dy))
 
 
+@pytest.mark.parametrize('layer', [(64, 64), (128, 32), (256, 16), (512, 8)])
+def test_encoder_layer_shapes_at_batch_64_vs_fp64_samples(layer):
+    """The same bs=64 launches against fp64 on the CPU, where that costs seconds: forward and data gradient are
+    per-sample independent -- samples 0 and 63 of the batch (first / last tiles, a tile that starts mid-image) against
+    conv2d in fp64; the weight gradient of the 512-channel 8 x 8 stage (a full reduction over the batch) entirely."""
+    import t2onet_amd.functional as T
+    c, h = layer
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(841 + c)
+    x = torch.rand(64, c, h, h, generator=g) * 2 - 1
+    w = (torch.rand(c, c, 3, 3, generator=g) * 2 - 1) * 0.05
+    dy = torch.rand(64, c, h, h, generator=g) * 2 - 1
+    xg, wg, dg = (t.to(dev).contiguous(memory_format=torch.channels_last) for t in (x, w, dy))
+    y = T.conv3x3_forward(xg, wg)
+    dx = T.conv3x3_dgrad(dg, wg)
+    for n in (0, 63):
+        x64 = x[n:n + 1].double().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(x64, w.double(), None, 1, 1)
+        ref.backward(dy[n:n + 1].double())
+        scale = float(ref.abs().max())
+        np.testing.assert_allclose(y[n:n + 1].cpu().numpy(), ref.detach().float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+        gscale = float(x64.grad.abs().max())
+        np.testing.assert_allclose(dx[n:n + 1].cpu().numpy(), x64.grad.float().numpy(), rtol=1e-5, atol=1e-5 * gscale)
+    if c == 512:
+        dw = T.conv3x3_wgrad(xg, dg)
+        ref = _ref_wgrad(x, dy, c, c)
+        np.testing.assert_allclose(dw.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+
+
 # (N, Ci, Co, Ho, Wo) of the stride-2 layers: dx is (N, Ci, 2Ho, 2Wo)
 S2_SHAPES = [(2, 64, 64, 8, 8), (3, 64, 128, 5, 16), (1, 128, 64, 3, 24), (2, 64, 32, 1, 8), (2, 128, 256, 20, 8), (1, 64, 64, 2, 136),
              (2, 3, 64, 16, 16), (3, 3, 64, 9, 37), (1, 3, 32, 1, 1), (2, 3, 64, 8, 64)]      # (the last four: the 3-channel stem)

@@ -99,3 +99,33 @@ def test_supervised_step(gold, sd, mode):
     gn = np.array([0.0 if leaf[n].grad is None else leaf[n].grad.double().norm().item() for n in names])
     # (entries that are pure rounding noise, e.g. weights feeding a train-mode BatchNorm, are below atol)
     np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-6 * gold[p + 'grad_norm'].max())
+
+
+def test_oracle_reproduces_the_reference_evaluation_loop(golden_dir):
+    """extra2.npz: the reference's test() (experiments/t2onet/test_seq2seqL1.py:28-95) over three synthetic batches,
+    restated with the oracle's episode_forward / select_end_images / l1_loss (eval mode, arg-max operators)."""
+    extra2 = np.load(os.path.join(golden_dir, 'extra2.npz'))
+    sd2 = synth.fill_state_dict(cpu_ref.actor_state_skeleton(OPT), seed=7)
+    # the fixture's batch-norm adjustment (tools/gen_golden.py tweak_batchnorms)
+    for k in list(sd2.keys()):
+        if k.startswith('vis_encoder.') and k.endswith('.weight') and sd2[k].dim() == 1 and (k.replace('.weight', '.running_mean') in sd2):
+            w = sd2[k]
+            sd2[k] = 0.5 + 0.5 * (w - w.min()) / (w.max() - w.min() + 1e-12)
+            sd2[k.replace('.weight', '.bias')] = sd2[k.replace('.weight', '.bias')] + 3.0
+    w = sd2['bn1.weight']
+    sd2['bn1.weight'] = 0.5 + 0.5 * (w - w.min()) / (w.max() - w.min() + 1e-12)
+    sd2['bn1.bias'] = sd2['bn1.bias'] + 4.0
+    sd2['decoder.vis_linear.bias'] = sd2['decoder.vis_linear.bias'] + 16.0
+    for k in list(sd2.keys()):
+        if k.startswith('executor.') and k.endswith('.fc1.bias'):
+            sd2[k] = sd2[k] + 3.0
+    avg_init = avg = 0.0
+    for k in range(3):
+        img_x, img_y, x = synth.images(2, 48, 64, 151 + k), synth.images(2, 48, 64, 161 + k), synth.requests(2, L, 171 + k)
+        with torch.no_grad():
+            r = cpu_ref.episode_forward(sd2, x, img_x, OPT, reinforce_sample=0, training=False)
+            pred = cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], OPT.end_id)
+        avg_init += (cpu_ref.l1_loss(img_x, img_y).item() - avg_init) / (k + 1)
+        avg += (cpu_ref.l1_loss(pred, img_y).item() - avg) / (k + 1)
+    assert abs(avg_init - float(extra2['eval_avg_init_dist'])) < 1e-6
+    assert abs(avg - float(extra2['eval_avg_dist'])) < 1e-5
