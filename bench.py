@@ -224,6 +224,8 @@ class FusedRunner(SequenceRunner):
         import torch
         super().__init__(ops, B, H, W, device)
         assert ops[-1] == 6 and 6 not in ops[:-1] and len(ops) - 1 <= 8, 'bench sequences end with one sharpness'
+        rc = self.lib.t2o_fused_sequence_prepare(self.c_ops, self.K)      # run-time specialisation of lists without an ahead-of-time kernel
+        self.specialised = rc == 0
         self.nbuf = self.lib.t2o_fused_sequence_buffers(self.c_ops, self.K)
         self.seg = torch.empty(max(self.nbuf, 1), B, 3, H, W, device=device)
         self.out = torch.empty(B, 3, H, W, device=device)
@@ -342,7 +344,10 @@ def executor_leg(ctx, ops, B, H, W, steps, warmup, with_api=False):
 
     mat = summary(*measure(SequenceRunner(ops, B, H, W, device)))
     torch.cuda.empty_cache()
-    fus = summary(*measure(FusedRunner(ops, B, H, W, device)))
+    fused_runner = FusedRunner(ops, B, H, W, device)
+    fus = summary(*measure(fused_runner))
+    fus['compile_time_specialised'] = bool(fused_runner.specialised)
+    del fused_runner
     torch.cuda.empty_cache()
     res = {'workload': 'bs=%d/GPU %dx%d fp32, executor ops %s forward + L1 + backward to all parameters and the image'
                        % (B, H, W, list(ops)),

@@ -124,6 +124,20 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
                            float* gimg, float* gparams, const float* seg_bufs, float* gbuf,
                            void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 
+/* ---- run-time specialisation of the fused chain kernels for an arbitrary operator list (t2o_jit.hip).
+ * The fastest kernels behind t2o_fused_sequence_fwd/bwd take the operator list as a compile-time constant; ahead of time
+ * only BASELINE.json's two lists are instantiated.  t2o_fused_sequence_prepare(ops, K) compiles (hipRTC, from the headers
+ * embedded in this library, same flags as the ahead-of-time build) and loads the kernels for every per-pixel segment of
+ * this list that has none; later t2o_fused_sequence_* calls with the same list pick them up.  Results are bit-identical
+ * to the run-time-loop kernels (same arithmetic per pixel; parameter gradients up to summation order).  Blocking (seconds
+ * per new list), HOST side: call it outside any stream capture.  T2O_EUNSUPPORTED when libhiprtc is not on the machine
+ * (the sequence calls then keep using the run-time-loop kernels).  t2o_jit_set_cache_dir: directory where compiled code
+ * objects are kept (keyed by source digest + operator list), NULL/"" = no disk cache.  Executor.execute permits any order
+ * (executors/executor.py:33-55); the planner enumerates them (utils/beam_search.py:218-231). */
+int t2o_fused_sequence_prepare(const int* ops, int K);
+int t2o_jit_set_cache_dir(const char* dir);
+int t2o_jit_specialisations(void);      /* operator lists specialised so far in this process */
+
 /* ---- planner candidate sweep (utils/beam_search.py:65-91: one executor call + .item() per
  * evaluated parameter): loss[c] = mean |clamp(process(img, params[c])) - target| for C candidate
  * parameter rows of ONE per-pixel operator (0,1,2,3,5,7) against ONE image pair (3,H,W), in a

@@ -90,6 +90,9 @@ SIGNATURES = {
     't2o_conv1x1s2_dgrad_acc_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_conv1x1s2_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv1x1s2_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_fused_sequence_prepare': (_I, [_P, _I]),
+    't2o_jit_set_cache_dir': (_I, [ctypes.c_char_p]),
+    't2o_jit_specialisations': (_I, []),
     't2o_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     't2o_lstm_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }
@@ -126,6 +129,12 @@ def load():
         fn.argtypes = args
     if lib.t2o_abi_version() != ABI_VERSION or lib.t2o_source_digest().decode() != want:
         raise RuntimeError('libt2onet_hip.so ABI version / source digest mismatch after load')
+    jit_dir = os.environ.get('T2O_JIT_CACHE', os.path.join(_HERE, 'lib', 'jit'))      # code objects of run-time specialised chains
+    try:
+        os.makedirs(jit_dir, exist_ok=True)
+        lib.t2o_jit_set_cache_dir(jit_dir.encode())
+    except OSError:
+        pass
     _lib = lib
     return lib
 

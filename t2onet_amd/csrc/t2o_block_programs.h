@@ -10,8 +10,10 @@
 // [0,1]; a sample is 3 planes of H*W floats.  Parameters are rows of
 // `param_stride` floats per sample.  Masks are (B,1,H,W) or (B,3,H,W).
 #pragma once
+#ifndef __HIPCC_RTC__      // (hipRTC: no system headers)
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #include "t2o_pixel_math.h"
 
@@ -1005,6 +1007,7 @@ struct SsimArgs {
 
 T2O_HD int ssim_lds_floats() { return 2 * kSsimIn * kSsimInStride + 5 * kSsimIn * kSsimHStride; }
 
+#ifndef __HIPCC_RTC__      // (host-side set-up)
 inline void ssim_window(float* g) {                     // utils/ssim/__init__.py:7-10
   float s = 0.0f;
   for (int i = 0; i < kSsimWin; ++i) {
@@ -1013,6 +1016,7 @@ inline void ssim_window(float* g) {                     // utils/ssim/__init__.p
   }
   for (int i = 0; i < kSsimWin; ++i) g[i] /= s;
 }
+#endif
 
 // phase 1: load the two 42x42 input windows (zero outside the image)
 T2O_HD void ssim_phase_load(const SsimArgs& s, int plane, int tile, int tid, float* lds) {

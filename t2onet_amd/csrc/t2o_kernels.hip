@@ -13,6 +13,8 @@
 
 #include "../../include/t2onet_hip.h"
 #include "t2o_block_programs.h"
+#include "t2o_chain_kernels.h"
+#include "t2o_jit.h"
 
 using namespace t2o;
 
@@ -28,72 +30,6 @@ int fail(int code, const char* msg) {
 }  // namespace
 namespace t2o { int set_error(int code, const char* msg) { return fail(code, msg); } }   // for t2o_norm.hip
 namespace {
-
-// ------------------------------------------------------------------ device helpers
-// Sum over the 64 lanes, returned in every lane.  Pure VALU: an inclusive scan inside each 16-lane
-// row by DPP row shifts (1, 2, 4, 8), row_bcast:15 / row_bcast:31 to fold the four rows, then a
-// broadcast of lane 63 -- 6 DPP adds instead of 6 LDS-crossbar shuffles (ds_bpermute).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_shift_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
-  return v + __builtin_bit_cast(float, moved);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v = dpp_shift_add<0x111, 0xF>(v);   // row_shr:1
-  v = dpp_shift_add<0x112, 0xF>(v);   // row_shr:2
-  v = dpp_shift_add<0x114, 0xF>(v);   // row_shr:4
-  v = dpp_shift_add<0x118, 0xF>(v);   // row_shr:8   -> lane 15 of every row holds the row sum
-  v = dpp_shift_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
-  v = dpp_shift_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2).  Give every XCD a
-// CONTIGUOUS range of logical work items so neighbouring tiles (shared halo rows) and
-// consecutive chunks of one image meet in the same L2.  Bijective for any total.
-__device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned total) {
-  const unsigned q = total / 8, r = total % 8, xcd = lin % 8, slot = lin / 8;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-// (sample, block-in-sample) of this workgroup, forced into scalar registers: the integer
-// division is lowered through the vector ALU, and without readfirstlane every per-sample
-// parameter load would become a per-lane vector load holding 24+ VGPRs.
-__device__ __forceinline__ void wg_coords(int per_sample, int& b, int& blk) {
-  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
-  b = __builtin_amdgcn_readfirstlane((int)(w / (unsigned)per_sample));
-  blk = __builtin_amdgcn_readfirstlane((int)(w % (unsigned)per_sample));
-}
-
-__device__ __forceinline__ int nred_of(int op) { return op == OP_COLOR ? 24 : op == OP_TONE ? 8 : 1; }
-
-// red[0..n) of every thread -> partials row of this block (fixed order => reproducible)
-__device__ __forceinline__ void block_reduce_store(const float (&red)[kRedSlots], int n, float* dst) {
-  __shared__ float sred[kThreads / 64][kRedSlots];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < kRedSlots; ++i) {
-    if (i < n) {
-      const float s = wave_sum(red[i]);
-      if (lane == 0) sred[wave][i] = s;
-    }
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < n)
-    dst[threadIdx.x] = ((sred[0][threadIdx.x] + sred[1][threadIdx.x]) + sred[2][threadIdx.x]) + sred[3][threadIdx.x];
-}
-
-__device__ __forceinline__ void block_reduce_store1(float v, float* dst) {
-  __shared__ float s1[kThreads / 64];
-  const float s = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) dst[0] = ((s1[0] + s1[1]) + s1[2]) + s1[3];
-}
 
 // ------------------------------------------------------------------ pointwise kernels
 // grid: 1-D, B * nblk workgroups (XCD-remapped); each handles `iters` x 256 pixel groups of one sample.
@@ -350,35 +286,6 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd(OpArgs a, int tiles) {
   block_reduce_store1(red0, a.partials + ((size_t)b * a.nblk_max + tile) * kRedSlots);
 }
 
-// ------------------------------------------------------------------ fused pointwise chain
-// raw parameter sums: quad (4-lane) DPP reduction, then one owner lane adds into its private LDS cell
-struct LdsAcc {
-  float* acc;
-  // N raw sums of this thread: 4-lane (quad) DPP reduction, then the quad's first lane adds into
-  // the quad's private LDS cells with plain read-add-write (sole owner: no atomics, fixed order).
-  // Measured alternatives on MI355X (5-operator chain, 126 us with this scheme): one cell per THREAD
-  // with ds_add_f32 -- 845 us (LDS float atomics cost ~190 cycles per wave instruction even with
-  // conflict-free addresses); one cell per thread with read-add-write -- 221 us (4x the LDS cells to
-  // zero and reduce per workgroup, 3 workgroups per CU instead of 5).
-  template <int N>
-  __device__ __forceinline__ void add_n(int slot0, float (&v)[N]) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      v[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j]), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-      v[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[j]), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-      asm volatile("" : "+v"(v[j]));   // finish the sum HERE (one v_add_f32_dpp), not as a dpp move + an add inside the owner branch
-    }
-    if ((threadIdx.x & 3) == 0) {
-      float* cell = acc + slot0 * kAccStride + (threadIdx.x >> 2);
-      float old[N];
-#pragma unroll
-      for (int j = 0; j < N; ++j) old[j] = cell[j * kAccStride];
-#pragma unroll
-      for (int j = 0; j < N; ++j) cell[j * kAccStride] = old[j] + v[j];
-    }
-  }
-};
-
 template <int V, bool L1>
 __global__ __launch_bounds__(kThreads) void k_chain_fwd(ChainArgs a) {
   __shared__ float tab[kMaxChain * kTabStride];
@@ -391,15 +298,7 @@ __global__ __launch_bounds__(kThreads) void k_chain_fwd(ChainArgs a) {
 }
 
 template <int V, bool L1, class SEQ>
-__global__ __launch_bounds__(kThreads) void k_chain_fwd_static(ChainArgs a) {
-  __shared__ float tab[kMaxChain * kTabStride];
-  int b, blk;
-  wg_coords(a.nblk, b, blk);
-  if ((int)threadIdx.x < SEQ::K) chain_build_table(a, b, threadIdx.x, tab);
-  __syncthreads();
-  const float l1 = chain_fwd_thread_static<V, L1, SEQ>(a, b, blk, threadIdx.x, tab);
-  if (L1) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk);
-}
+__global__ __launch_bounds__(kThreads) void k_chain_fwd_static(ChainArgs a) { chain_fwd_static_body<V, L1, SEQ>(a); }
 
 template <int V, bool L1>
 __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
@@ -425,31 +324,10 @@ __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
     a.partials[((size_t)b * a.nblk + blk) * S + s] = chain_slot_value(a, s, bsum);
 }
 
-// the backward for an operator list fixed at compile time (chain_bwd_thread_static): no save area in LDS, no
-// per-pixel flush.  One instantiation per entry of the dispatch in fused_chain_launch_bwd.
+// the backward for an operator list fixed at compile time: body in t2o_chain_kernels.h (shared with the hipRTC path,
+// t2o_fused_sequence_prepare).  One instantiation per entry of the dispatch in fused_chain_launch_bwd.
 template <bool L1, class SEQ, bool SV_LDS, int MINW>
-__global__ __launch_bounds__(kThreads, MINW) void k_chain_bwd_static(ChainArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // accumulator cells: NB rows of kAccStride [+ save area]
-  __shared__ float tab[kMaxChain * kTabStride];
-  __shared__ float bsum[kMaxChainBins];
-  int b, blk;
-  wg_coords(a.nblk, b, blk);
-  const int S = a.slot_off[kMaxChain], NB = a.bin_off[kMaxChain];
-  for (int i = threadIdx.x; i < NB * kAccStride; i += kThreads) lds[i] = 0.0f;
-  if ((int)threadIdx.x < SEQ::K) chain_build_table(a, b, threadIdx.x, tab);
-  __syncthreads();
-  LdsAcc acc{lds};
-  chain_bwd_thread_static<L1, SEQ, SV_LDS>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
-  __syncthreads();
-  for (int s = threadIdx.x; s < NB; s += kThreads) {
-    float sum = 0.0f;
-    for (int q = 0; q < kThreads / 4; ++q) sum += lds[s * kAccStride + q];
-    bsum[s] = sum;
-  }
-  __syncthreads();
-  for (int s = threadIdx.x; s < S; s += kThreads)
-    a.partials[((size_t)b * a.nblk + blk) * S + s] = chain_slot_value(a, s, bsum);
-}
+__global__ __launch_bounds__(kThreads, MINW) void k_chain_bwd_static(ChainArgs a) { chain_bwd_static_body<L1, SEQ, SV_LDS>(a); }
 
 // one workgroup per sample: per-block sums -> raw sums -> parameter gradients of every chain operator.
 // 8 threads per slot walk the block rows (stride 8), then a fixed-order LDS combine.
@@ -1197,14 +1075,19 @@ static int chain_static_variant() {
   static const int v = env_int("T2O_CHAIN_STATIC", 1);                   // 0: the run-time loop kernel for every list (A/B runs)
   return v;
 }
+static bool chain_has_aot(const ChainArgs& a) { return chain_is<SeqCfg2>(a) || chain_is<SeqCfg5>(a); }
 static bool chain_has_static_bwd(const ChainArgs& a, int vec) {
-  return vec == 1 && chain_static_variant() && (chain_is<SeqCfg2>(a) || chain_is<SeqCfg5>(a));
+  if (vec != 1 || !chain_static_variant()) return false;
+  t2o::JitChain j;
+  return chain_has_aot(a) || t2o::jit_lookup(a.ops, a.K, &j);
 }
 
 static int fused_chain_launch_fwd(ChainArgs& a, int vec, bool l1, hipStream_t st) {
   if (chain_static_variant()) {
     if (chain_is<SeqCfg2>(a)) { launch_static_fwd<SeqCfg2>(a, vec, l1, st); return 0; }
     if (chain_is<SeqCfg5>(a)) { launch_static_fwd<SeqCfg5>(a, vec, l1, st); return 0; }
+    t2o::JitChain j;                       // an operator list specialised at run time (t2o_fused_sequence_prepare)
+    if (t2o::jit_lookup(a.ops, a.K, &j)) return t2o::jit_launch(j.fwd[vec == 2 ? 1 : 0][l1 ? 1 : 0], a, (unsigned)a.B * a.nblk, 0, st);
   }
   const unsigned grid = (unsigned)a.B * a.nblk;
   if (vec == 2) { if (l1) k_chain_fwd<2, true><<<grid, kThreads, 0, st>>>(a); else k_chain_fwd<2, false><<<grid, kThreads, 0, st>>>(a); }
@@ -1217,6 +1100,9 @@ static int fused_chain_launch_bwd(ChainArgs& a, int vec, bool l1, hipStream_t st
   if (vec == 1 && use_static) {
     if (chain_is<SeqCfg2>(a)) { launch_static_bwd_variant<SeqCfg2>(a, use_static, l1, st); return 0; }
     if (chain_is<SeqCfg5>(a)) { launch_static_bwd_variant<SeqCfg5>(a, use_static, l1, st); return 0; }
+    t2o::JitChain j;
+    if (t2o::jit_lookup(a.ops, a.K, &j))
+      return t2o::jit_launch(j.bwd[l1 ? 1 : 0], a, (unsigned)a.B * a.nblk, sizeof(float) * (size_t)a.bin_off[kMaxChain] * kAccStride, st);
   }
   const unsigned grid = (unsigned)a.B * a.nblk;
   const size_t lds = sizeof(float) * ((size_t)a.bin_off[kMaxChain] * kAccStride +
@@ -1226,6 +1112,23 @@ static int fused_chain_launch_bwd(ChainArgs& a, int vec, bool l1, hipStream_t st
   return 0;
 }
 
+
+int t2o_fused_sequence_prepare(const int* ops, int K) {
+  if (!ops || K < 0) return fail(T2O_EINVAL, "fused_sequence_prepare: null pointer");
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  if (ns < 0) return fail(T2O_EUNSUPPORTED, "operator index not supported, or more than 64 segments");
+  for (int s = 0; s < ns; ++s) {
+    if (seg[s].sharp || seg[s].n <= 0) continue;
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    chain_fill(a, seg[s], 1, 4, 4, 1, 1);                // (only the operator list matters here)
+    if (chain_has_aot(a)) continue;                      // compiled ahead of time
+    const int rc = t2o::jit_prepare(a.ops, a.K);
+    if (rc != T2O_OK) return rc;
+  }
+  return T2O_OK;
+}
 
 int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float* params, const float* target,
                            float* out, float* loss, float* seg_bufs, void* workspace, size_t workspace_bytes, int B,

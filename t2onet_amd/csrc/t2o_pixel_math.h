@@ -21,7 +21,9 @@
 // PyTorch's conventions (clamp passes the gradient on [lo,hi] inclusive;
 // max/min over channels route to one index).
 #pragma once
+#ifndef __HIPCC_RTC__      // (hipRTC: no system headers; the device math functions and size_t are built in)
 #include <math.h>
+#endif
 
 #if defined(__HIPCC__)
 #define T2O_HD __host__ __device__ __forceinline__

@@ -742,6 +742,29 @@ def sequence_l1(img, ops, params, target):
     return _SequenceFn.apply(img, params, target, [int(o) for o in ops])
 
 
+_prepared_chains = {}
+_CHAIN_JIT = os.environ.get('T2O_CHAIN_JIT', '1') != '0'
+
+
+def prepare_fused_sequence(ops):
+    """Run-time specialisation of the fused chain kernels for this operator list (t2o_fused_sequence_prepare: hipRTC,
+    ~1 s per new list, code objects cached on disk).  Returns True when the list now runs on compile-time-specialised
+    kernels (ahead-of-time or run-time compiled), False when the machine has no hipRTC (run-time-loop kernels stay)."""
+    key = tuple(int(o) for o in ops)
+    got = _prepared_chains.get(key)
+    if got is None:
+        lib = _lib.load()
+        c_ops = (ctypes.c_int * max(len(key), 1))(*key)
+        rc = lib.t2o_fused_sequence_prepare(c_ops, len(key))
+        if rc == 2:                                            # T2O_EUNSUPPORTED: no libhiprtc here (or an unsupported operator: the call itself reports that)
+            got = False
+        else:
+            _lib.check(rc, 't2o_fused_sequence_prepare')
+            got = True
+        _prepared_chains[key] = got
+    return got
+
+
 class _FusedSequenceFn(torch.autograd.Function):
     """A known operator list with runs of pointwise operators fused in registers; only the
     final image (and the images around each sharpness) exist in HBM."""
@@ -759,6 +782,8 @@ class _FusedSequenceFn(torch.autograd.Function):
         nbuf = lib.t2o_fused_sequence_buffers(c_ops, K)
         if nbuf < 0:
             raise RuntimeError('unsupported operator in sequence %s' % (ops,))
+        if _CHAIN_JIT and tuple(ops) not in _prepared_chains and not torch.cuda.is_current_stream_capturing():
+            prepare_fused_sequence(ops)                        # first use of this list: specialise its chain kernels
         seg = torch.empty((max(nbuf, 1),) + tuple(img.shape), dtype=torch.float32, device=img.device)
         out = torch.empty_like(img)
         loss = torch.empty((), dtype=torch.float32, device=img.device)

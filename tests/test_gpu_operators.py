@@ -659,3 +659,59 @@ def test_param_heads_add_their_gradients_into_existing_grad_tensors(dev):
             continue
         want = 2 * (torch.zeros_like(qb) if qb.grad is None else qb.grad)
         np.testing.assert_allclose(qa.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-6 * max(float(want.abs().max()), 1e-6), err_msg=n)
+
+
+@pytest.mark.gpu
+def test_runtime_specialised_chain_matches_runtime_loop_and_fp64_oracle(monkeypatch):
+    """An operator order with no ahead-of-time chain kernel ([2,0,3,1,5] + sharpness; Executor.execute permits any order,
+    executors/executor.py:33-55): first through the run-time-loop kernels (no specialisation), then after
+    t2o_fused_sequence_prepare has compiled the list with hipRTC.  Images bit-identical, loss identical, parameter
+    gradients equal up to summation order; and the specialised path against fp64 autograd of the oracle."""
+    import t2onet_amd
+    import t2onet_amd.functional as T
+    from t2onet_amd import _lib
+    from oracle import cpu_ref
+    dev = torch.device('cuda:0')
+    ops = [2, 0, 3, 1, 5, 6]
+    B, H, W = 3, 40, 64
+    img, tgt = synth.images(B, H, W, 301), synth.images(B, H, W, 302)
+    ps = [synth.op_params(op, B, 310 + k, 'mid') for k, op in enumerate(ops)]
+    params = torch.zeros(len(ops), B, 24)
+    for k, p in enumerate(ps):
+        params[k, :, :p.shape[1]] = p
+    lib = _lib.load()
+
+    def run():
+        x = img.to(dev).requires_grad_(True)
+        pr = params.to(dev).requires_grad_(True)
+        loss, out = T.fused_sequence_l1(x, ops, pr, tgt.to(dev))
+        loss.backward()
+        return loss.item(), out.detach().cpu(), x.grad.cpu(), pr.grad.cpu()
+    monkeypatch.setattr(T, '_CHAIN_JIT', False)
+    T._prepared_chains.pop(tuple(ops), None)
+    n0 = lib.t2o_jit_specialisations()
+    base = run()
+    assert lib.t2o_jit_specialisations() == n0                       # nothing was compiled: the run-time-loop kernels ran
+    monkeypatch.setattr(T, '_CHAIN_JIT', True)
+    if not T.prepare_fused_sequence(ops):
+        pytest.skip('no libhiprtc on this machine: run-time specialisation unavailable')
+    assert lib.t2o_jit_specialisations() == n0 + 1
+    spec = run()
+    assert lib.t2o_jit_specialisations() == n0 + 1                   # (cached: not compiled again)
+    assert spec[0] == base[0] and torch.equal(spec[1], base[1])      # same arithmetic per pixel
+    # (the two compilations order a few operations differently: a pixel on a hue-sector edge may take the other branch)
+    _close_except_branch_flips(spec[2].numpy(), base[2].numpy(), 1e-5, 1e-9, max_frac=4e-4, what='gimg specialised vs run-time loop')
+    np.testing.assert_allclose(spec[3].numpy(), base[3].numpy(), rtol=2e-5, atol=1e-7)
+    # fp64 autograd of the oracle
+    x64 = img.double().requires_grad_(True)
+    p64 = [p.double().requires_grad_(True) for p in ps]
+    ref, _ = cpu_ref.run_sequence(x64, ops, p64, cpu_ref.default_opt())
+    l64 = (ref - tgt.double()).abs().mean()
+    l64.backward()
+    assert abs(spec[0] - l64.item()) < 1e-6
+    gscale = float(x64.grad.abs().max())
+    _close_except_branch_flips(spec[2].numpy(), x64.grad.float().numpy(), 2e-4, 2e-5 * gscale, max_frac=4e-4, what='gimg vs fp64')
+    for k, p in enumerate(p64):
+        got = spec[3][k, :, :p.shape[1]].numpy()
+        # (a 40 x 64 image: one pixel on the other side of a hue-sector edge moves a one-parameter gradient by a few 1e-3)
+        np.testing.assert_allclose(got, p.grad.float().numpy(), rtol=1e-2, atol=1e-3 * float(p.grad.abs().max()))
