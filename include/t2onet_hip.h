@@ -173,6 +173,13 @@ int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix,
 int t2o_attn_bwd(const float* q, const float* ctx, const float* attn, const float* gmix,
                  const float* gattn, float* gq, float* gctx, int B, int L, int D, void* stream);
 
+/* ---- choice of the next operator in the free-running decode, models/actor.py:222-236 (one launch for: exp, explore
+ * mix, op-mask, renormalisation, Categorical draw or arg-max, op-mask update).  logp (B,n) log-probabilities, op_mask
+ * (B,n) in/out (the chosen entry is cleared), u (B) uniform [0,1) numbers or NULL for arg-max, pred_op (B) int64
+ * operator-vocabulary ids, exec_op (B) int32 = pred_op - 3 (the executor index t2o_apply_* takes; negative = identity). */
+int t2o_choose_op(const float* logp, float* op_mask, const float* u, float explore_prob, long long* pred_op, int* exec_op,
+                  int B, int n_cls, void* stream);
+
 /* ---- training-mode BatchNorm2d fused with the residual add and ReLU that follow it in the image
  * encoder: models/actor_resnet.py:38-44 (BasicBlock.forward: relu(bn1(conv1(x))), relu(bn2(conv2(.)) +
  * shortcut(x))) and :99-100 (stem).  x, res, out: (N,C,H*W) contiguous NCHW; HW = H*W.

@@ -45,6 +45,7 @@ SIGNATURES = {
     't2o_op_candidates_multi_l1': (_I, [c_i, c_i, _I, _P, _I, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P]),
     't2o_ssim_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     't2o_ssim_fwd': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    't2o_choose_op': (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
     't2o_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     't2o_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     't2o_bn_workspace_bytes': (_Z, [_I, _I]),

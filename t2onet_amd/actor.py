@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as T
 from .action_decoder import Decoder
 from .actor_resnet import ResNet
 from .executor import Executor, PARAM_PAD
@@ -157,9 +158,10 @@ class Actor(nn.Module):
             t.record_stream(main)                              # allocated on the side stream, consumed on the caller's
         return enc_out, hidden, feat
 
-    def _execute(self, img, ops_vocab, context, mask=None):
-        """ops_vocab (B,) operator-vocabulary ids; executor index = id - 3, negative -> identity."""
-        return self.executor.execute_per_sample(img, ops_vocab.view(-1) - 3, mask, features=context)
+    def _execute(self, img, ops_vocab, context, mask=None, exec_op=None):
+        """ops_vocab (B,) operator-vocabulary ids; executor index = id - 3, negative -> identity (exec_op: that index
+        when the caller has it already, int32)."""
+        return self.executor.execute_per_sample(img, ops_vocab.view(-1) - 3 if exec_op is None else exec_op, mask, features=context)
 
     # ------------------------------------------------------------------ teacher forcing
     def supervised_forward(self, x, y, img_x, img_y, gt_params, mask, lengths=None):
@@ -217,20 +219,25 @@ class Actor(nn.Module):
             feat = feat0 if (call == 0 and feat0 is not None) else self.image_features(img_x, call)
             logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
             hiddens.append(tuple(h.detach() for h in hidden))
-            probs = torch.exp(logp).squeeze(1)
-            probs = probs * (1 - self.opt.explore_prob) + self.opt.explore_prob
-            probs = probs * op_mask
-            probs = probs / (probs.sum(1, keepdim=True) + 1e-30)
-            if reinforce_sample:
-                pred_op = sample_categorical(probs)
+            exec_op = None
+            if logp.is_cuda and logp.dtype == torch.float32 and op_mask.shape[1] <= 32:
+                # exp, exploration floor, op-mask, renormalisation, draw / arg-max and the op-mask update: ONE launch
+                pred_op, exec_op = T.choose_op(logp, op_mask, self.opt.explore_prob, bool(reinforce_sample))
             else:
-                pred_op = probs.topk(1)[1].view(B, -1)
-            op_mask.scatter_(1, pred_op, 0.0)              # an operator is used at most once
+                probs = torch.exp(logp).squeeze(1)
+                probs = probs * (1 - self.opt.explore_prob) + self.opt.explore_prob
+                probs = probs * op_mask
+                probs = probs / (probs.sum(1, keepdim=True) + 1e-30)
+                if reinforce_sample:
+                    pred_op = sample_categorical(probs)
+                else:
+                    pred_op = probs.topk(1)[1].view(B, -1)
+                op_mask.scatter_(1, pred_op, 0.0)          # an operator is used at most once
             pred_mask = None
             if mask_dict is not None:                      # local edits (GIER): one host sync per step, as the reference
                 pred_mask = self.get_gt_mask(img_x, mask_dict, pred_op.detach().cpu().numpy())
                 pred_masks.append(pred_mask)
-            img_x, par = self._execute(img_x, pred_op, context, pred_mask)
+            img_x, par = self._execute(img_x, pred_op, context, pred_mask, exec_op)
             pred_imgs.append(img_x)
             pred_params.append(par)
             pred_ops.append(pred_op.squeeze(-1))

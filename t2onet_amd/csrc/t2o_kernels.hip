@@ -593,6 +593,37 @@ __global__ __launch_bounds__(64) void k_candidates_finalize(const float* partial
   if (threadIdx.x == 0) loss[blockIdx.x] = acc * inv_n;
 }
 
+// ---------------------------------------------------------------- next-operator choice of the free-running decode
+// (models/actor.py:222-236: probs = exp(logp) * (1 - e) + e; probs *= op_mask; probs /= sum + 1e-30; Categorical
+// sample or arg-max; op_mask[b][choice] = 0).  ~17 framework launches per decoder step as one: a thread per sample.
+// u: one uniform [0,1) number per sample (null: arg-max).  Inverse-CDF draw as actor.sample_categorical: the first
+// index whose cumulative weight exceeds u * total; arg-max if rounding pushes it past the end.
+__global__ __launch_bounds__(64) void k_choose_op(const float* logp, float* op_mask, const float* u, float explore,
+                                                 long long* pred_op, int* exec_op, int B, int n) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float* lp = logp + (size_t)b * n;
+  float* m = op_mask + (size_t)b * n;
+  float p[32];
+  float total = 0.0f;
+  for (int k = 0; k < n; ++k) { p[k] = (expf(lp[k]) * (1.0f - explore) + explore) * m[k]; total += p[k]; }
+  const float inv = 1.0f / (total + 1e-30f);
+  int best = 0;
+  float bestv = p[0] * inv;
+  float cdf = 0.0f, cdf_total = 0.0f;
+  for (int k = 0; k < n; ++k) { p[k] *= inv; cdf_total += p[k]; if (p[k] > bestv) { bestv = p[k]; best = k; } }
+  int choice = best;
+  if (u) {
+    const float thr = u[b] * cdf_total;
+    int idx = 0;
+    for (int k = 0; k < n; ++k) { cdf += p[k]; idx += (cdf <= thr) ? 1 : 0; }
+    choice = idx >= n ? best : idx;
+  }
+  pred_op[b] = choice;
+  exec_op[b] = choice - 3;                 // executor index = operator-vocabulary id - 3 (actor.py:165)
+  m[choice] = 0.0f;                        // an operator is used at most once (actor.py:235-236)
+}
+
 // ------------------------------------------------------------------ attention core
 // One workgroup (4 waves) per sample.  Scores: wave w takes encoder rows w, w+4, ... (lanes stride
 // the D columns, shuffle reduction); softmax over all L rows from LDS; mix / gradients: one thread
@@ -1309,6 +1340,14 @@ int t2o_ssim_fwd(const float* img1, const float* img2, float* out, void* workspa
   k_ssim_fwd<<<(unsigned)(B * C * s.tiles), kThreads, sizeof(float) * ssim_lds_floats(), st>>>(s);
   k_ssim_finalize<<<B, kThreads, 0, st>>>(s.partials, C * s.tiles, 1.0f / ((float)C * (float)H * (float)W), out);
   return check_launch("ssim forward");
+}
+
+int t2o_choose_op(const float* logp, float* op_mask, const float* u, float explore_prob, long long* pred_op, int* exec_op,
+                  int B, int n_cls, void* stream) {
+  if (!logp || !op_mask || !pred_op || !exec_op) return fail(T2O_EINVAL, "choose_op: null pointer");
+  if (B <= 0 || n_cls <= 0 || n_cls > 32) return fail(T2O_EINVAL, "choose_op: 1..32 operator tokens");
+  k_choose_op<<<(unsigned)((B + 63) / 64), 64, 0, (hipStream_t)stream>>>(logp, op_mask, u, explore_prob, pred_op, exec_op, B, n_cls);
+  return check_launch("choose_op");
 }
 
 int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix, int B, int L, int D, void* stream) {

@@ -220,6 +220,24 @@ def attention_core(q, context):
     return _AttnFn.apply(q, context)
 
 
+def choose_op(logp, op_mask, explore_prob, sample=True):
+    """Next operator of the free-running decode (models/actor.py:222-236) in one launch (t2o_choose_op): probabilities
+    from logp (B,n) with the exploration floor, masked by op_mask (B,n) and renormalised, one Categorical draw per
+    sample (sample=True: uniform numbers from torch's generator) or the arg-max; op_mask's chosen entries are cleared in
+    place.  Returns (pred_op (B,1) int64 operator-vocabulary ids, exec_op (B) int32 executor indices = id - 3)."""
+    _need_gpu(logp, op_mask)
+    B, n = op_mask.shape
+    logp = logp.detach().reshape(B, n).contiguous()
+    if not op_mask.is_contiguous():
+        raise ValueError('choose_op: op_mask must be contiguous (it is updated in place)')
+    u = torch.rand(B, device=logp.device, dtype=torch.float32) if sample else None
+    pred = torch.empty(B, 1, dtype=torch.int64, device=logp.device)
+    exe = torch.empty(B, dtype=torch.int32, device=logp.device)
+    rc = _lib.load().t2o_choose_op(_ptr(logp), _ptr(op_mask), _ptr(u), float(explore_prob), _ptr(pred), _ptr(exe), B, n, _stream(logp.device))
+    _lib.check(rc, 't2o_choose_op')
+    return pred, exe
+
+
 def _is_nhwc(x):
     """4-D activations stored channels-last with a channel count the NHWC kernels take (power of two in [4, 1024])."""
     C = x.shape[1]
