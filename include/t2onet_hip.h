@@ -367,6 +367,8 @@ int t2o_conv3x3s2_dgrad_pre_nhwc(const float* dy, const float* wt, float* dx, vo
  * call); planar == 0: (N,2Ho,2Wo,3).  y / dy are (N,Ho,Wo,Co) NHWC, w (Co,3,3,3) channels-last.  accumulate != 0: the
  * weight gradient is added to dw, the data gradient to dx (the image gradient already holds the operator's part). */
 int t2o_stem_fwd(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, int planar, void* stream);
+/* forward for an input of ANY size (Hi, Wi; Ho = (Hi+1)/2): full-resolution inference images have odd sizes */
+int t2o_stem_fwd_any(const float* x, const float* w, float* y, float* stats, int N, int Hi, int Wi, int Co, int planar, void* stream);
 int t2o_stem_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int Ho, int Wo,
                    int Co, int planar, int accumulate, void* stream);
 int t2o_stem_dgrad(const float* dy, const float* w, float* dx, int N, int Ho, int Wo, int Co, int planar, int accumulate, void* stream);
@@ -384,6 +386,22 @@ int t2o_conv1x1s2_dgrad_acc_nhwc(const float* dy, const float* wt, float* dx, in
 size_t t2o_conv1x1s2_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
 int t2o_conv1x1s2_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                              int N, int H, int W, int Ci, int Co, int accumulate, void* stream);
+
+/* ---- the same 3x3 convolutions (padding 1, stride 1 or 2) for ANY image size (t2o_conv_generic.hip): gathered-row
+ * implicit GEMMs on the fp32 matrix cores, about half the rate of the LDS-DMA kernels above, for the layers those
+ * cannot take (image width not a multiple of 8 / 4, odd sizes under stride 2: the 4 x 4 stage of a 128 x 128 training
+ * image, every stage of a full-resolution inference image) -- replaces the library fall-back there, deterministic.
+ *   forward        x (N,H,W,Ci), w (Co,3,3,Ci) -> y (N,Ho,Wo,Co), Ho = (H-1)/stride + 1
+ *   data gradient  dy (N,Ho,Wo,Co), wt = t2o_conv_weight_transform(w, wt, Co, Ci, 9, stride == 1) -> dx (N,H,W,Ci)
+ *                  (+ addend (N,H,W,Ci), nullable)
+ *   weight gradient x, dy -> dw (Co,3,3,Ci), split-K partials in `workspace`, accumulate != 0: dw +=
+ * Ci % 32 == 0 (weight gradient: % 64), Co % 64 == 0 (data gradient: Co % 32, Ci % 64). */
+int t2o_conv3x3_any_fwd_nhwc(const float* x, const float* w, float* y, int N, int H, int W, int Ci, int Co, int stride, void* stream);
+int t2o_conv3x3_any_dgrad_nhwc(const float* dy, const float* wt, const float* addend, float* dx, int N, int H, int W, int Ci, int Co,
+                               int stride, void* stream);
+size_t t2o_conv3x3_any_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co, int stride);
+int t2o_conv3x3_any_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                               int N, int H, int W, int Ci, int Co, int stride, int accumulate, void* stream);
 
 /* ---- LSTM layers of the request encoder (models/lang_encoder.py:70-113: 2-layer bidirectional LSTM over packed, i.e.
  * per-sample-length, sequences; nn.LSTM gate order i, f, g, o), one launch per time step for both directions (t2o_rnn.hip).

@@ -85,6 +85,7 @@ SIGNATURES = {
     't2o_conv3x3_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_stem_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_stem_fwd_any': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_stem_wgrad': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     't2o_stem_dgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     't2o_conv1x1s2_fwd_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -94,6 +95,10 @@ SIGNATURES = {
     't2o_fused_sequence_prepare': (_I, [_P, _I]),
     't2o_jit_set_cache_dir': (_I, [ctypes.c_char_p]),
     't2o_jit_specialisations': (_I, []),
+    't2o_conv3x3_any_fwd_nhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_conv3x3_any_dgrad_nhwc': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_conv3x3_any_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I, _I]),
+    't2o_conv3x3_any_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     't2o_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     't2o_lstm_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }

@@ -43,8 +43,7 @@ def _conv(conv, x, bn=None):
             and conv.weight.is_contiguous(memory_format=torch.channels_last):
         y = T.conv3x3(x, conv.weight, True) if want else T.conv3x3(x, conv.weight)
     elif _OWN_WGRAD and conv.bias is None and T.conv3x3s2_supported(x, conv.weight, conv.stride, conv.padding) \
-            and conv.weight.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled() \
-            and (x.requires_grad or conv.weight.requires_grad):
+            and conv.weight.is_contiguous(memory_format=torch.channels_last):
         y = T.conv3x3s2(x, conv.weight, True) if want else T.conv3x3s2(x, conv.weight)
     else:
         y, want = conv(x), False
@@ -90,7 +89,12 @@ class BasicBlock(nn.Module):
     def forward(self, x, counted=False):
         y, st = _conv(self.conv1, x, self.bn1)
         out = _bn_relu(self.bn1, y, None, counted, st)
-        sc = _bn_plain(self.shortcut[1], self.shortcut[0](x), counted) if len(self.shortcut) else x
+        if len(self.shortcut):
+            sconv = self.shortcut[0]
+            ys = T.conv1x1s2(x, sconv.weight) if (_OWN_WGRAD and T.conv1x1s2_supported(x, sconv)) else sconv(x)
+            sc = _bn_plain(self.shortcut[1], ys, counted)
+        else:
+            sc = x
         y, st = _conv(self.conv2, out, self.bn2)
         return _bn_relu(self.bn2, y, sc, counted, st)
 

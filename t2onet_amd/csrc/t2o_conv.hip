@@ -978,13 +978,13 @@ constexpr int kSfTilesPerWg = 8;          // consecutive tiles of a workgroup: t
 
 template <int kCo, bool kPlanar>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                  float* __restrict__ stats, int N, int Ho, int Wo, int tiles_total) {
+                                                  float* __restrict__ stats, int N, int Ho, int Wo, int tiles_total, int Hi, int Wi) {
   constexpr int CQ = kCo / 4, PP = 256 / CQ, kPasses = (kSfTH * kSfTW) / PP;
   __shared__ __attribute__((aligned(16))) float patch[kSfRows][kSfRowFloats + 1];       // (196 floats per row: 8-byte aligned pairs)
   __shared__ float red[2][PP][kCo];
   const int tid = threadIdx.x, cq = tid % CQ, ps = tid / CQ;
   const int tiles_w = (Wo + kSfTW - 1) / kSfTW, tiles_h = (Ho + kSfTH - 1) / kSfTH;
-  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  // (Hi, Wi: the input size, 2 Ho or 2 Ho - 1 rows: odd sizes at full-resolution inference)
   float wr[4][27];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -1383,6 +1383,11 @@ int t2o_stem_fwd_nhwc(const float* x, const float* w, float* y, float* stats, in
 }
 
 int t2o_stem_fwd(const float* x, const float* w, float* y, float* stats, int N, int Ho, int Wo, int Co, int planar, void* stream) {
+  return t2o_stem_fwd_any(x, w, y, stats, N, 2 * Ho, 2 * Wo, Co, planar, stream);
+}
+
+int t2o_stem_fwd_any(const float* x, const float* w, float* y, float* stats, int N, int Hi, int Wi, int Co, int planar, void* stream) {
+  const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
   if (!x || !w || !y) return set_error(T2O_EINVAL, "stem_fwd: null pointer");
   if (N <= 0 || Ho <= 0 || Wo <= 0 || (Co != 32 && Co != 64) || (size_t)N * Ho * Wo * 4 * 3 >= ((size_t)1 << 40))
     return set_error(T2O_EUNSUPPORTED, "stem_fwd: 3 input channels, 32 or 64 output channels");
@@ -1390,8 +1395,8 @@ int t2o_stem_fwd(const float* x, const float* w, float* y, float* stats, int N, 
   if (tiles >= ((long long)1 << 30)) return set_error(T2O_EUNSUPPORTED, "stem_fwd: too many tiles");
   const unsigned grid = (unsigned)t2o_stem_fwd_stats_rows(N, Ho, Wo);
   hipStream_t st = (hipStream_t)stream;
-  if (Co == 64) { if (planar) k_stem_fwd<64, true><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); else k_stem_fwd<64, false><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); }
-  else { if (planar) k_stem_fwd<32, true><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); else k_stem_fwd<32, false><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles); }
+  if (Co == 64) { if (planar) k_stem_fwd<64, true><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles, Hi, Wi); else k_stem_fwd<64, false><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles, Hi, Wi); }
+  else { if (planar) k_stem_fwd<32, true><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles, Hi, Wi); else k_stem_fwd<32, false><<<grid, 256, 0, st>>>(x, w, y, stats, N, Ho, Wo, (int)tiles, Hi, Wi); }
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_fwd launch failed");
 }
 

@@ -25,6 +25,12 @@ from . import _lib
 from .functional import _need_gpu, _ptr, _stream, _conv_workspace
 
 
+def _fast_direct(stride, Hi, Wi, Wo):
+    """The LDS-DMA forward / data-gradient kernels take this layer: the OUTPUT-side width a multiple of 8 and, under
+    stride 2, an even input."""
+    return Wo % 8 == 0 and (stride == 1 or (Hi % 2 == 0 and Wi % 2 == 0))
+
+
 def _nhwc(N, H, W, C, dev):
     return torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
 
@@ -52,12 +58,14 @@ class TrunkPlan:
         self._wt = None
 
     def supported(self, img):
-        """fp32 GPU image (N,3,H,W) whose every stage the matrix-core kernels take: after the stem and four stride-2
-        stages the last feature map must still be a multiple of 8 pixels wide (W % 256 == 0), H a multiple of 32."""
+        """fp32 GPU image (N,3,H,W) with even H and W (the stem's gradient kernels).  Every later stage takes any size:
+        the LDS-DMA kernels where the stage width allows (multiples of 8 / 4, even sizes under stride 2 -- every stage
+        of a 256 x 256 image), the gathered-row kernels (t2o_conv_generic.hip) elsewhere (e.g. the 4 x 4 stage of a
+        128 x 128 image)."""
         net = self.net
         if not (img.is_cuda and img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3):
             return False
-        if img.shape[2] % 32 or img.shape[3] % 256 or net.conv1.weight.shape[0] != 64:
+        if img.shape[2] % 2 or img.shape[3] % 2 or net.conv1.weight.shape[0] != 64:
             return False
         if not (img.is_contiguous() or img.is_contiguous(memory_format=torch.channels_last)):
             return False
@@ -120,13 +128,16 @@ class _TrunkFn(torch.autograd.Function):
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             s = conv.stride[0]
-            Ho, Wo = Hi // s, Wi // s
+            Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
             y = _nhwc(Nn, Ho, Wo, Co, dev)
-            stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(Nn, Ho, Wo, Co, s), 2, Co), dtype=torch.float32, device=dev)
-            rc = lib.t2o_conv3x3_fwd_stats_nhwc(_ptr(x), _ptr(w), _ptr(y), _ptr(stats), _ptr(conv_ws), conv_ws.numel(), Nn, Ho, Wo,
-                                                Ci, Co, s, st)
-            _lib.check(rc, 't2o_conv3x3_fwd_stats_nhwc')
-            return y, stats
+            if _fast_direct(s, Hi, Wi, Wo):
+                stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(Nn, Ho, Wo, Co, s), 2, Co), dtype=torch.float32, device=dev)
+                rc = lib.t2o_conv3x3_fwd_stats_nhwc(_ptr(x), _ptr(w), _ptr(y), _ptr(stats), _ptr(conv_ws), conv_ws.numel(), Nn, Ho, Wo,
+                                                    Ci, Co, s, st)
+                _lib.check(rc, 't2o_conv3x3_fwd_stats_nhwc')
+                return y, stats
+            _lib.check(lib.t2o_conv3x3_any_fwd_nhwc(_ptr(x), _ptr(w), _ptr(y), Nn, Hi, Wi, Ci, Co, s, st), 't2o_conv3x3_any_fwd_nhwc')
+            return y, None                                     # (the batch norm makes its own statistics pass)
 
         # ---- stem: conv 3 -> 64 stride 2 + bn + relu
         Ho, Wo = H // 2, W // 2
@@ -141,7 +152,7 @@ class _TrunkFn(torch.autograd.Function):
         for b in plan.blocks:
             s = b.conv1.stride[0]
             Co = b.conv1.weight.shape[0]
-            Hn, Wn = Hc // s, Wc // s
+            Hn, Wn = (Hc - 1) // s + 1, (Wc - 1) // s + 1
             M = N * Hn * Wn
             y1, s1 = conv3(x, b.conv1, N, Hc, Wc, True)
             a1 = torch.empty_like(y1)
@@ -197,34 +208,56 @@ class _TrunkFn(torch.autograd.Function):
             _lib.check(rc, 't2o_bn_relu_nhwc_bwd_acc')
             return dx, dres
 
-        def wgrad3(conv, x, dy, Hn, Wn):
+        def wgrad3(conv, x, dy, Hi, Wi, Hn, Wn):
+            """(Hi, Wi): the convolution's input grid, (Hn, Wn): its output grid."""
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             s = conv.stride[0]
-            need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)
+            if Wn % 4 == 0 and (s == 1 or (Hi % 2 == 0 and Wi % 2 == 0)):
+                need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                rc = lib.t2o_conv3x3_wgrad_acc_nhwc(_ptr(x), _ptr(dy), _ptr(g(w)), _ptr(ws), need, N, Hn, Wn, Ci, Co, s, acc, st)
+                _lib.check(rc, 't2o_conv3x3_wgrad_acc_nhwc')
+                return
+            need = lib.t2o_conv3x3_any_wgrad_workspace_bytes(N, Hi, Wi, Ci, Co, s)
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            rc = lib.t2o_conv3x3_wgrad_acc_nhwc(_ptr(x), _ptr(dy), _ptr(g(w)), _ptr(ws), need, N, Hn, Wn, Ci, Co, s, acc, st)
-            _lib.check(rc, 't2o_conv3x3_wgrad_acc_nhwc')
+            rc = lib.t2o_conv3x3_any_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(g(w)), _ptr(ws), need, N, Hi, Wi, Ci, Co, s, acc, st)
+            _lib.check(rc, 't2o_conv3x3_any_wgrad_nhwc')
+
+        def dgrad3(conv, dy, dx, addend, Hi, Wi, Hn, Wn):
+            """dx (N,Hi,Wi,Ci) = data gradient of conv for dy (N,Hn,Wn,Co) (+ addend, stride 1 only)."""
+            w = conv.weight
+            Co, Ci = w.shape[0], w.shape[1]
+            s = conv.stride[0]
+            if _fast_direct(s, Hi, Wi, Wn):
+                if s == 1:
+                    rc = lib.t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy), _ptr(wt[id(conv)]), _ptr(addend), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
+                                                        N, Hi, Wi, Ci, Co, st)
+                else:
+                    rc = lib.t2o_conv3x3s2_dgrad_pre_nhwc(_ptr(dy), _ptr(wt[id(conv)]), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
+                                                          N, Hn, Wn, Ci, Co, st)
+                _lib.check(rc, 't2o_conv3x3_dgrad_pre_nhwc')
+            else:
+                rc = lib.t2o_conv3x3_any_dgrad_nhwc(_ptr(dy), _ptr(wt[id(conv)]), _ptr(addend), _ptr(dx), N, Hi, Wi, Ci, Co, s, st)
+                _lib.check(rc, 't2o_conv3x3_any_dgrad_nhwc')
 
         d = dout.permute(0, 2, 3, 1).contiguous()              # NHWC (a no-op for a channels_last gradient)
         for b, rec in zip(reversed(plan.blocks), reversed(ctx.saved)):
             s = b.conv1.stride[0]
             Co, Ci = b.conv1.weight.shape[0], b.conv1.weight.shape[1]
             Hc, Wc = rec['H'], rec['W']
-            Hn, Wn = Hc // s, Wc // s
+            Hn, Wn = (Hc - 1) // s + 1, (Wc - 1) // s + 1
             M = N * Hn * Wn
             # out = relu(bn2(y2) + sc)
             dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co)
             da1 = torch.empty_like(rec['a1'])
-            rc = lib.t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy2), _ptr(wt[id(b.conv2)]), None, _ptr(da1), _ptr(conv_ws), conv_ws.numel(),
-                                                N, Hn, Wn, Co, Co, st)
-            _lib.check(rc, 't2o_conv3x3_dgrad_pre_nhwc')
-            wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn)
+            dgrad3(b.conv2, dy2, da1, None, Hn, Wn, Hn, Wn)
+            wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn, Hn, Wn)
             del dy2
             # a1 = relu(bn1(y1))
             dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co)
             del da1
-            wgrad3(b.conv1, rec['x'], dy1, Hn, Wn)
+            wgrad3(b.conv1, rec['x'], dy1, Hc, Wc, Hn, Wn)
             dx = torch.empty_like(rec['x'])
             if len(b.shortcut):
                 sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
@@ -234,15 +267,11 @@ class _TrunkFn(torch.autograd.Function):
                 rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(rec['x']), _ptr(dys), _ptr(g(sc_conv.weight)), _ptr(ws), need, N, Hc, Wc, Ci, Co,
                                                   acc, st)
                 _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
-                rc = lib.t2o_conv3x3s2_dgrad_pre_nhwc(_ptr(dy1), _ptr(wt[id(b.conv1)]), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
-                                                      N, Hn, Wn, Ci, Co, st)
-                _lib.check(rc, 't2o_conv3x3s2_dgrad_pre_nhwc')
+                dgrad3(b.conv1, dy1, dx, None, Hc, Wc, Hn, Wn)
                 rc = lib.t2o_conv1x1s2_dgrad_acc_nhwc(_ptr(dys), _ptr(wt[id(sc_conv)]), _ptr(dx), N, Hc, Wc, Ci, Co, st)
                 _lib.check(rc, 't2o_conv1x1s2_dgrad_acc_nhwc')
             else:
-                rc = lib.t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy1), _ptr(wt[id(b.conv1)]), _ptr(dsc), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
-                                                    N, Hc, Wc, Ci, Co, st)
-                _lib.check(rc, 't2o_conv3x3_dgrad_pre_nhwc')
+                dgrad3(b.conv1, dy1, dx, dsc, Hc, Wc, Hn, Wn)
             d = dx
         # ---- stem
         y0, m0, i0 = ctx.stem

@@ -547,16 +547,16 @@ def stem_forward(x, weight, want_stats=False):
     _need_gpu(x, weight)
     N, Ci, Hi, Wi = x.shape
     Co = weight.shape[0]
-    if Ci != 3 or Co not in (32, 64) or Hi % 2 or Wi % 2:
-        raise ValueError('stem_forward: 3 input channels, 32 or 64 output channels, even image size')
-    Ho, Wo = Hi // 2, Wi // 2
+    if Ci != 3 or Co not in (32, 64):
+        raise ValueError('stem_forward: 3 input channels, 32 or 64 output channels')
+    Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2                      # (odd sizes: full-resolution inference images)
     x = x.contiguous(memory_format=torch.channels_last)
     weight = weight.contiguous(memory_format=torch.channels_last)
     lib = _lib.load()
     y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     stats = torch.empty((lib.t2o_stem_fwd_stats_rows(N, Ho, Wo), 2, Co), dtype=torch.float32, device=x.device) if want_stats else None
-    rc = lib.t2o_stem_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), _ptr(stats), N, Ho, Wo, Co, _stream(x.device))
-    _lib.check(rc, 't2o_stem_fwd_nhwc')
+    rc = lib.t2o_stem_fwd_any(_ptr(x), _ptr(weight), _ptr(y), _ptr(stats), N, Hi, Wi, Co, 0, _stream(x.device))
+    _lib.check(rc, 't2o_stem_fwd_any')
     return (y, stats) if want_stats else y
 
 
@@ -603,12 +603,13 @@ def conv3x3s2_supported(x, weight, stride, padding):
     padding 1, even image size; either Ci a multiple of 64, Co of 32 and an output width that is a multiple of 8
     (matrix cores), or the 3-channel stem with 32 / 64 output channels."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
-            and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-            and x.is_contiguous(memory_format=torch.channels_last)):
+            and tuple(stride) == (2, 2) and tuple(padding) == (1, 1) and x.is_contiguous(memory_format=torch.channels_last)):
         return False
+    if weight.shape[1] == 3 and (x.shape[2] % 2 or x.shape[3] % 2) and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return False                                           # (the stem's GRADIENT kernels want an even image; its forward takes any)
     if weight.shape[1] == 3:                                   # the stem: a streaming kernel (no matrix-core shape)
         return weight.shape[0] in (32, 64)
-    return weight.shape[0] % 32 == 0 and weight.shape[1] % 64 == 0 and x.shape[3] % 16 == 0
+    return weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
 
 
 class _Conv3x3S2Fn(torch.autograd.Function):
@@ -618,34 +619,46 @@ class _Conv3x3S2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, want_stats=False):
         ctx.save_for_backward(x, weight)
-        own = 'F' in _CONV_OWN and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0 and x.shape[3] % 16 == 0
+        even = x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+        own = 'F' in _CONV_OWN and weight.shape[1] % 32 == 0 and weight.shape[0] % 64 == 0 and x.shape[3] % 16 == 0 and even
         stem = 'T' in _CONV_OWN and weight.shape[1] == 3 and weight.shape[0] in (32, 64)
         fwd = conv3x3s2_forward if own else stem_forward if stem else None
-        if want_stats:                                       # (y, stats); stats None where the library computes y
-            y, stats = fwd(x, weight, True) if fwd else (torch.nn.functional.conv2d(x, weight, None, 2, 1), None)
+        slow = (lambda: conv3x3_any_forward(x, weight, 2)) if weight.shape[1] % 32 == 0 else \
+            (lambda: torch.nn.functional.conv2d(x, weight, None, 2, 1))
+        if want_stats:                                       # (y, stats); stats None where the any-size kernel computes y
+            y, stats = fwd(x, weight, True) if fwd else (slow(), None)
             if stats is not None:
                 ctx.mark_non_differentiable(stats)
             return y, stats
-        return fwd(x, weight) if fwd else torch.nn.functional.conv2d(x, weight, None, 2, 1)
+        return fwd(x, weight) if fwd else slow()
 
     @staticmethod
     def backward(ctx, dy, _gstats=None):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
-        own = ctx.needs_input_grad[0] and 's' in _CONV_OWN
+        is_stem = weight.shape[1] == 3
+        even = x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+        fast_d = even and (is_stem or dy.shape[3] % 8 == 0)
+        own = ctx.needs_input_grad[0] and 's' in _CONV_OWN and fast_d
         own_w = (ctx.needs_input_grad[1] and 'S' in _CONV_OWN and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0
-                 and dy.shape[3] % 4 == 0)
-        stem_w = ctx.needs_input_grad[1] and 'W' in _CONV_OWN and weight.shape[1] == 3 and weight.shape[0] in (32, 64)
-        mask = [ctx.needs_input_grad[0] and not own, ctx.needs_input_grad[1] and not own_w and not stem_w, False]
+                 and dy.shape[3] % 4 == 0 and even)
+        stem_w = ctx.needs_input_grad[1] and 'W' in _CONV_OWN and is_stem and weight.shape[0] in (32, 64)
+        any_d = ctx.needs_input_grad[0] and not own and not is_stem
+        any_w = ctx.needs_input_grad[1] and not own_w and not stem_w and not is_stem
+        mask = [ctx.needs_input_grad[0] and not own and not any_d, ctx.needs_input_grad[1] and not own_w and not stem_w and not any_w, False]
         dx = dw = None
-        if mask[0] or mask[1]:
+        if mask[0] or mask[1]:                               # (only a 3-channel stem with directions switched off by T2O_OWN_CONV)
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, mask)
         if own:
             dx = conv3x3s2_dgrad(dy, weight)
+        elif any_d:
+            dx = conv3x3_any_dgrad(dy, weight, x.shape[2:], 2)
         if own_w:
             dw = conv3x3s2_wgrad(x, dy)
         elif stem_w:
             dw = stem_wgrad(x, dy)
+        elif any_w:
+            dw = conv3x3_any_wgrad(x, dy, 2)
         return dx, dw, None
 
 
@@ -660,7 +673,7 @@ def conv3x3_supported(x, weight, stride, padding):
     encoder except the strided ones, for inputs of 32 pixels and more)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)
             and tuple(stride) == (1, 1) and tuple(padding) == (1, 1) and weight.shape[0] % 64 == 0
-            and weight.shape[1] % 64 == 0 and x.shape[3] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+            and weight.shape[1] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
 # which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
@@ -681,12 +694,12 @@ class _Conv3x3Fn(torch.autograd.Function):
     def forward(ctx, x, weight, want_stats=False):
         ctx.save_for_backward(x, weight)
         own = 'f' in _CONV_OWN and _own_direct(x)
-        if want_stats:                                       # (y, stats); stats None where the library computes y
-            y, stats = conv3x3_forward(x, weight, True) if own else (torch.nn.functional.conv2d(x, weight, None, 1, 1), None)
+        if want_stats:                                       # (y, stats); stats None where the any-size kernel computes y
+            y, stats = conv3x3_forward(x, weight, True) if own else (conv3x3_any_forward(x, weight, 1), None)
             if stats is not None:
                 ctx.mark_non_differentiable(stats)
             return y, stats
-        return conv3x3_forward(x, weight) if own else torch.nn.functional.conv2d(x, weight, None, 1, 1)
+        return conv3x3_forward(x, weight) if own else conv3x3_any_forward(x, weight, 1)
 
     @staticmethod
     def backward(ctx, dy, _gstats=None):
@@ -697,15 +710,13 @@ class _Conv3x3Fn(torch.autograd.Function):
             if 'd' in _CONV_OWN and _own_direct(x):
                 dx = conv3x3_dgrad(dy, weight)
             else:
-                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                         [True, False, False])[0]
+                dx = conv3x3_any_dgrad(dy, weight, x.shape[2:], 1)
         dw = None
         if ctx.needs_input_grad[1]:
-            if 'w' in _CONV_OWN:
+            if 'w' in _CONV_OWN and x.shape[3] % 4 == 0:
                 dw = conv3x3_wgrad(x, dy)
             else:
-                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                         [False, True, False])[1]
+                dw = conv3x3_any_wgrad(x, dy, 1)
         return dx, dw, None
 
 
@@ -1071,3 +1082,83 @@ def lstm_layer(x, lengths, dirs):
     has_bias = len(dirs[0]) == 4
     flat = [t for d in dirs for t in d]
     return _LstmLayerFn.apply(x, lengths, has_bias, *flat)
+
+
+# ---- 3x3 convolutions for any image size (t2o_conv_generic.hip): what the LDS-DMA kernels cannot take ------------------
+def conv3x3_any_forward(x, weight, stride=1):
+    """conv2d(x, weight, None, stride, 1) for any H, W (Ci % 32 == 0, Co % 64 == 0): gathered-row kernel."""
+    _need_gpu(x, weight)
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    x = x.contiguous(memory_format=torch.channels_last)
+    weight = weight.contiguous(memory_format=torch.channels_last)
+    y = torch.empty((N, Co, (H - 1) // stride + 1, (W - 1) // stride + 1), dtype=torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    rc = _lib.load().t2o_conv3x3_any_fwd_nhwc(_ptr(x), _ptr(weight), _ptr(y), N, H, W, Ci, Co, stride, _stream(x.device))
+    _lib.check(rc, 't2o_conv3x3_any_fwd_nhwc')
+    return y
+
+
+def conv3x3_any_dgrad(dy, weight, in_hw, stride=1, addend=None):
+    """Data gradient of conv2d(x, weight, None, stride, 1) for an x of spatial size in_hw = (H, W); dy channels-last."""
+    _need_gpu(dy, weight, addend)
+    N, Co = dy.shape[0], dy.shape[1]
+    Ci = weight.shape[1]
+    H, W = in_hw
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    wt = conv_weight_transform(weight, 9, stride == 1)
+    addend = None if addend is None else addend.contiguous(memory_format=torch.channels_last)
+    dx = torch.empty((N, Ci, H, W), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    rc = _lib.load().t2o_conv3x3_any_dgrad_nhwc(_ptr(dy), _ptr(wt), _ptr(addend), _ptr(dx), N, H, W, Ci, Co, stride, _stream(dy.device))
+    _lib.check(rc, 't2o_conv3x3_any_dgrad_nhwc')
+    return dx
+
+
+def conv3x3_any_wgrad(x, dy, stride=1, into=None):
+    """Weight gradient (Co,Ci,3,3) channels-last of conv2d(x, w, None, stride, 1) for any image size; into: added to."""
+    _need_gpu(x, dy, into)
+    N, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    x = x.contiguous(memory_format=torch.channels_last)
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3_any_wgrad_workspace_bytes(N, H, W, Ci, Co, stride)
+    if need == 0:
+        raise RuntimeError('conv3x3_any_wgrad: unsupported shape (channel counts must be multiples of 64)')
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    dw = into if into is not None else torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    rc = lib.t2o_conv3x3_any_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), need, N, H, W, Ci, Co, stride, 1 if into is not None else 0,
+                                        _stream(x.device))
+    _lib.check(rc, 't2o_conv3x3_any_wgrad_nhwc')
+    return dw
+
+
+class _Conv1x1S2Fn(torch.autograd.Function):
+    """conv2d(x, w, None, stride 2) for a 1x1 weight: the shortcut branch on this library's kernels (t2o_conv1x1.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return conv1x1s2_forward(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x, memory_format=torch.channels_last)
+            conv1x1s2_dgrad_acc(dy, weight, dx)
+        if ctx.needs_input_grad[1]:
+            dw = conv1x1s2_wgrad(x, dy).view_as(weight)
+        return dx, dw
+
+
+def conv1x1s2(x, weight):
+    return _Conv1x1S2Fn.apply(x, weight)
+
+
+def conv1x1s2_supported(x, conv):
+    w = conv.weight
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.bias is None and tuple(w.shape[2:]) == (1, 1)
+            and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (0, 0) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))

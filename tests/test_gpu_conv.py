@@ -263,15 +263,22 @@ def test_kernels_inside_replayed_graphs():
 
 
 def test_wgrad_refuses_widths_it_does_not_take():
-    """W % 4 != 0 is not a shape of the kernel: the library says so and the autograd wrapper's predicate sends such
-    layers to the library convolution."""
+    """W % 4 != 0 is not a shape of the LDS-DMA weight-gradient kernel: the library says so; the autograd wrapper takes
+    the layer all the same and routes it to the any-size kernels (round 3: no library convolution at any width)."""
     import t2onet_amd.functional as T
     dev = torch.device('cuda:0')
-    x = torch.zeros(1, 64, 6, 6, device=dev).contiguous(memory_format=torch.channels_last)
-    w = torch.zeros(64, 64, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
-    assert not T.conv3x3_supported(x, w, (1, 1), (1, 1))
+    x = synth.uniform((1, 64, 6, 6), 905, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    w = synth.uniform((64, 64, 3, 3), 906, -0.1, 0.1).to(dev).contiguous(memory_format=torch.channels_last)
+    assert T.conv3x3_supported(x, w, (1, 1), (1, 1))
     with pytest.raises(RuntimeError):
         T.conv3x3_wgrad(x, x)
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    gy = synth.uniform((1, 64, 6, 6), 907, -1.0, 1.0).to(dev)
+    T.conv3x3(x1, w1).backward(gy)
+    torch.nn.functional.conv2d(x2, w2, None, 1, 1).backward(gy)
+    np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(w1.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(w2.grad.abs().max()))
 
 
 def test_conv3x3_autograd_function_matches_library():
@@ -420,3 +427,43 @@ def test_stem_wgrad_matches_conv2d_fp64(shape):
     assert dw.shape == (Co, 3, 3, 3) and dw.is_contiguous(memory_format=torch.channels_last)
     np.testing.assert_allclose(dw.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
     assert torch.equal(dw, T.stem_wgrad(xg, dg))
+
+
+# (N, Ci, Co, H, W): odd sizes, widths that are no multiple of 4 / 8, one-pixel images, ragged tile tails, both strides
+ANY_SHAPES = [(2, 64, 64, 4, 4), (3, 64, 128, 5, 7), (1, 128, 64, 19, 13), (2, 32, 64, 1, 1), (2, 256, 128, 3, 5),
+              (1, 64, 64, 38, 57), (5, 64, 64, 2, 9)]
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+@pytest.mark.parametrize('shape', ANY_SHAPES)
+def test_any_size_kernels_match_conv2d_fp64(shape, stride):
+    """t2o_conv_generic.hip (gathered-row kernels for the layers the LDS-DMA kernels cannot take): forward, data gradient
+    (+ addend) and weight gradient against fp64 conv2d, strides 1 and 2, odd and tiny images."""
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    x = synth.uniform((N, Ci, H, W), 901, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 902, -1.0, 1.0)
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, None, stride, 1)
+    dy = synth.uniform(tuple(y64.shape), 903, -1.0, 1.0)
+    y64.backward(dy.double())
+    dev = torch.device('cuda:0')
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)      # noqa: E731
+    y = T.conv3x3_any_forward(cl(x), cl(w), stride)
+    assert y.shape == y64.shape
+    np.testing.assert_allclose(y.cpu().numpy(), y64.detach().float().numpy(), rtol=1e-5, atol=1e-5 * float(y64.detach().abs().max()))
+    if Ci % 64 == 0:                                        # (data / weight gradient: 64-channel granularity on the reduced side)
+        dx = T.conv3x3_any_dgrad(cl(dy), cl(w), (H, W), stride)
+        gs = float(x64.grad.abs().max()) or 1.0
+        np.testing.assert_allclose(dx.cpu().numpy(), x64.grad.float().numpy(), rtol=1e-5, atol=1e-5 * gs)
+        if stride == 1:
+            add = synth.uniform((N, Ci, H, W), 904, -1.0, 1.0)
+            dxa = T.conv3x3_any_dgrad(cl(dy), cl(w), (H, W), 1, addend=cl(add))
+            np.testing.assert_allclose(dxa.cpu().numpy(), (x64.grad + add.double()).float().numpy(), rtol=1e-5, atol=1e-5 * (gs + 1.0))
+        dw = T.conv3x3_any_wgrad(cl(x), cl(dy), stride)
+        np.testing.assert_allclose(dw.cpu().numpy(), w64.grad.float().numpy(), rtol=1e-5, atol=1e-5 * float(w64.grad.abs().max()))
+        assert torch.equal(dw, T.conv3x3_any_wgrad(cl(x), cl(dy), stride))
+        acc = dw.clone(memory_format=torch.channels_last)
+        T.conv3x3_any_wgrad(cl(x), cl(dy), stride, into=acc)
+        np.testing.assert_allclose(acc.cpu().numpy(), 2 * w64.grad.float().numpy(), rtol=1e-5, atol=2e-5 * float(w64.grad.abs().max()))

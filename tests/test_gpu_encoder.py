@@ -118,8 +118,9 @@ def _run(net, img, gout):
     return out.detach(), img.grad.detach(), grads
 
 
+@pytest.mark.parametrize('size', [(64, 256), (128, 128), (96, 160)])
 @pytest.mark.parametrize('bias', [(3.0, 4.0), (-0.2, 0.2)])
-def test_trunk_matches_per_layer_path_and_fp64(monkeypatch, bias):
+def test_trunk_matches_per_layer_path_and_fp64(monkeypatch, bias, size):
     """One-node trunk vs the per-layer autograd path and vs the fp64 PyTorch module.
 
     Among the 1.6 M ReLU inputs of this small case some lie within fp32 rounding of zero (|pre-activation| < 1e-6): in
@@ -128,8 +129,8 @@ def test_trunk_matches_per_layer_path_and_fp64(monkeypatch, bias):
     above the kink (0.1 % still masked, none expected within 1e-6 of it): there everything is compared elementwise.  With the default-like
     biases only the forward is compared elementwise and the gradients in relative L2."""
     import t2onet_amd.actor_resnet as R
-    N, H, W = 4, 64, 256
-    img = synth.images(N, H, W, 31)
+    N, (H, W) = 4, size                                     # (64,256): the LDS-DMA kernels everywhere; (128,128): the reference's
+    img = synth.images(N, H, W, 31)                         # training size, 4 x 4 last stage; (96,160): odd stages (3 x 5)
     gout = synth.uniform((N, 512), 32, -1.0, 1.0)
     cpu = _encoder(bias=bias).double().train()
     ref_out, ref_dimg, ref_g = _run(cpu, img.double(), gout.double())
