@@ -302,6 +302,22 @@ def pmc_traffic(kernel, P):
         return None
 
 
+def pmc_launch_traffic(kernel):
+    """HBM bytes per launch of a kernel measured at bench.py's own shapes (profiles/pmc_traffic.json 'bytes_per_launch'),
+    under the same digest rule as pmc_traffic()."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        from t2onet_amd import build
+        with open(path) as f:
+            d = json.load(f)
+        if d.get('lib_digest') != build.source_digest():
+            return None
+        v = d.get('bytes_per_launch', {}).get(kernel)
+        return None if v is None else int(v)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def executor_leg(ctx, ops, B, H, W, steps, warmup, with_api=False):
     """Fused + materialised timing of one executor configuration on this rank's GPU; throughput aggregated
     over ranks (batch shards, no collective: SURVEY 8(e))."""
@@ -457,7 +473,7 @@ def _host_info():
     return {'cpu_model': model, 'logical_cpus': os.cpu_count(), 'physical_cores': phys}
 
 
-def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=8, with_gpu_parity=True):
+def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
     """configs[0] (one image, brightness->contrast->saturation), configs[1] (6-op
     sequence fwd + L1 + bwd) and a bounded sample of configs[2] (the episode/L1 train step), each through
     oracle/cpu_ref.py -- the eager-PyTorch restatement of the reference, validated against it by the
@@ -506,7 +522,7 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=8, with_gpu_parity=True):
             pred = cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], opt.end_id)
             cpu_ref.l1_loss(pred, xtgt).backward()
             adam.step()
-        med3, n3 = _median_time(train_once, 2, 20.0)
+        med3, n3 = _median_time(train_once, 2, 12.0)
         res['cfg3'] = {'value': round(B3 / med3, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
                        'config': 'configs[2]',
                        'sample': 'oracle episode_forward (training mode, sampled ops) + END select + L1 + backward + Adam, '
@@ -626,7 +642,7 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
                         'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world)}
 
 
-def conv_kernel_table(B, H, W, device, reps=20):
+def conv_kernel_table(B, H, W, device, reps=40):
     """HIP-event timings (on the launch stream) of the train step's dominant kernel, k_conv3x3_fwd<2,1>: the forward
     and the data gradient of the stride-1 3x3 convolutions of the encoder's 64-, 128- and 256-channel stages
     (models/actor_resnet.py:27-44) at this batch / image size -- 3 + 3 launches per stage and encoder pass, each
@@ -653,14 +669,16 @@ def conv_kernel_table(B, H, W, device, reps=20):
             for _ in range(3):
                 _lib.check(fn(), 'conv table')
             evs = []
-            for _ in range(reps):
+            group = 10                                      # back-to-back launches between two events: the per-launch figure is
+            for _ in range(max(reps // group, 2)):          # the kernel's duration + the dispatch gap, not event / launch latency
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                _lib.check(fn(), 'conv table')
+                for _ in range(group):
+                    _lib.check(fn(), 'conv table')
                 e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
-            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            ms = sum(a.elapsed_time(b) for a, b in evs) / (len(evs) * group)
             rows['%s_c%d_%dx%d' % (name, C, h, w)] = {'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2),
                                                    'kernel': 'k_conv3x3_fwd<2,1>' if C < 512 else 'k_conv3x3_fwd<1,1>'}
     dom = [v for v in rows.values() if v['kernel'] == 'k_conv3x3_fwd<2,1>']
@@ -814,6 +832,11 @@ def worker(args):
     except Exception as e:                     # noqa: BLE001
         executor['error'] = '%s: %s' % (type(e).__name__, e)
     line['executor'] = executor
+    try:                                   # the train step's dominant kernel on its own, HIP-event timed: the line's `roofline`
+        line['conv_kernels'], line['roofline'] = conv_kernel_table(B, H, W, device)
+        line['roofline']['traffic'] = pmc_launch_traffic('k_conv3x3_fwd<2, 1>')
+    except Exception as e:                 # noqa: BLE001
+        line['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baselines(H, W, args.cpu_sample, args.cpu_train_sample)
 
@@ -847,10 +870,6 @@ def worker(args):
         line['ms_per_step'] = train['ms_per_step']
         line['train_step'] = train
         line['train_roofline'] = train['roofline']
-        try:
-            line['conv_kernels'], line['roofline'] = conv_kernel_table(B, H, W, device)
-        except Exception as e:             # noqa: BLE001
-            line['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     except Exception as e:                 # noqa: BLE001
         import traceback
         traceback.print_exc()
@@ -878,7 +897,7 @@ def main():
     ap.add_argument('--no-train', action='store_true',
                     help='executor legs only (profiling passes; the line then has no headline value)')
     ap.add_argument('--cpu-sample', type=int, default=64, help='images of the configs[1] CPU baseline')
-    ap.add_argument('--cpu-train-sample', type=int, default=8, help='images of the configs[2] CPU baseline')
+    ap.add_argument('--cpu-train-sample', type=int, default=64, help='images of the configs[2] CPU baseline (its full batch; 1 warm-up + <= 2 reps)')
     ap.add_argument('--train-timeout', type=int, default=600, help='seconds before the train-step leg is abandoned')
     ap.add_argument('--launch-timeout', type=int, default=1500, help='launcher: seconds before the ranks are stopped')
     ap.add_argument('--selftest', action='store_true',

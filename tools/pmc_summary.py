@@ -11,12 +11,15 @@ from collections import defaultdict
 out = sys.argv[1]
 P = float(sys.argv[2]) if len(sys.argv) > 2 else 64 * 256 * 256.0
 acc = defaultdict(lambda: defaultdict(list))
+full = defaultdict(lambda: defaultdict(list))      # keyed by the full kernel name incl. template arguments
 for f in glob.glob(os.path.join(out, '*', '*', '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
         if not name.startswith('k_'):
             continue
         acc[name][r['Counter_Name']].append(float(r['Counter_Value']))
+        long_name = r['Kernel_Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+        full[long_name[:long_name.index('(')] if '(' in long_name else long_name][r['Counter_Name']].append(float(r['Counter_Value']))
 traffic = {}
 for k in sorted(acc):
     d = {c: sum(v) / len(v) for c, v in acc[k].items()}
@@ -39,4 +42,11 @@ js = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools
       'lib_digest': build.source_digest(),
       'bytes_per_pixel': {a: round(max(traffic[k] for k in ks), 3) for a, ks in alias.items() if ks},
       'kernels': {a: ks for a, ks in alias.items() if ks}}
+per_launch = {}
+for k, d in full.items():
+    if k.startswith('k_conv3x3'):
+        fe = sum(d.get('FETCH_SIZE', [0])) / max(len(d.get('FETCH_SIZE', [0])), 1) * 1024 * 2
+        wr = sum(d.get('WRITE_SIZE', [0])) / max(len(d.get('WRITE_SIZE', [0])), 1) * 1024
+        per_launch[k] = round(fe + wr)
+js['bytes_per_launch'] = per_launch        # mean over bench.py's conv_kernel_table launches (HIP-event timed there)
 json.dump(js, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
