@@ -26,7 +26,7 @@ from .actor_resnet import ResNet
 from .executor import Executor, PARAM_PAD
 from .lang_encoder import RNNEncoder
 
-_OVERLAP_LANG = os.environ.get('T2O_OVERLAP_LANG', '1') != '0'   # request encoder on a side stream (Actor._encode_request)
+_OVERLAP_LANG = True          # request encoder on a side stream (Actor._encode_request); module switch for A/B runs
 _SIDE_STREAMS = {}
 
 # operators the FiveK path may choose: END + brightness/contrast/saturation/color/tone/sharpness
@@ -138,8 +138,7 @@ class Actor(nn.Module):
         On a GPU in training mode the request encoder (a 17-step BiLSTM: ~1 ms forward and ~2 ms backward of
         small, latency-bound library kernels) runs on a SIDE stream while the first image-encoder pass -- which
         does not depend on it -- runs on the caller's stream; autograd runs each node's backward on its forward's
-        stream, so the recurrent backward likewise overlaps the last image-encoder backward.  T2O_OVERLAP_LANG=0:
-        everything on the caller's stream."""
+        stream, so the recurrent backward likewise overlaps the last image-encoder backward."""
         if not (img_x.is_cuda and self.training and torch.is_grad_enabled() and _OVERLAP_LANG):
             enc_out, enc_hidden, _ = self.lang_encoder(x, lengths, longest)
             return enc_out, self.decoder._init_state(enc_hidden), (self.image_features(img_x, 0) if want_feat else None)

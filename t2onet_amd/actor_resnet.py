@@ -18,19 +18,15 @@ import torch.nn.functional as F
 from . import functional as T
 
 
-_FUSED = os.environ.get('T2O_FUSED_BN', '1') != '0'      # 0: PyTorch's batch norm everywhere (A/B timing)
-# The hand-written MFMA kernels (t2o_conv.hip: forward, data gradient, weight gradient) for the 3x3 stride-1 convolutions
-# in channels-last mode: 1.06-1.25x the library's kernels on MI355X (profiles/r02d_conv_*.txt), the weight gradient
-# deterministic (fixed-order split-K; the library's adds atomically); the train step 65.2 -> 60.0 ms.
-# T2O_OWN_WGRAD=0: library calls for all three (A/B); T2O_OWN_CONV=w|f|d...: a subset (functional._CONV_OWN).
-_OWN_WGRAD = os.environ.get('T2O_OWN_WGRAD', '1') != '0'
-
-
-# T2O_CONV_BN_STATS=0: every fused batch norm makes its own statistics pass (A/B); default: the own forward
-# convolution leaves the per-channel sums of its output (from its accumulators) and the batch norm starts there
-_CONV_STATS = os.environ.get('T2O_CONV_BN_STATS', '1') != '0'
-# T2O_TRUNK=0: never take the one-node trunk (encoder.py); the per-layer path everywhere (A/B, and what the tests compare it with)
-_TRUNK = os.environ.get('T2O_TRUNK', '1') != '0'
+# ONE kill-switch: T2O_LIBRARY_KERNELS=1 sends the encoder's convolutions and batch norms (and the request encoder's
+# LSTM, lang_encoder.py) to the framework's library calls -- the comparison the A/B timings of DESIGN.md were made
+# against.  Everything else is frozen at the measured best; the module-level names below exist for the tests, which
+# flip them with monkeypatch.
+_LIBRARY = os.environ.get('T2O_LIBRARY_KERNELS', '0') == '1'
+_FUSED = not _LIBRARY          # fused training-mode batch norm (+ add + ReLU) kernels
+_OWN_WGRAD = not _LIBRARY      # the hand-written convolution kernels (t2o_conv*.hip), all three directions
+_CONV_STATS = True             # the forward convolution leaves the batch-norm statistics of its output (from its accumulators)
+_TRUNK = not _LIBRARY          # the one-node trunk (encoder.py); False: the per-layer path everywhere (what the tests compare it with)
 
 
 def _conv(conv, x, bn=None):

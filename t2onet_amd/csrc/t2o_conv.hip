@@ -1158,11 +1158,6 @@ bool misaligned16(const void* a, const void* b = nullptr, const void* c = nullpt
   return ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(c) | reinterpret_cast<size_t>(d)) & 15) != 0;
 }
 
-int conv_env(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 bool fwd_supported(int N, int H, int W, int Ci, int Co) {
   return N > 0 && H > 0 && W >= 8 && W % 8 == 0 && Ci >= 32 && Ci % 32 == 0 && Co >= 64 && Co % 64 == 0 &&
          (size_t)N * H * W + (size_t)H * W + 1024 < ((size_t)1 << 31);
@@ -1173,9 +1168,8 @@ size_t fwd_zero_bytes(int Ci) { return ((size_t)8 * Ci * 4 + 1024 + 255) / 256 *
 // pixels per workgroup tile of the forward kernel for a layer (256, or 128 where 256-pixel tiles would fill less than
 // one round of workgroups, one per CU, and for the two-plane x tile of stride 2)
 int fwd_tile_pixels(int P, int Co, int stride) {
-  static const int force_bm = conv_env("T2O_FWD_BM", 0);
   const int wg256 = ((P + 255) / 256) * (Co / kFwdCo);
-  const int bm = stride == 2 ? 1 : (force_bm == 1 || force_bm == 2 ? force_bm : (wg256 < 256 ? 1 : 2));
+  const int bm = stride == 2 ? 1 : (wg256 < 256 ? 1 : 2);
   return 128 * bm;
 }
 
@@ -1223,8 +1217,7 @@ bool wgrad_supported(int N, int H, int W, int Ci, int Co) {
 
 WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int stride = 1) {
   WgradPlan p;
-  static const int tile_n = conv_env("T2O_WGRAD_TILE_N", 64);            // 128: 128 x 128 tiles -- twice the split-K partial bytes per workgroup
-  static const int tile_m = conv_env("T2O_WGRAD_TILE_M", 128);
+  constexpr int tile_n = 64, tile_m = 128;      // measured best (128 x 128 tiles: twice the split-K partial bytes per workgroup)
   p.tm = (Co % 128 == 0 && tile_m == 128) ? 128 : 64;
   p.tn = (Ci % 128 == 0 && tile_n == 128 && stride == 1) ? 128 : 64;      // (stride 2: two x planes per tile, 64 wide)
   p.tiles_m = Co / p.tm;
@@ -1236,8 +1229,7 @@ WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int stride = 1) {
   // ONE round of workgroups: 2 are resident per CU, 64 slots per XCD; a second, partly filled round would cost a
   // whole round's time.  (split, tile) units are dealt to the 8 XCDs in turn, 3 workgroups (kernel rows) each:
   // 21 units per XCD = 63 slots.  At least 8 stages of K per workgroup.
-  static const int units = conv_env("T2O_WGRAD_UNITS", 0);
-  int splits = (units > 0 ? units : 168) / (p.tiles_m * p.tiles_n);      // 168 units x 3 kernel rows = 504 workgroups
+  int splits = 168 / (p.tiles_m * p.tiles_n);      // 168 units x 3 kernel rows = 504 workgroups
   if (splits > p.total_stages / 8) splits = p.total_stages / 8;
   if (splits < 1) splits = 1;
   p.stages_per_split = (p.total_stages + splits - 1) / splits;

@@ -697,7 +697,7 @@ int env_int(const char* name, int dflt) {
 }
 
 Geometry launch_geometry(int B, int H, int W) {
-  static const int forced = env_int("T2O_ITERS", 0);   // tuning knob: pixel groups per thread
+  constexpr int forced = 0;                            // (pixel groups per thread: derived from the image size)
   return t2o::geometry(B, H, W, forced);
 }
 
@@ -705,7 +705,7 @@ Geometry launch_geometry(int B, int H, int W) {
 // per-operator geometry and the fused-chain geometry; kMaxChainSlots floats per block row.
 size_t ws_block_rows(const Geometry& g, int B, int H, int W) {
   int vec, iters, nblk;
-  chain_geometry(B, H, W, env_int("T2O_CHAIN_ITERS", 0), vec, iters, nblk, 1);   // the finer (vec 1) geometry bounds both
+  chain_geometry(B, H, W, 0, vec, iters, nblk, 1);   // the finer (vec 1) geometry bounds both
   return (size_t)(g.nblk_max > nblk ? g.nblk_max : nblk);
 }
 size_t ws_partials_floats(const Geometry& g, int B, int H, int W) { return (size_t)B * ws_block_rows(g, B, H, W) * kMaxChainSlots; }
@@ -755,7 +755,7 @@ void launch_point_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
 }
 // which stencil kernels run, and how many per-sample partial rows they write
 bool sharp_uses_strips(const Geometry& g) {
-  static const int mode = env_int("T2O_SHARP_STRIPS", 1);      // 0: LDS-tile kernels everywhere (A/B runs)
+  constexpr int mode = 1;                                       // LDS-free strips wherever W % 4 == 0 (tile kernels: ragged widths)
   return mode && g.vec_tile == 4;
 }
 bool sharp_bwd_uses_strips(const OpArgs&, const Geometry& g) { return sharp_uses_strips(g); }
@@ -867,7 +867,7 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
     // the 24 / 8 per-thread raw sums cost a wave + LDS reduction per workgroup: give each thread 4x the
     // pixels (48 vs 60 us for the color curve at bs=64 256x256); block rows only shrink, so the
     // workspace bound still holds
-    static const int mult = env_int("T2O_CURVE_BWD_ITERS", 4);
+    constexpr int mult = 4;
     const size_t groups = (size_t)H * W / g.vec;
     int it = g.iters * (mult > 0 ? mult : 1);
     if (it > 8) it = 8;
@@ -1172,9 +1172,9 @@ int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float*
   if (ns < 0) return fail(T2O_EUNSUPPORTED, "operator index not supported, or more than 64 segments");
   if (ns > 1 && !seg_bufs) return fail(T2O_EINVAL, "seg_bufs is null (see t2o_fused_sequence_buffers)");
   if (target && (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W))) return fail(T2O_EWORKSPACE, "workspace too small");
-  static const int forced = env_int("T2O_CHAIN_ITERS", 0);
+  constexpr int forced = 0;
   int vec, iters, nblk;
-  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CHAIN_VEC", 0));
+  chain_geometry(B, H, W, forced, vec, iters, nblk, 0);
   const Geometry g = launch_geometry(B, H, W);
   const size_t img_floats = (size_t)B * 3 * H * W;
   hipStream_t st = (hipStream_t)stream;
@@ -1213,11 +1213,11 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
   if (ns < 0) return fail(T2O_EUNSUPPORTED, "operator index not supported, or more than 64 segments");
   if (ns > 1 && (!seg_bufs || !gbuf)) return fail(T2O_EINVAL, "seg_bufs / gbuf is null");
   if (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
-  static const int forced = env_int("T2O_CHAIN_ITERS", 0);
+  constexpr int forced = 0;
   int vec, iters, nblk;
   // backward: one pixel per thread-iteration (measured 164 vs 182 us at bs=64 256x256: the LDS save
   // area halves, so more workgroups are resident); T2O_CHAIN_BWD_VEC=2 restores pixel pairs
-  chain_geometry(B, H, W, forced, vec, iters, nblk, env_int("T2O_CHAIN_BWD_VEC", 1));
+  chain_geometry(B, H, W, forced, vec, iters, nblk, 1);
   const size_t img_floats = (size_t)B * 3 * H * W;
   hipStream_t st = (hipStream_t)stream;
   bool has_identity = false;                     // identity rows are written by no kernel

@@ -614,7 +614,7 @@ def conv3x3s2_supported(x, weight, stride, padding):
 
 class _Conv3x3S2Fn(torch.autograd.Function):
     """conv2d(x, w, 3x3, stride 2, padding 1) on the hand-written kernels: 'F' forward, 's' data gradient, 'S' weight
-    gradient in T2O_OWN_CONV (the 3-channel stem: only its data gradient; the rest are library calls)."""
+    gradient in _CONV_OWN (a stem with an odd-sized image and gradients keeps the library call: its gradient kernels want an even image)."""
 
     @staticmethod
     def forward(ctx, x, weight, want_stats=False):
@@ -647,7 +647,7 @@ class _Conv3x3S2Fn(torch.autograd.Function):
         any_w = ctx.needs_input_grad[1] and not own_w and not stem_w and not is_stem
         mask = [ctx.needs_input_grad[0] and not own and not any_d, ctx.needs_input_grad[1] and not own_w and not stem_w and not any_w, False]
         dx = dw = None
-        if mask[0] or mask[1]:                               # (only a 3-channel stem with directions switched off by T2O_OWN_CONV)
+        if mask[0] or mask[1]:                               # (only a 3-channel stem on an odd-sized image)
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, mask)
         if own:
             dx = conv3x3s2_dgrad(dy, weight)
@@ -676,10 +676,10 @@ def conv3x3_supported(x, weight, stride, padding):
             and weight.shape[1] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
-# which directions of a supported layer run on the own kernels (A/B timing; the rest are library calls):
-# 'w' weight gradient, 'f' forward, 'd' data gradient (stride-1 layers); 'F' forward, 's' data gradient, 'S' weight
-# gradient of the stride-2 layers, 'T' forward and 'W' weight gradient of the 3-channel stem
-_CONV_OWN = os.environ.get('T2O_OWN_CONV', 'wfdFsSTW')
+# every direction of a supported layer runs on the own kernels (the letters name them: 'w' weight gradient, 'f' forward,
+# 'd' data gradient of the stride-1 layers; 'F' / 's' / 'S' the same for stride 2; 'T' forward and 'W' weight gradient
+# of the 3-channel stem).  Frozen since round 3 (was an A/B environment switch while the kernels were being written).
+_CONV_OWN = 'wfdFsSTW'
 
 
 def _own_direct(x):
@@ -772,7 +772,7 @@ def sequence_l1(img, ops, params, target):
 
 
 _prepared_chains = {}
-_CHAIN_JIT = os.environ.get('T2O_CHAIN_JIT', '1') != '0'
+_CHAIN_JIT = True        # (module switch for the tests; no environment knob)
 
 
 def prepare_fused_sequence(ops):

@@ -77,9 +77,15 @@ class GraphedEncoder:
         if plan is not None:
             plan.persistent_wt = False
             plan.weights_changed()
+        # the warm-up passes run real backwards: the trunk adds its parameter gradients into .grad inside its kernels
+        # (encoder.py into_grad) -- put the gradient buffers back as they were
+        saved_grads = [t.clone() for t in self.grads]
         try:
             self.slots = self._capture(sample_img, calls, warmup)
         finally:
+            with torch.no_grad():
+                for t, keep in zip(self.grads, saved_grads):
+                    t.copy_(keep)
             if plan is not None:
                 plan.persistent_wt = keep_wt
             with torch.no_grad():                      # warm-up and capture ran real forwards: undo their running statistics
@@ -151,8 +157,8 @@ class GraphedEpisodeStep:
     sampling, parameter heads, operator), END select, L1 and the whole backward -- as ONE hipGraph.  Outside stay only
     the gradient all-reduce and Adam.  Per step the host issues a handful of calls instead of ~3,000 kernel launches; the
     ~1,500 small launches of the decoder steps between the encoder passes, which ran ~4 us apart when enqueued one by
-    one, are graph nodes, and so is the request encoder (lang_encoder.masked_lstm: static shapes for a given request
-    length), forked onto a second stream inside the capture (Actor._encode_request), i.e. a parallel branch of the
+    one, are graph nodes, and so is the request encoder (static shapes for a given request
+    length), the step kernels of functional.lstm_layer, forked onto a second stream inside the capture (Actor._encode_request), i.e. a parallel branch of the
     graph beside the first image-encoder pass and, in the backward, beside the last one.
 
     The graph zeroes the flat gradient buffer first.  Sampling (`torch.rand` in actor.sample_categorical) and the

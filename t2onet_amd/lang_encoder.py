@@ -12,8 +12,8 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 import os
 
-# T2O_OWN_LSTM=0: the library's packed sequence call (MIOpen) on the GPU too (A/B timing, and what the tests compare with)
-_OWN_LSTM = os.environ.get('T2O_OWN_LSTM', '1') != '0'
+# T2O_LIBRARY_KERNELS=1 (the one kill-switch, see actor_resnet.py): the library's packed sequence call (MIOpen) on the GPU too
+_OWN_LSTM = os.environ.get('T2O_LIBRARY_KERNELS', '0') != '1'
 
 
 class Embedding(nn.Embedding):
@@ -91,17 +91,6 @@ class RNNEncoder(nn.Module):
                 if layer + 1 < rnn.num_layers and rnn.dropout > 0 and self.training:
                     layer_in = F.dropout(layer_in, rnn.dropout, True)
             return layer_in, (torch.cat(hs, 0), torch.cat(cs, 0)), embedded
-        if dev.type == 'cuda' and longest is not None and isinstance(self.rnn, nn.LSTM) and self.rnn.proj_size == 0 and self.rnn.batch_first:
-            # `longest` given (a hipGraph capture): the same arithmetic as the packed library call, unrolled with
-            # per-sample masks -- static shapes, no host-side lengths.  (The library's sequence entry point, MIOpen,
-            # blocks the host until its stream has drained: 16 ms forward and 21 ms backward of host stall per train
-            # step.  As ~2,000 torch launches per step this form costs 6 ms of GPU time, though: in-graph nodes still
-            # run ~6 us apart.)
-            dev_lengths = lengths if (lengths is not None and lengths.device == dev) else (input_labels != self.pad_id).sum(dim=1)
-            tokens = input_labels[:, :longest]
-            embedded = self.input_dropout(self.embedding(tokens))
-            outputs, state = masked_lstm(self.rnn, embedded, dev_lengths, self.training)
-            return outputs, state, embedded
         if lengths is None:
             lengths = (input_labels != self.pad_id).sum(dim=1).cpu()
         lengths = lengths.cpu()
@@ -123,39 +112,3 @@ class RNNEncoder(nn.Module):
         else:
             state = state[:, undo]
         return outputs, state, embedded
-
-
-def masked_lstm(rnn, x, lengths, training):
-    """nn.LSTM (batch_first, uni- or bidirectional, any depth) over zero-padded rows x (B,L,E) with per-sample lengths
-    (B,) on x's device: what pack_padded_sequence -> rnn -> pad_packed_sequence computes (lang_encoder.py:94-104 of the
-    reference), as L unrolled steps per layer and direction.  A sample's state stops changing after its last token
-    (forward direction) / starts from zero at its last token (reverse direction); outputs are zero at pads; the final
-    state is each sample's own.  Per layer and direction: ONE input GEMM for all steps, then per step one recurrent
-    GEMM and the fused gate kernel.  GPU tensors only (aten::_thnn_fused_lstm_cell, the gate kernel of torch.lstm_cell)."""
-    B, L, _ = x.shape
-    H, D = rnn.hidden_size, 2 if rnn.bidirectional else 1
-    valid = (torch.arange(L, device=x.device).unsqueeze(0) < lengths.unsqueeze(1)).unsqueeze(2)      # (B,L,1)
-    zero = x.new_zeros(B, H)
-    layer_in = x
-    hs, cs = [], []
-    for layer in range(rnn.num_layers):
-        outs = []
-        for d in range(D):
-            sfx = '_l%d%s' % (layer, '_reverse' if d else '')
-            w_ih, w_hh = getattr(rnn, 'weight_ih' + sfx), getattr(rnn, 'weight_hh' + sfx)
-            b_ih, b_hh = (getattr(rnn, 'bias_ih' + sfx), getattr(rnn, 'bias_hh' + sfx)) if rnn.bias else (None, None)
-            gi = F.linear(layer_in, w_ih)                      # (B,L,4H): every step's input gates in one GEMM
-            h, c = zero, zero
-            out_t = [None] * L
-            for t in (range(L - 1, -1, -1) if d else range(L)):
-                h2, c2, _ = torch.ops.aten._thnn_fused_lstm_cell(gi[:, t], F.linear(h, w_hh), c, b_ih, b_hh)
-                m = valid[:, t]
-                h, c = torch.where(m, h2, h), torch.where(m, c2, c)
-                out_t[t] = torch.where(m, h2, zero)
-            outs.append(torch.stack(out_t, 1))
-            hs.append(h)
-            cs.append(c)
-        layer_in = torch.cat(outs, 2) if D == 2 else outs[0]
-        if layer + 1 < rnn.num_layers and rnn.dropout > 0 and training:
-            layer_in = F.dropout(layer_in, rnn.dropout, True)
-    return layer_in, (torch.stack(hs, 0), torch.stack(cs, 0))

@@ -142,7 +142,7 @@ class Trainer:
         # the parameter heads add their gradients into the flat buffer inside their backward kernel (this trainer
         # zeroes it before every backward): 28 tensors x 5 decoder steps of autograd accumulation launches less
         executor = getattr(model, 'executor', None)
-        if executor is not None and self.grads.flat.is_cuda and os.environ.get('T2O_HEADS_GRAD_IN_PLACE', '1') != '0':
+        if executor is not None and self.grads.flat.is_cuda:
             executor.__dict__['heads_grad_in_place'] = True
 
     def _maybe_graph(self, img):
