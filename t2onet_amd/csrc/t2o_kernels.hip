@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void k_zero_floats(float* p, size_t n) {
 
 extern "C" {
 
-int t2o_abi_version(void) { return 3; }
+int t2o_abi_version(void) { return 4; }   // 4: round 3 additions (accumulate forms, 1x1 / any-size convolutions, LSTM, choose_op, run-time specialisation)
 #ifndef T2O_SRC_DIGEST
 #define T2O_SRC_DIGEST "unstamped"
 #endif

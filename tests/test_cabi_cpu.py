@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_argument_validation_without_a_device(lib):
-    assert lib.t2o_abi_version() == 3
+    assert lib.t2o_abi_version() == 4
     assert [lib.t2o_op_num_params(i) for i in range(-1, 9)] == [-1, 1, 1, 1, 24, 1, 8, 1, 1, -1]
     assert lib.t2o_workspace_bytes(0, 4, 4) == 0 and lib.t2o_workspace_bytes(64, 256, 256) > 0
     # null image / unsupported operator / bad mask are rejected before any launch

@@ -44,7 +44,7 @@ def gold(golden_dir):
 def test_library_is_loaded_natively():
     from t2onet_amd import _lib
     lib = _lib.load()
-    assert lib.t2o_abi_version() == 3
+    assert lib.t2o_abi_version() == 4
     with open('/proc/self/maps') as f:
         assert 'libt2onet_hip.so' in f.read()
 
