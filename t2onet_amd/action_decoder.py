@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as T
 from .attention import Attention
 
 
@@ -44,14 +45,17 @@ class Decoder(nn.Module):
         img_feat (B,d).  Returns (log-probabilities (B,1,n_tokens), new hidden, attention (B,1,L) or
         None, context (B,d))."""
         n = input_var.shape[0]
+        gpu = img_feat.is_cuda and img_feat.dtype == torch.float32
         token = self.embedding(input_var)                                   # (B,1,300)
-        visual = F.relu(self.vis_linear(img_feat)).unsqueeze(1)            # (B,1,d)
+        vis = T.linear_acc(img_feat, self.vis_linear.weight, self.vis_linear.bias) if gpu else self.vis_linear(img_feat)
+        visual = F.relu(vis).unsqueeze(1)                                   # (B,1,d)
         step_in = self.input_dropout(torch.cat((token, visual), dim=2))
         context, hidden = self._rnn_step(step_in, hidden)
         attn = None
         if self.use_attention:
             context, attn = self.attention(context, encoder_outputs)
-        scores = self.out_linear(context.reshape(n, self.hidden_size))
+        flat = context.reshape(n, self.hidden_size)
+        scores = T.linear_acc(flat, self.out_linear.weight, self.out_linear.bias) if gpu else self.out_linear(flat)
         return F.log_softmax(scores, dim=-1).view(n, 1, -1), hidden, attn, context.squeeze(1)
 
     def _rnn_step(self, step_in, hidden):
@@ -60,18 +64,25 @@ class Decoder(nn.Module):
         entry point, whose per-call host cost (~1.8 ms forward, more backward: descriptors, workspaces) made
         the five decoder steps the largest host-side item of the train step."""
         rnn = self.rnn
-        if not (isinstance(rnn, nn.LSTM) and step_in.shape[1] == 1 and isinstance(hidden, tuple)
+        if not (isinstance(rnn, nn.LSTM) and step_in.shape[1] == 1 and isinstance(hidden, (tuple, list))
                 and not rnn.bidirectional and rnn.proj_size == 0 and (rnn.dropout == 0 or not self.training)):
             return rnn(step_in, hidden)
         h0, c0 = hidden
-        x = step_in[:, 0]
+        unstacked = isinstance(h0, (list, tuple))       # per-layer tensors in, per-layer tensors out (no stack / select pairs:
+        x = step_in[:, 0]                               # their backward is a zero fill + copies + adds per decoder step)
         hs, cs = [], []
+        gpu = x.is_cuda and x.dtype == torch.float32
         for layer in range(rnn.num_layers):
             w = [getattr(rnn, '%s_l%d' % (name, layer)) for name in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')] \
                 if rnn.bias else [getattr(rnn, 'weight_ih_l%d' % layer), getattr(rnn, 'weight_hh_l%d' % layer), None, None]
-            x, c = torch._VF.lstm_cell(x, (h0[layer], c0[layer]), w[0], w[1], w[2], w[3])
+            if gpu:
+                x, c = T.lstm_cell_acc(x, h0[layer], c0[layer], w[0], w[1], w[2], w[3])
+            else:
+                x, c = torch._VF.lstm_cell(x, (h0[layer], c0[layer]), w[0], w[1], w[2], w[3])
             hs.append(x)
             cs.append(c)
+        if unstacked:
+            return x.unsqueeze(1), (hs, cs)
         return x.unsqueeze(1), (torch.stack(hs, 0), torch.stack(cs, 0))
 
     def _init_state(self, encoder_hidden):

@@ -210,14 +210,17 @@ class Actor(nn.Module):
         stack=False: pred_imgs is returned as the list of T images (no (B,T,3,H,W) copy; `state` is then None)."""
         B = img_x.shape[0]
         dev = img_x.device
-        hiddens = [tuple(h.detach() for h in hidden)]
+        hiddens = [tuple(h.detach() for h in hidden)] if stack else None
+        if isinstance(hidden, tuple) and torch.is_tensor(hidden[0]) and hidden[0].dim() == 3 and isinstance(self.decoder.rnn, nn.LSTM):
+            hidden = (list(hidden[0].unbind(0)), list(hidden[1].unbind(0)))      # per-layer tensors through the steps (Decoder._rnn_step)
         op_mask = self._op_mask_row.repeat(B, 1)                # device-resident: no host-to-device copy (a sync)
         pred_op = torch.full((B, 1), self.start_id, dtype=torch.long, device=dev)
         pred_ops, pred_params, pred_imgs, pred_masks = [], [], [], []
         for call in range(self.opt.decoder_max_len):
             feat = feat0 if (call == 0 and feat0 is not None) else self.image_features(img_x, call)
             logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
-            hiddens.append(tuple(h.detach() for h in hidden))
+            if stack:
+                hiddens.append(tuple(torch.stack([t.detach() for t in h], 0) if isinstance(h, list) else h.detach() for h in hidden))
             exec_op = None
             if logp.is_cuda and logp.dtype == torch.float32 and op_mask.shape[1] <= 32:
                 # exp, exploration floor, op-mask, renormalisation, draw / arg-max and the op-mask update: ONE launch

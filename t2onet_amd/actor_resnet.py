@@ -141,7 +141,7 @@ class ResNet(nn.Module):
                 from .encoder import trunk_forward
                 torch._foreach_add_(self._batch_counters(), 1)
                 x = trunk_forward(plan, x).mean((2, 3))
-                return self.fc(x.view(x.size(0), -1))
+                return T.linear_acc(x.view(x.size(0), -1), self.fc.weight, self.fc.bias)
         if self.conv1.weight.is_contiguous(memory_format=torch.channels_last) and x.is_cuda:
             # channels-last encoder (Actor.use_channels_last): one packed NHWC copy of the 3-channel image, then every
             # convolution and every fused batch-norm pass runs NHWC -- no layout transposes inside the encoder

@@ -28,5 +28,6 @@ class Attention(nn.Module):
         q = output.reshape(B, d)
         mix, attn = T.attention_core(q, context)
         comb = torch.cat((mix, q), dim=1)
-        out = torch.tanh(self.linear_out(comb)).view(B, 1, d)
+        lin = T.linear_acc(comb, self.linear_out.weight, self.linear_out.bias) if comb.is_cuda else self.linear_out(comb)
+        out = torch.tanh(lin).view(B, 1, d)
         return out, attn.view(B, 1, -1)

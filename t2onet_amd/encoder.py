@@ -52,10 +52,11 @@ class TrunkPlan:
             self.index[id(p)] = i
         self.bns = [resnet.bn1] + [m for b in blocks for m in ([b.bn1, b.bn2] + ([b.shortcut[1]] if len(b.shortcut) else []))]
         self.persistent_wt = False                             # Trainer: transformed weights live until weights_changed()
-        self._wt = None
+        self._wt = None                                        # persistent buffers (fixed addresses: captured graphs read them)
+        self._wt_valid = False
 
     def weights_changed(self):
-        self._wt = None
+        self._wt_valid = False
 
     def supported(self, img):
         """fp32 GPU image (N,3,H,W) with even H and W (the stem's gradient kernels).  Every later stage takes any size:
@@ -76,9 +77,9 @@ class TrunkPlan:
 
     def transformed(self, lib, st):
         """{id(conv): wt}: 3x3 stride-1 -> tap-mirrored transpose, 3x3 stride-2 -> plain transpose per tap, 1x1 -> transpose."""
-        if self._wt is not None:
+        if self.persistent_wt and self._wt_valid:
             return self._wt
-        wt = {}
+        wt = self._wt if (self.persistent_wt and self._wt is not None) else {}
         for b in self.blocks:
             convs = [(b.conv1, 9, 1 if b.conv1.stride[0] == 1 else 0), (b.conv2, 9, 1)]
             if len(b.shortcut):
@@ -86,11 +87,13 @@ class TrunkPlan:
             for conv, taps, flip in convs:
                 w = conv.weight
                 Co, Ci = w.shape[0], w.shape[1]
-                t = torch.empty(Ci * taps * Co, dtype=torch.float32, device=w.device)
+                t = wt.get(id(conv))
+                if t is None or t.device != w.device:
+                    t = torch.empty(Ci * taps * Co, dtype=torch.float32, device=w.device)
                 _lib.check(lib.t2o_conv_weight_transform(_ptr(w), _ptr(t), Co, Ci, taps, flip, st), 't2o_conv_weight_transform')
                 wt[id(conv)] = t
         if self.persistent_wt:
-            self._wt = wt
+            self._wt, self._wt_valid = wt, True
         return wt
 
 

@@ -1039,6 +1039,8 @@ class _LstmLayerFn(torch.autograd.Function):
         c_n = torch.stack([cnew[last[d], d] for d in range(D)], 0)
         ctx.save_for_backward(x, lengths, wih_cat, hnew, cnew, gates, *w_hh)
         ctx.meta = (B, L, E, H, D, has_bias)
+        ctx.params = w
+        ctx.acc = all(_persistent_grad(p) for p in w)
         return out, h_n, c_n
 
     @staticmethod
@@ -1059,8 +1061,21 @@ class _LstmLayerFn(torch.autograd.Function):
         _lib.check(rc, 't2o_lstm_layer_bwd')
         dgi = dgates.permute(2, 0, 1, 3).reshape(B * L, D * 4 * H)             # rows (b, t), columns (d, gate): gi's layout
         dx = (dgi @ wih_cat).view(B, L, E) if ctx.needs_input_grad[0] else None
-        dwih = dgi.t() @ x.reshape(B * L, E)                                   # (D*4H, E)
         dbias = dgi.sum(0) if has_bias else None
+        per = 4 if has_bias else 2
+        if ctx.acc:                                                            # parameter gradients added in place by the GEMMs
+            p, x2 = ctx.params, x.reshape(B * L, E)
+            for d in range(D):
+                p[per * d].grad.addmm_(dgi[:, d * 4 * H:(d + 1) * 4 * H].t(), x2)
+                if L > 1:
+                    dg = (dgates[1:, d] if d == 0 else dgates[:-1, d]).reshape((L - 1) * B, 4 * H)
+                    hp = (hnew[:-1, d] if d == 0 else hnew[1:, d]).reshape((L - 1) * B, H)
+                    p[per * d + 1].grad.addmm_(dg.t(), hp)
+            if has_bias:
+                torch._foreach_add_([p[per * d + k].grad for d in range(D) for k in (2, 3)],
+                                    [dbias[d * 4 * H:(d + 1) * 4 * H] for d in range(D) for _ in (2, 3)])
+            return (dx, None, None) + (None,) * len(p)
+        dwih = dgi.t() @ x.reshape(B * L, E)                                   # (D*4H, E)
         grads = []
         for d in range(D):
             # dW_hh = sum_t dgates[t]^T h_prev(t): h_prev of time t is the state after t-1 (direction 0) / t+1 (direction 1)
@@ -1162,3 +1177,86 @@ def conv1x1s2_supported(x, conv):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.bias is None and tuple(w.shape[2:]) == (1, 1)
             and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (0, 0) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
             and x.is_contiguous(memory_format=torch.channels_last))
+
+
+# ---- dense layers of the decoder with in-place gradient accumulation ----------------------------------------------------
+# The decoder's Linear layers and LSTM cells are library GEMMs with M = 64; what this adds is bookkeeping: with persistent
+# gradient buffers (the Trainer's flat buffer) the weight gradient is accumulated BY the GEMM that computes it (beta = 1)
+# and the bias gradient by one GEMV, so autograd hands out no parameter gradient and launches no accumulation kernel --
+# ~120 tiny launches per train step (each costs ~5 us of GPU time, inside a hipGraph as much as outside).
+def _persistent_grad(p):
+    g = p.grad
+    return g is not None and g.dtype == torch.float32 and g.shape == p.shape and g.stride() == p.stride() and g.is_cuda
+
+_ones_cache = {}
+
+
+def _ones(n, device):
+    key = (n, device)
+    t = _ones_cache.get(key)
+    if t is None or torch.cuda.is_current_stream_capturing():
+        t = torch.ones(n, dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _ones_cache[key] = t
+    return t
+
+
+class _LinearAccFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight, bias)
+        ctx.acc = _persistent_grad(weight) and (bias is None or _persistent_grad(bias))
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        weight, bias = ctx.params
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        if ctx.acc:
+            weight.grad.addmm_(dy.t(), x)
+            if bias is not None:
+                bias.grad.addmv_(dy.t(), _ones(dy.shape[0], dy.device))
+            return dx, None, None
+        return dx, dy.t() @ x, (dy.sum(0) if bias is not None else None)
+
+
+def linear_acc(x, weight, bias=None):
+    """F.linear(x, weight, bias) for 2-D x; with persistent .grad buffers the backward adds the parameter gradients in place."""
+    return _LinearAccFn.apply(x, weight, bias)
+
+
+class _LstmCellAccFn(torch.autograd.Function):
+    """torch.lstm_cell (one step of nn.LSTM, gate order i, f, g, o) as two GEMMs + the framework's fused gate kernel, with the
+    parameter gradients accumulated in place by the GEMMs of the backward (persistent .grad buffers)."""
+
+    @staticmethod
+    def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh):
+        ig, hg = x @ w_ih.t(), h @ w_hh.t()
+        hy, cy, ws = torch.ops.aten._thnn_fused_lstm_cell(ig, hg, c, b_ih, b_hh)
+        ctx.save_for_backward(x, h, c, cy, ws, w_ih, w_hh)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.acc = all(_persistent_grad(p) for p in ctx.params if p is not None)
+        return hy, cy
+
+    @staticmethod
+    def backward(ctx, ghy, gcy):
+        x, h, c, cy, ws, w_ih, w_hh = ctx.saved_tensors
+        p_ih, p_hh, b_ih, b_hh = ctx.params
+        has_bias = b_ih is not None
+        gg, gcx, gb = torch.ops.aten._thnn_fused_lstm_cell_backward_impl(ghy, gcy, c, cy, ws, has_bias)
+        dx = gg @ w_ih if ctx.needs_input_grad[0] else None
+        dh = gg @ w_hh if ctx.needs_input_grad[1] else None
+        if ctx.acc:
+            p_ih.grad.addmm_(gg.t(), x)
+            p_hh.grad.addmm_(gg.t(), h)
+            if has_bias:
+                torch._foreach_add_([b_ih.grad, b_hh.grad], [gb, gb])
+            return dx, dh, gcx, None, None, None, None
+        return dx, dh, gcx, gg.t() @ x, gg.t() @ h, (gb if has_bias else None), (gb if has_bias else None)
+
+
+def lstm_cell_acc(x, h, c, w_ih, w_hh, b_ih=None, b_hh=None):
+    return _LstmCellAccFn.apply(x, h, c, w_ih, w_hh, b_ih, b_hh)

@@ -24,7 +24,7 @@ from . import _lib
 
 
 class _Slot:
-    __slots__ = ('static_in', 'static_out', 'static_gout', 'static_gin', 'fwd', 'bwd', 'needs_gin')
+    __slots__ = ('static_in', 'static_out', 'static_gout', 'static_gin', 'fwd', 'bwd', 'needs_gin', 'plan')
 
 
 class _Replay(torch.autograd.Function):
@@ -39,6 +39,8 @@ class _Replay(torch.autograd.Function):
     def backward(ctx, gout):
         slot = ctx.slot
         slot.static_gout.copy_(gout)
+        if slot.plan is not None:                      # transformed weights at fixed addresses, refreshed once per optimiser step
+            slot.plan.transformed(_lib.load(), torch.cuda.current_stream(gout.device).cuda_stream)
         slot.bwd.replay()                              # parameter gradients are accumulated inside the graph
         return (slot.static_gin.detach() if slot.needs_gin else None), None, None
 
@@ -70,12 +72,12 @@ class GraphedEncoder:
         self.memsets_replaced = 0                      # memset nodes of the captured graphs turned into kernel nodes
         buffers = list(module.buffers())
         saved = [t.clone() for t in buffers]
-        # every backward graph must carry its own weight transforms (any subset of the slots may be replayed in a step):
-        # no transformed-weight cache across the captured calls
+        # With the plan's transformed-weight cache on (the Trainer: it calls weights_changed() after every optimiser step) the
+        # backward graphs READ the cache's fixed buffers and _Replay.backward refreshes them eagerly, once per step;
+        # without it every backward graph carries its own weight transforms (any subset of slots may be replayed in a step).
         plan = module.trunk_plan() if hasattr(module, 'trunk_plan') else None
-        keep_wt = plan.persistent_wt if plan is not None else False
+        self.static_plan = plan if (plan is not None and plan.persistent_wt) else None
         if plan is not None:
-            plan.persistent_wt = False
             plan.weights_changed()
         # the warm-up passes run real backwards: the trunk adds its parameter gradients into .grad inside its kernels
         # (encoder.py into_grad) -- put the gradient buffers back as they were
@@ -87,7 +89,7 @@ class GraphedEncoder:
                 for t, keep in zip(self.grads, saved_grads):
                     t.copy_(keep)
             if plan is not None:
-                plan.persistent_wt = keep_wt
+                plan.weights_changed()
             with torch.no_grad():                      # warm-up and capture ran real forwards: undo their running statistics
                 for t, keep in zip(buffers, saved):
                     t.copy_(keep)
@@ -109,6 +111,7 @@ class GraphedEncoder:
         slots = []
         for k in range(calls):
             s = _Slot()
+            s.plan = self.static_plan
             s.needs_gin = k > 0                        # call 0 sees the input image: no gradient needed
             s.static_in = sample_img.detach().clone().requires_grad_(True)
             s.fwd = torch.cuda.CUDAGraph(keep_graph=True)
@@ -127,7 +130,8 @@ class GraphedEncoder:
                 else:
                     s.static_gin = None
                 have = [(acc, gi) for acc, gi in zip(self.grads, g) if gi is not None]
-                torch._foreach_add_([a for a, _ in have], [b for _, b in have])
+                if have:                                # (all in place already: trunk kernels + functional.linear_acc)
+                    torch._foreach_add_([a for a, _ in have], [b for _, b in have])
             self.memsets_replaced += _harden(s.bwd)
         for s in slots:
             # keep the buffers, drop the autograd graph: it holds the parameters' AccumulateGrad nodes, which were

@@ -1,4 +1,4 @@
-"""N graphed episode train steps and nothing else (for rocprofv3 --kernel-trace): python tools/step_only.py [steps] [graph_step 0|1]"""
+"""N graphed episode train steps and nothing else (for rocprofv3 --kernel-trace): python tools/step_only.py [steps] [graph_step 0|1] [graph_encoder 0|1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ torch.manual_seed(10)
 model = Actor(opt).to(dev).train()
 model.use_channels_last()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-tr = Trainer(model, opt, graph_encoder=True, graph_step=(sys.argv[2] != '0') if len(sys.argv) > 2 else True)
+tr = Trainer(model, opt, graph_encoder=(sys.argv[3] != '0') if len(sys.argv) > 3 else True, graph_step=(sys.argv[2] != '0') if len(sys.argv) > 2 else True)
 g = torch.Generator().manual_seed(10)
 B, H, W = 64, 256, 256
 img = torch.rand(B, 3, H, W, generator=g).to(dev)
