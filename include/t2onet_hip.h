@@ -403,6 +403,22 @@ size_t t2o_conv3x3_any_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co
 int t2o_conv3x3_any_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                                int N, int H, int W, int Ci, int Co, int stride, int accumulate, void* stream);
 
+/* ---- Winograd F(2x2, 3x3) transforms for the stride-1 3x3 convolutions of the deep encoder stages (t2o_winograd.hip;
+ * models/actor_resnet.py:24-44, the 256- and 512-channel BasicBlocks).  y = conv2d(x, w, None, 1, 1), NHWC, H and W even:
+ *   U (16, Co, Ci) = t2o_wino_weight_transform(w (Co,3,3,Ci), Cn = Co, Ck = Ci)          once per weight update
+ *   V (16, T, Ci)  = t2o_wino_input_transform(x (N,H,W,Ci)),  T = N * H/2 * W/2
+ *   M (16, T, Co)  = 16 plain GEMMs  M[xi] = V[xi] * U[xi]^T                               (caller: any fp32 GEMM)
+ *   y (N,H,W,Co)   = t2o_wino_output_transform(M, addend, y, stats)
+ * addend: null or (N,H,W,Co), added to y (the gradient through a block's identity shortcut, as in
+ * t2o_conv3x3_dgrad_pre_nhwc); stats: null or (t2o_wino_stats_rows(N,H,W,Co), 2, Co) per-workgroup channel sums / sums
+ * of squares of y for t2o_bn_relu_nhwc_fwd_partials (as t2o_conv3x3_fwd_stats_nhwc).  The data gradient is the same
+ * pipeline on dy with U = t2o_wino_weight_transform(wt, Cn = Ci, Ck = Co), wt = t2o_conv_weight_transform(w, ., Co, Ci, 9, 1).
+ * C: a power of two in [4, 1024]; all tensors 16-byte aligned. */
+int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* stream);
+int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
+int t2o_wino_stats_rows(int N, int H, int W, int C);
+int t2o_wino_output_transform(const float* M, const float* addend, float* y, float* stats, int N, int H, int W, int C, void* stream);
+
 /* ---- LSTM layers of the request encoder (models/lang_encoder.py:70-113: 2-layer bidirectional LSTM over packed, i.e.
  * per-sample-length, sequences; nn.LSTM gate order i, f, g, o), one launch per time step for both directions (t2o_rnn.hip).
  *   gi    (B, L, D*4H)  x W_ih^T for every step and direction (a library GEMM), no bias

@@ -1260,3 +1260,39 @@ class _LstmCellAccFn(torch.autograd.Function):
 
 def lstm_cell_acc(x, h, c, w_ih, w_hh, b_ih=None, b_hh=None):
     return _LstmCellAccFn.apply(x, h, c, w_ih, w_hh, b_ih, b_hh)
+
+
+# ---- Winograd F(2x2,3x3) for the stride-1 3x3 convolutions of the deep stages (t2o_winograd.hip) -----------------------
+def wino_weight(w_taps_last, Cn, Ck):
+    """(Cn,3,3,Ck) filter bank (channels-last conv weight, or the mirrored transpose from conv_weight_transform) -> U (16,Cn,Ck)."""
+    U = torch.empty((16, Cn, Ck), dtype=torch.float32, device=w_taps_last.device)
+    _lib.check(_lib.load().t2o_wino_weight_transform(_ptr(w_taps_last), _ptr(U), Cn, Ck, _stream(U.device)), 't2o_wino_weight_transform')
+    return U
+
+
+def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None):
+    """x (N,H,W,Ci) NHWC buffer, U (16,Co,Ci) -> y (N,H,W,Co) (+ addend) [, stats rows for the batch norm that follows]."""
+    lib = _lib.load()
+    dev = x.device
+    st = _stream(dev)
+    Co, Ci = U.shape[1], U.shape[2]
+    T = N * (H // 2) * (W // 2)
+    V = torch.empty((16, T, Ci), dtype=torch.float32, device=dev)
+    _lib.check(lib.t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, Ci, st), 't2o_wino_input_transform')
+    M = torch.bmm(V, U.transpose(1, 2))                   # 16 plain fp32 GEMMs (T x Ci) x (Ci x Co): the library's batched GEMM
+    y = out if out is not None else torch.empty((N, H, W, Co), dtype=torch.float32, device=dev)
+    stats = torch.empty((lib.t2o_wino_stats_rows(N, H, W, Co), 2, Co), dtype=torch.float32, device=dev) if want_stats else None
+    _lib.check(lib.t2o_wino_output_transform(_ptr(M), _ptr(addend), _ptr(y), _ptr(stats), N, H, W, Co, st), 't2o_wino_output_transform')
+    return y, stats
+
+
+def conv3x3_winograd(x, weight, addend=None):
+    """conv2d(x, weight, None, 1, 1) (+ addend) through the Winograd pipeline; x (N,Ci,H,W) any layout, returns channels_last."""
+    _need_gpu(x, weight)
+    N, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    U = wino_weight(weight.permute(0, 2, 3, 1).contiguous(), Co, Ci)
+    ad = None if addend is None else addend.permute(0, 2, 3, 1).contiguous()
+    y, _ = wino_conv_nhwc(xh, U, N, H, W, ad)
+    return y.permute(0, 3, 1, 2)

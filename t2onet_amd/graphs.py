@@ -31,6 +31,8 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, _anchor, slot):
         slot.static_in.copy_(img)
+        if slot.plan is not None:                      # (Winograd-transformed filters: refreshed once per optimiser step)
+            slot.plan.wino_forward(_lib.load(), torch.cuda.current_stream(img.device).cuda_stream)
         slot.fwd.replay()
         ctx.slot = slot
         return slot.static_out.detach()

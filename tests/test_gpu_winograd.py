@@ -1,0 +1,79 @@
+"""Winograd F(2x2,3x3) path of the deep encoder stages (t2o_winograd.hip: input / filter / output transforms around 16
+plain GEMMs) against F.conv2d and its data gradient in fp64 (models/actor_resnet.py:27-44, the 256- / 512-channel layers)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+# (N, Ci, Co, H, W): the two encoder stages at small batch, non-square maps, one tile per image, unequal channel counts,
+# more tiles than the output transform's workgroup cap covers in one sweep
+SHAPES = [(4, 256, 256, 16, 16), (3, 512, 512, 8, 8), (2, 256, 512, 6, 10), (5, 64, 128, 2, 2), (1, 128, 64, 2, 12), (40, 256, 256, 16, 16)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_winograd_forward_matches_conv2d_fp64(shape):
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    x = synth.uniform((N, Ci, H, W), 1701, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 1702, -1.0, 1.0)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    dev = torch.device('cuda:0')
+    y = T.conv3x3_winograd(x.to(dev), w.to(dev))
+    assert y.shape == (N, Co, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    # (Winograd's transforms add a few roundings to the direct kernel's: 1e-5 of the output scale still holds)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize('shape', SHAPES[:4])
+def test_winograd_data_gradient_with_addend_matches_fp64(shape):
+    """dx = conv_transpose(dy, w) + addend through the same pipeline on dy with the mirrored, transposed filter."""
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    dy = synth.uniform((N, Co, H, W), 1711, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 1712, -1.0, 1.0)
+    ad = synth.uniform((N, Ci, H, W), 1713, -1.0, 1.0)
+    x64 = torch.zeros(N, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(x64, w.double(), None, 1, 1) * dy.double()).sum().backward()
+    ref = x64.grad + ad.double()
+    dev = torch.device('cuda:0')
+    wg = w.to(dev).contiguous(memory_format=torch.channels_last)
+    wt = T.conv_weight_transform(wg, 9, True)                                  # (Ci,3,3,Co) mirrored transpose
+    U = T.wino_weight(wt, Ci, Co)
+    dyh = dy.to(dev).permute(0, 2, 3, 1).contiguous()
+    adh = ad.to(dev).permute(0, 2, 3, 1).contiguous()
+    dx, _ = T.wino_conv_nhwc(dyh, U, N, H, W, adh)
+    got = dx.permute(0, 3, 1, 2).cpu().numpy()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got, ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize('shape', [(4, 256, 256, 16, 16), (3, 512, 512, 8, 8), (40, 256, 256, 16, 16)])
+def test_winograd_output_leaves_the_batch_norm_statistics(shape):
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    dev = torch.device('cuda:0')
+    x = synth.uniform((N, H, W, Ci), 1721, -1.0, 1.0).to(dev)
+    w = synth.uniform((Co, 3, 3, Ci), 1722, -0.1, 0.1).to(dev)
+    U = T.wino_weight(w, Co, Ci)
+    y0, none = T.wino_conv_nhwc(x, U, N, H, W)
+    y, st = T.wino_conv_nhwc(x, U, N, H, W, None, True)
+    assert none is None and torch.equal(y, y0) and st.shape[1:] == (2, Co)
+    y64 = y.double()
+    ref = torch.stack([y64.sum((0, 1, 2)), (y64 * y64).sum((0, 1, 2))]).cpu().numpy()
+    np.testing.assert_allclose(st.double().sum(0).cpu().numpy(), ref, rtol=2e-6, atol=2e-6 * np.abs(ref).max())
+    assert torch.equal(st, T.wino_conv_nhwc(x, U, N, H, W, None, True)[1])      # fixed summation order
+
+
+def test_transforms_refuse_shapes_they_do_not_take():
+    import t2onet_amd.functional as T
+    dev = torch.device('cuda:0')
+    U = torch.zeros(16, 64, 64, device=dev)
+    for (N, H, W) in ((1, 3, 4), (1, 4, 5)):
+        with pytest.raises(RuntimeError):
+            T.wino_conv_nhwc(torch.zeros(N, H, W, 64, device=dev), U, N, H, W)
+    with pytest.raises(RuntimeError):                                          # channel count not a power of two
+        T.wino_conv_nhwc(torch.zeros(1, 4, 4, 96, device=dev), torch.zeros(16, 64, 96, device=dev), 1, 4, 4)
