@@ -417,6 +417,11 @@ int t2o_conv3x3_any_wgrad_nhwc(const float* x, const float* dy, float* dw, void*
 int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* stream);
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
 int t2o_wino_stats_rows(int N, int H, int W, int C);
+/* weight gradient in the transformed domain: Ad (16,T,Co) = t2o_wino_dy_transform(dy (N,H,W,Co));
+ * dU[xi] (Co,Ci) = Ad[xi]^T * V[xi] (16 plain GEMMs over the tiles, V as in the forward);
+ * dw (Co,3,3,Ci) (+)= t2o_wino_dw_transform(dU) = G^T dU G. */
+int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream);
+int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int accumulate, void* stream);
 int t2o_wino_output_transform(const float* M, const float* addend, float* y, float* stats, int N, int H, int W, int C, void* stream);
 
 /* ---- LSTM layers of the request encoder (models/lang_encoder.py:70-113: 2-layer bidirectional LSTM over packed, i.e.

@@ -154,6 +154,63 @@ __global__ __launch_bounds__(kThreads) void k_wino_weight(const float* __restric
   }
 }
 
+// WEIGHT GRADIENT in the transformed domain: dg = G^T [ sum_t (A dY A^T)[t] (x) (B^T d B)[t] ] G per (co, ci):
+//   Ad (16, T, Co) = A dY A^T of the 2 x 2 output-gradient tiles (A = [[1,0],[1,1],[1,-1],[0,-1]])
+//   dU[xi] (Co, Ci) = Ad[xi]^T * V[xi]       16 GEMMs with K = T, V = the forward's transformed input (kept, or redone)
+//   dw (Co,3,3,Ci) (+)= G^T dU G
+__global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ Ad, int N, int H, int W, int C) {
+  const int q = C >> 2, TH = H >> 1, TW = W >> 1;
+  const size_t T = (size_t)N * TH * TW;
+  const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= T * q) return;
+  const size_t t = idx / q;
+  const int cq = (int)(idx - t * q);
+  const int n = (int)(t / (TH * TW)), rem = (int)(t - (size_t)n * TH * TW), th = rem / TW, tw = rem - th * TW;
+  const float* p = dy + (((size_t)n * H + 2 * th) * W + 2 * tw) * C + 4 * cq;
+  const float4 d00 = ld4(p), d01 = ld4(p + C), d10 = ld4(p + (size_t)W * C), d11 = ld4(p + (size_t)W * C + C);
+  // A d: rows (d0, d0 + d1, d0 - d1, -d1)
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const float4 r[4][2] = {{d00, d01}, {add4(d00, d10), add4(d01, d11)}, {sub4(d00, d10), sub4(d01, d11)}, {sub4(zero, d10), sub4(zero, d11)}};
+  const size_t plane = T * C;
+  float* o = Ad + t * C + 4 * cq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st4(o + (size_t)(4 * i + 0) * plane, r[i][0]);
+    st4(o + (size_t)(4 * i + 1) * plane, add4(r[i][0], r[i][1]));
+    st4(o + (size_t)(4 * i + 2) * plane, sub4(r[i][0], r[i][1]));
+    st4(o + (size_t)(4 * i + 3) * plane, sub4(zero, r[i][1]));
+  }
+}
+
+// dU (16, Co, Ci) -> dw (Co,3,3,Ci) = G^T dU G (acc: added to dw)
+__global__ __launch_bounds__(kThreads) void k_wino_dw(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci, int acc) {
+  const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x, total = (size_t)Co * Ci;
+  if (idx >= total) return;
+  const int co = (int)(idx / Ci), ci = (int)(idx - (size_t)co * Ci);
+  float u[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) u[a][b] = dU[(size_t)(4 * a + b) * total + idx];
+  // G^T u: rows (u0 + (u1 + u2)/2, (u1 - u2)/2, (u1 + u2)/2 + u3)
+  float r[3][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const float h = 0.5f * (u[1][b] + u[2][b]);
+    r[0][b] = u[0][b] + h;
+    r[1][b] = 0.5f * (u[1][b] - u[2][b]);
+    r[2][b] = h + u[3][b];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float h = 0.5f * (r[a][1] + r[a][2]);
+    const float g0 = r[a][0] + h, g1 = 0.5f * (r[a][1] - r[a][2]), g2 = h + r[a][3];
+    float* o = dw + ((size_t)co * 9 + a * 3) * Ci + ci;
+    if (acc) { o[0] += g0; o[Ci] += g1; o[2 * (size_t)Ci] += g2; }
+    else { o[0] = g0; o[Ci] = g1; o[2 * (size_t)Ci] = g2; }
+  }
+}
+
 bool wino_shape_ok(int N, int H, int W, int C) {
   return N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C >= 4 && C <= 1024 && (C & (C - 1)) == 0 &&
          (size_t)N * H * W * C < ((size_t)1 << 40);
@@ -184,6 +241,21 @@ int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int 
   const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / 4);
   k_wino_input<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(x, V, N, H, W, C);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_input_transform: launch failed");
+}
+
+int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream) {
+  if (!dy || !Ad || !wino_shape_ok(N, H, W, C)) return set_error(T2O_EINVAL, "wino_dy_transform: null pointer or bad shape (H, W even; C a power of two in [4, 1024])");
+  if ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(Ad)) & 15) return set_error(T2O_EINVAL, "wino_dy_transform: tensors must be 16-byte aligned");
+  const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  k_wino_dy<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, Ad, N, H, W, C);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transform: launch failed");
+}
+
+int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int accumulate, void* stream) {
+  if (!dU || !dw || Co <= 0 || Ci <= 0) return set_error(T2O_EINVAL, "wino_dw_transform: null pointer or bad shape");
+  const size_t total = (size_t)Co * Ci;
+  k_wino_dw<<<(unsigned)((total + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dU, dw, Co, Ci, accumulate ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dw_transform: launch failed");
 }
 
 int t2o_wino_stats_rows(int N, int H, int W, int C) { return wino_shape_ok(N, H, W, C) ? output_blocks(N, H, W, C) : 0; }

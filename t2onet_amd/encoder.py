@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from .functional import _need_gpu, _ptr, _stream, _conv_workspace, wino_conv_nhwc
+from .functional import _need_gpu, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
@@ -172,6 +172,7 @@ class _TrunkFn(torch.autograd.Function):
         conv_ws = _conv_workspace(dev, 64 << 10)               # zero region only (registered once per device: not cleared per call)
         saved = []                                             # per layer: what the backward needs
         uf = plan.wino_forward(lib, st) if _WINOGRAD else {}
+        kept_v = {}
 
         def conv3(x, conv, Nn, Hi, Wi, want_stats):
             """3x3, padding 1, stride 1 / 2 on (Nn,Hi,Wi,Ci) -> (y (Nn,Ho,Wo,Co), stats)."""
@@ -180,7 +181,10 @@ class _TrunkFn(torch.autograd.Function):
             s = conv.stride[0]
             Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
             if plan.wino(conv, Hi, Wi):
-                return wino_conv_nhwc(x, uf[id(conv)], Nn, Hi, Wi, None, True)
+                keep = []
+                y, stats = wino_conv_nhwc(x, uf[id(conv)], Nn, Hi, Wi, None, True, keep_v=keep)
+                kept_v[id(conv)] = keep[0]                     # (4x the layer's input: its weight gradient starts from it)
+                return y, stats
             y = _nhwc(Nn, Ho, Wo, Co, dev)
             if _fast_direct(s, Hi, Wi, Wo):
                 stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(Nn, Ho, Wo, Co, s), 2, Co), dtype=torch.float32, device=dev)
@@ -228,6 +232,7 @@ class _TrunkFn(torch.autograd.Function):
             x, Hc, Wc = out, Hn, Wn
         ctx.plan, ctx.img, ctx.stem, ctx.saved, ctx.planar = plan, img, stem, saved, planar
         ctx.a0 = a0
+        ctx.kept_v = kept_v
         # persistent, dense gradient buffers for every parameter: the kernels accumulate into them
         ctx.into_grad = all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape
                             and p.grad.stride() == p.stride() for p in plan.params)
@@ -265,6 +270,10 @@ class _TrunkFn(torch.autograd.Function):
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             s = conv.stride[0]
+            if plan.wino(conv, Hi, Wi):
+                V = ctx.kept_v.pop(id(conv), None)
+                wino_wgrad_nhwc(V if V is not None else wino_input(x, N, Hi, Wi), dy, g(w), N, Hi, Wi, acc)
+                return
             if Wn % 4 == 0 and (s == 1 or (Hi % 2 == 0 and Wi % 2 == 0)):
                 need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)
                 ws = torch.empty(need, dtype=torch.uint8, device=dev)

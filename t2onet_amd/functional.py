@@ -1270,8 +1270,28 @@ def wino_weight(w_taps_last, Cn, Ck):
     return U
 
 
-def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None):
-    """x (N,H,W,Ci) NHWC buffer, U (16,Co,Ci) -> y (N,H,W,Co) (+ addend) [, stats rows for the batch norm that follows]."""
+def wino_input(x, N, H, W):
+    """x (N,H,W,C) -> V (16, T, C), the transformed 4x4 input patches of the T = N*H/2*W/2 output tiles."""
+    C = x.shape[-1]
+    V = torch.empty((16, N * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, C, _stream(x.device)), 't2o_wino_input_transform')
+    return V
+
+
+def wino_wgrad_nhwc(V, dy, dw, N, H, W, accumulate):
+    """dw (Co,3,3,Ci) (+)= weight gradient of the convolution whose transformed input is V (16,T,Ci), for dy (N,H,W,Co)."""
+    lib = _lib.load()
+    st = _stream(dy.device)
+    Co, Ci = dy.shape[-1], V.shape[2]
+    Ad = torch.empty((16, V.shape[1], Co), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.t2o_wino_dy_transform(_ptr(dy), _ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transform')
+    dU = torch.bmm(Ad.transpose(1, 2), V)                 # 16 plain fp32 GEMMs (Co x T) x (T x Ci)
+    _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, 1 if accumulate else 0, st), 't2o_wino_dw_transform')
+
+
+def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_v=None):
+    """x (N,H,W,Ci) NHWC buffer, U (16,Co,Ci) -> y (N,H,W,Co) (+ addend) [, stats rows for the batch norm that follows].
+    keep_v: a list that receives V (the weight gradient reuses it: wino_wgrad_nhwc)."""
     lib = _lib.load()
     dev = x.device
     st = _stream(dev)
@@ -1279,6 +1299,8 @@ def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None):
     T = N * (H // 2) * (W // 2)
     V = torch.empty((16, T, Ci), dtype=torch.float32, device=dev)
     _lib.check(lib.t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, Ci, st), 't2o_wino_input_transform')
+    if keep_v is not None:
+        keep_v.append(V)
     M = torch.bmm(V, U.transpose(1, 2))                   # 16 plain fp32 GEMMs (T x Ci) x (Ci x Co): the library's batched GEMM
     y = out if out is not None else torch.empty((N, H, W, Co), dtype=torch.float32, device=dev)
     stats = torch.empty((lib.t2o_wino_stats_rows(N, H, W, Co), 2, Co), dtype=torch.float32, device=dev) if want_stats else None

@@ -77,3 +77,23 @@ def test_transforms_refuse_shapes_they_do_not_take():
             T.wino_conv_nhwc(torch.zeros(N, H, W, 64, device=dev), U, N, H, W)
     with pytest.raises(RuntimeError):                                          # channel count not a power of two
         T.wino_conv_nhwc(torch.zeros(1, 4, 4, 96, device=dev), torch.zeros(16, 64, 96, device=dev), 1, 4, 4)
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_winograd_weight_gradient_matches_fp64(shape, accumulate):
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    x = synth.uniform((N, Ci, H, W), 1731, -1.0, 1.0)
+    dy = synth.uniform((N, Co, H, W), 1732, -1.0, 1.0)
+    w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(x.double(), w64, None, 1, 1) * dy.double()).sum().backward()
+    ref = w64.grad
+    dev = torch.device('cuda:0')
+    V = T.wino_input(x.to(dev).permute(0, 2, 3, 1).contiguous(), N, H, W)
+    start = synth.uniform((Co, 3, 3, Ci), 1733, -1.0, 1.0).to(dev)
+    dw = start.clone()
+    T.wino_wgrad_nhwc(V, dy.to(dev).permute(0, 2, 3, 1).contiguous(), dw, N, H, W, accumulate)
+    got = (dw - start if accumulate else dw).permute(0, 3, 1, 2).cpu().numpy()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got, ref.float().numpy(), rtol=1e-5, atol=(3e-5 if accumulate else 1e-5) * scale)
