@@ -584,8 +584,8 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
     if dist is not None:                                   # identical replicas
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
-    want_graph = os.environ.get('T2O_GRAPH_ENCODER', '1') != '0'
-    want_step_graph = want_graph and os.environ.get('T2O_GRAPH_STEP', '0') != '0'
+    want_graph = os.environ.get('T2O_GRAPH_ENCODER', '0') != '0'
+    want_step_graph = os.environ.get('T2O_GRAPH_STEP', '0') != '0'
     tr = Trainer(model, opt, graph_encoder=want_graph, graph_step=want_step_graph)
     g = torch.Generator().manual_seed(10 + ctx['rank'])
     img = torch.rand(B, 3, H, W, generator=g).to(device)
@@ -644,10 +644,11 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
 
 def conv_kernel_table(B, H, W, device, reps=40):
     """HIP-event timings (on the launch stream) of the train step's dominant kernel, k_conv3x3_fwd<2,1>: the forward
-    and the data gradient of the stride-1 3x3 convolutions of the encoder's 64-, 128- and 256-channel stages
-    (models/actor_resnet.py:27-44) at this batch / image size -- 3 + 3 launches per stage and encoder pass, each
-    2 * 9 * C * C * pixels FLOP (19.33 GFLOP at bs=64 256x256 in every stage).  The 512-channel stage runs the
-    128-pixel-tile template <1,1> and is listed beside it."""
+    and the data gradient of the stride-1 3x3 convolutions of the encoder's 64- and 128-channel stages
+    (models/actor_resnet.py:27-44) at this batch / image size -- 60 launches per train step, each 2 * 9 * C * C * pixels
+    FLOP (19.33 GFLOP at bs=64 256x256 in every stage).  The 256- and 512-channel stages run Winograd F(2x2,3x3) in the
+    train step (t2o_winograd.hip: transform kernels around 16 library GEMMs of 8.6 GFLOP); their direct kernels and the
+    Winograd pipeline are both listed, the latter with the DIRECT convolution's FLOP as the numerator ("effective")."""
     import torch
     from t2onet_amd import _lib
     import t2onet_amd.functional as T
@@ -681,16 +682,43 @@ def conv_kernel_table(B, H, W, device, reps=40):
             ms = sum(a.elapsed_time(b) for a, b in evs) / (len(evs) * group)
             rows['%s_c%d_%dx%d' % (name, C, h, w)] = {'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2),
                                                    'kernel': 'k_conv3x3_fwd<2,1>' if C < 512 else 'k_conv3x3_fwd<1,1>'}
-    dom = [v for v in rows.values() if v['kernel'] == 'k_conv3x3_fwd<2,1>']
+    for C, div in ((256, 16), (512, 32)):
+        h, w = H // div, W // div
+        x = torch.rand(B, h, w, C, generator=g).to(device) - 0.5
+        wt = (torch.rand(C, 3, 3, C, generator=g).to(device) - 0.5) * 0.05
+        U = T.wino_weight(wt, C, C)
+        y = torch.empty_like(x)
+        dw = torch.zeros_like(wt)
+        V = T.wino_input(x, B, h, w)
+        flop = 2.0 * 9 * C * C * B * h * w
+        for name, fn in (('wino_fwd', lambda: T.wino_conv_nhwc(x, U, B, h, w, None, True, out=y)),
+                         ('wino_wgrad', lambda: T.wino_wgrad_nhwc(V, x, dw, B, h, w, True))):
+            for _ in range(3):
+                fn()
+            evs = []
+            for _ in range(max(reps // 10, 2)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in evs) / (len(evs) * 10)
+            rows['%s_c%d_%dx%d' % (name, C, h, w)] = {
+                'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2), 'effective': True,
+                'kernel': ('k_wino_input + 16 library GEMMs + k_wino_output<stats>' if name == 'wino_fwd'
+                           else 'k_wino_dy + 16 library GEMMs + k_wino_dw (V kept from the forward)')}
+    dom = [v for k, v in rows.items() if v['kernel'] == 'k_conv3x3_fwd<2,1>' and ('_c64_' in k or '_c128_' in k)]
     avg_ms = sum(v['ms'] for v in dom) / len(dom)
     flop = dom[0]['GFLOP'] * 1e9
     tf = flop / avg_ms / 1e9
-    return rows, {'bound': 'mfma', 'kernel': 'k_conv3x3_fwd<2,1>', 'of': 'train step (encoder 3x3 stride-1 convolutions, forward + data gradient, stages 1-3)',
+    return rows, {'bound': 'mfma', 'kernel': 'k_conv3x3_fwd<2,1>', 'of': 'train step (encoder 3x3 stride-1 convolutions, forward + data gradient, 64- and 128-channel stages)',
                   'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(tf / FP32_MATRIX_PEAK_TF, 4),
                   'traffic': None, 'algorithmic_flop_per_launch': flop, 'avg_launch_ms': round(avg_ms, 5),
-                  'launches_per_step': 90,
+                  'launches_per_step': 60,
                   'note': 'dominant kernel of the train step (about a quarter of its GPU time): algorithmic FLOP per launch = '
-                          '2 x 9 x C^2 x pixels (SURVEY 8(d)), duration = mean of HIP-event timed launches over the six '
+                          '2 x 9 x C^2 x pixels (SURVEY 8(d)), duration = mean of HIP-event timed launches over the four '
                           '(stage, direction) shapes it runs with, equally often; v_mfma_f32_32x32x2_f32 dense peak'}
 
 

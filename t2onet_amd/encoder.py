@@ -28,6 +28,7 @@ from .functional import _need_gpu, _ptr, _stream, _conv_workspace, wino_conv_nhw
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
+_WINO_MIN_C = int(os.environ.get('T2O_WINOGRAD_MIN_C', '256'))
 
 
 def _fast_direct(stride, Hi, Wi, Wo):
@@ -70,11 +71,11 @@ class TrunkPlan:
         """Winograd F(2x2,3x3) for this layer?  Stride 1, even maps, >= 256 channels: where 16 GEMMs of 8.6 GFLOP plus two
         transform passes over 4x the activation beat the direct kernel's 19.3 GFLOP (t2o_winograd.hip)."""
         w = conv.weight
-        return (_WINOGRAD and conv.stride[0] == 1 and H % 2 == 0 and W % 2 == 0 and w.shape[0] >= 256 and w.shape[1] >= 256
+        return (_WINOGRAD and conv.stride[0] == 1 and H % 2 == 0 and W % 2 == 0 and w.shape[0] >= _WINO_MIN_C and w.shape[1] >= _WINO_MIN_C
                 and w.shape[0] <= 1024 and w.shape[1] <= 1024 and (w.shape[0] & (w.shape[0] - 1)) == 0 and (w.shape[1] & (w.shape[1] - 1)) == 0)
 
     def wino_convs(self):
-        return [c for b in self.blocks for c in (b.conv1, b.conv2) if c.stride[0] == 1 and c.weight.shape[0] >= 256 and c.weight.shape[1] >= 256]
+        return [c for b in self.blocks for c in (b.conv1, b.conv2) if c.stride[0] == 1 and c.weight.shape[0] >= _WINO_MIN_C and c.weight.shape[1] >= _WINO_MIN_C]
 
     def wino_forward(self, lib, st):
         """{id(conv): U (16,Co,Ci)} for the forward, refreshed once per weight update (persistent_wt) or per call."""

@@ -14,7 +14,7 @@ cd /tmp
 echo "== rocprofv3 (bench)"; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python $ROOT/bench.py --no-cpu-baseline > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof.err; echo "rocprof rc=$?"
 find $ROOT/$OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $ROOT/$OUT/bench_kernel_stats.csv
 rm -rf $ROOT/$OUT/prof
-echo "== rocprofv3 (graphed train step only)"; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof2 -- python $ROOT/tools/step_only.py 8 1 > $ROOT/$OUT/step_only.log 2>&1; echo "rc=$?"
+echo "== rocprofv3 (train step only, as bench.py runs it: eager encoder)"; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof2 -- python $ROOT/tools/step_only.py 10 0 0 > $ROOT/$OUT/step_only.log 2>&1; echo "rc=$?"
 f=$(find $ROOT/$OUT/prof2 -name "*kernel_trace.csv" | head -1)
 python $ROOT/tools/trace_gaps.py $f 0.4 > $ROOT/$OUT/step_trace_gaps.txt 2>&1
 find $ROOT/$OUT/prof2 -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $ROOT/$OUT/step_kernel_stats.csv
