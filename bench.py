@@ -625,6 +625,20 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
         allreduce_ms = round(ctx['max_over_ranks'](sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]), 4)
     flop = TRAIN_FLOP_PER_IMAGE * (H * W) / (256.0 * 256.0) * B
     tf = flop / (dt / steps) / 1e12                        # per GPU
+    # what the matrix cores really execute: the stride-1 3x3 layers that take the Winograd F(2x2,3x3) path (encoder.py: >= 256
+    # channels, 6 layers x 3 directions x 5 encoder passes) do 16/36 of the direct convolution's multiplies
+    from t2onet_amd import encoder as _enc
+    wino_saved = 0.0
+    if _enc._WINOGRAD and getattr(model.vis_encoder, 'trunk_plan', None) is not None:
+        plan = model.vis_encoder.trunk_plan()
+        hh, ww = H // 2, W // 2                            # after the stem
+        for blk in plan.blocks:
+            s1 = blk.conv1.stride[0]
+            hh, ww = (hh - 1) // s1 + 1, (ww - 1) // s1 + 1
+            for conv in (blk.conv1, blk.conv2):
+                if plan.wino(conv, hh, ww):
+                    wino_saved += 3 * 5 * 2.0 * 9 * conv.weight.shape[0] * conv.weight.shape[1] * B * hh * ww * (1.0 - 16.0 / 36.0)
+    executed = flop - wino_saved
     finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())   # (a step that produced inf/nan gradients is no measurement)
     if not finite:
         raise RuntimeError('train leg: non-finite parameters after %d steps' % (warmup + steps))
@@ -636,8 +650,13 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             'ms_per_step_over_ranks': spread, 'allreduce_ms': allreduce_ms, 'allreduce_bytes': tr.grads.flat.numel() * 4,
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,
+                         'executed_flop_per_step_per_gpu': executed,
+                         'executed_TFLOPs': round(executed / (dt / steps) / 1e12, 2),
+                         'executed_frac': round(executed / (dt / steps) / 1e12 / FP32_MATRIX_PEAK_TF, 4),
                          'note': 'whole step against the dense fp32 matrix peak: 5 x ResNet-18 forward+backward = '
-                                 '67.8 GFLOP/image at 256x256 (SURVEY 8(d)); per GPU'},
+                                 '67.8 GFLOP/image at 256x256 (SURVEY 8(d)), the ALGORITHMIC count of the direct convolutions; '
+                                 'per GPU.  executed_*: the same minus what Winograd F(2x2,3x3) removes on the layers that '
+                                 'take it (16 of 36 multiplies) -- the matrix pipe\'s real load'},
             'workload': 'episode/L1 train step (train_seq2seqL1.py:74-88), bs=%d/GPU %dx%d fp32, sampled ops, '
                         'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world)}
 
