@@ -97,3 +97,36 @@ def test_winograd_weight_gradient_matches_fp64(shape, accumulate):
     got = (dw - start if accumulate else dw).permute(0, 3, 1, 2).cpu().numpy()
     scale = float(ref.abs().max())
     np.testing.assert_allclose(got, ref.float().numpy(), rtol=1e-5, atol=(3e-5 if accumulate else 1e-5) * scale)
+
+
+def test_each_transform_kernel_matches_the_numpy_restatement():
+    """k_wino_input / k_wino_weight / k_wino_dy / k_wino_output / k_wino_dw one by one against oracle/winograd.py (fp64)."""
+    import t2onet_amd.functional as T
+    from t2onet_amd import _lib
+    from oracle import winograd as wg
+    N, H, W, Ci, Co = 3, 6, 10, 64, 128
+    dev = torch.device('cuda:0')
+    x = synth.uniform((N, H, W, Ci), 1741, -1.0, 1.0)
+    w = synth.uniform((Co, 3, 3, Ci), 1742, -1.0, 1.0)
+    dy = synth.uniform((N, H, W, Co), 1743, -1.0, 1.0)
+    V = T.wino_input(x.to(dev), N, H, W).cpu().numpy()
+    np.testing.assert_allclose(V, wg.input_transform(x.numpy().astype(np.float64)), rtol=0, atol=1e-6)
+    U = T.wino_weight(w.to(dev), Co, Ci).cpu().numpy()
+    np.testing.assert_allclose(U, wg.weight_transform(w.numpy()), rtol=0, atol=1e-6)
+    lib = _lib.load()
+    st = T._stream(dev)
+    Ad = torch.empty(16, N * (H // 2) * (W // 2), Co, device=dev)
+    dyg = dy.to(dev)
+    _lib.check(lib.t2o_wino_dy_transform(T._ptr(dyg), T._ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transform')
+    np.testing.assert_allclose(Ad.cpu().numpy(), wg.dy_transform(dy.numpy()), rtol=0, atol=1e-6)
+    M = synth.uniform((16, N * (H // 2) * (W // 2), Co), 1744, -1.0, 1.0)
+    y = torch.empty(N, H, W, Co, device=dev)
+    Mg = M.to(dev)
+    _lib.check(lib.t2o_wino_output_transform(T._ptr(Mg), None, T._ptr(y), None, N, H, W, Co, st), 't2o_wino_output_transform')
+    np.testing.assert_allclose(y.cpu().numpy(), wg.output_transform(M.numpy().astype(np.float64), N, H, W), rtol=0, atol=4e-6)
+    dU = synth.uniform((16, Co, Ci), 1745, -1.0, 1.0)
+    dw = torch.empty(Co, 3, 3, Ci, device=dev)
+    dUg = dU.to(dev)
+    _lib.check(lib.t2o_wino_dw_transform(T._ptr(dUg), T._ptr(dw), Co, Ci, 0, st), 't2o_wino_dw_transform')
+    ref = np.einsum('ai,aboc,bj->oijc', wg.G, dU.numpy().astype(np.float64).reshape(4, 4, Co, Ci), wg.G)
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=0, atol=4e-6)
