@@ -415,6 +415,10 @@ int t2o_conv3x3_any_wgrad_nhwc(const float* x, const float* dy, float* dw, void*
  * pipeline on dy with U = t2o_wino_weight_transform(wt, Cn = Ci, Ck = Co), wt = t2o_conv_weight_transform(w, ., Co, Ci, 9, 1).
  * C: a power of two in [4, 1024]; all tensors 16-byte aligned. */
 int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* stream);
+/* the 16 GEMMs of the pipeline on this library's fp32 matrix-core kernel (t2o_conv.hip k_gemm_nt: the forward convolution's
+ * LDS-DMA machinery without taps): C[b] (M,N) = A[b] (M,K) * B[b] (N,K)^T for b < batches, all row-major and dense;
+ * N a multiple of 64, K of 32, 16-byte aligned.  M[xi] = V[xi] U[xi]^T is (A, B, C) = (V, U, M), batches = 16. */
+int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, int M, int N, int K, void* stream);
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
 int t2o_wino_stats_rows(int N, int H, int W, int C);
 /* weight gradient in the transformed domain: Ad (16,T,Co) = t2o_wino_dy_transform(dy (N,H,W,Co));

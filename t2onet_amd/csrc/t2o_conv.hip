@@ -681,6 +681,160 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 #endif
 }
 
+// ================================================================================================================
+// BATCHED GEMM   C[b][m][n] = sum_k A[b][m][k] * B[b][n][k]      (both operands K-contiguous, fp32, one rounding order)
+//   The 16 multiplications of a Winograd F(2x2,3x3) layer (t2o_winograd.hip): A = V[xi] (tiles x Ci), B = U[xi] (Co x Ci),
+//   C = M[xi].  It is the forward convolution kernel above without taps, halos and padding: 512 threads = 8 waves
+//   (4 along m x 2 along n), one workgroup per CU, tile 256 x (64 kBN), wave tile 64 x (32 kBN) = 2 x kBN MFMA blocks;
+//   K in stages of 32 (rows of 128 bytes, LDS-DMA pieces of 8 rows, the c ^ ((r >> 1) & 7) chunk swizzle, one
+//   conflict-free ds_read_b128 per fragment and 4 k-steps); A and B double-buffered (96 KiB at kBN = 2).  Per stage and
+//   wave: 16 kBN MFMAs per group of 8 k, 4 groups; 4 + kBN DMA pieces dealt over groups 0 and 1; no vector-ALU instruction
+//   in the loop besides the MFMAs.  Rows past M re-read row M - 1 (their results are not stored).
+struct GemmNtArgs {
+  const float* A;       // (batches, M, K)
+  const float* B;       // (batches, N, K)
+  float* C;             // (batches, M, N)
+  int M, N, K, batches;
+  int tiles_m, tiles_n;
+};
+
+template <int kBN>
+__global__ __launch_bounds__(kFwdThreads, 1) void k_gemm_nt(GemmNtArgs a) {
+  constexpr int kTM = 256, kTN = 64 * kBN;
+  constexpr int kABuf = kTM * 128, kBBuf = kTN * 128;
+  constexpr int kAPw = kTM / 64, kBPw = kTN / 64;          // DMA pieces (8 rows) per wave and stage: 4 of A, kBN of B
+  __shared__ __attribute__((aligned(16))) char As[2][kABuf];
+  __shared__ __attribute__((aligned(16))) char Bs[2][kBBuf];
+
+  // block -> (row tile R = batch * tiles_m + m tile, n tile): the n tiles of one row tile are neighbours inside one XCD
+  const int blk = blockIdx.x;
+  const int xcd = blk % 8, k8 = blk / 8;
+  const int R = (k8 / a.tiles_n) * 8 + xcd, nt = k8 % a.tiles_n;
+  if (R >= a.batches * a.tiles_m) return;
+  const int batch = R / a.tiles_m, mt = R - batch * a.tiles_m;
+  const int m0 = mt * kTM, n0 = nt * kTN;
+  const char* const Ab = (const char*)(a.A + (size_t)batch * a.M * a.K);
+  const char* const Bb = (const char*)(a.B + (size_t)batch * a.N * a.K);
+  float* const Cb = a.C + (size_t)batch * a.M * a.N;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ln = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][kBN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < kBN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // ---- LDS-DMA: lane l of a piece writes LDS bytes 16 l .. = (row l / 8, position l % 8) and fetches chunk position ^ swizzle(row)
+  const unsigned lds_a = lds_addr(&As[0][0]), lds_b = lds_addr(&Bs[0][0]);
+  const int prow = lane >> 3, ppos = lane & 7;
+  const int pswz = ((wave * 8 + prow) >> 1) & 7;           // (pieces wave + 8 i: the swizzle does not depend on i)
+  const unsigned kbytes = (unsigned)a.K * 4u;
+  unsigned voffA[kAPw], voffB[kBPw];                        // loop-invariant lane offsets from the operand's (batch, k chunk) base
+#pragma unroll
+  for (int i = 0; i < kAPw; ++i) {
+    int row = m0 + (wave + 8 * i) * 8 + prow;
+    row = row < a.M ? row : a.M - 1;
+    voffA[i] = (unsigned)row * kbytes + (unsigned)((ppos ^ pswz) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < kBPw; ++j) voffB[j] = (unsigned)(n0 + (wave + 8 * j) * 8 + prow) * kbytes + (unsigned)((ppos ^ pswz) << 4);
+  const int stages = a.K / 32;
+  auto dma_piece = [&](auto jc, int buf, int cc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < kAPw) glds16(voffA[j], Ab + cc * 128, lds_a + (unsigned)(buf * kABuf + (wave + 8 * j) * 1024));
+    else glds16(voffB[j - kAPw], Bb + cc * 128, lds_b + (unsigned)(buf * kBBuf + (wave + 8 * (j - kAPw)) * 1024));
+  };
+  constexpr int NPW = kAPw + kBPw;
+  constexpr int kDmaGroups = 2;
+
+  // ---- fragment addresses (loop-invariant byte offsets)
+  unsigned fa_off[2][4], fb_off[kBN][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + ln;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) fa_off[i][g] = (unsigned)(row * 128 + (((2 * g + lh) ^ ((row >> 1) & 7)) << 4));
+  }
+#pragma unroll
+  for (int j = 0; j < kBN; ++j) {
+    const int row = wn * 32 * kBN + j * 32 + ln;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) fb_off[j][g] = (unsigned)(row * 128 + (((2 * g + lh) ^ ((row >> 1) & 7)) << 4));
+  }
+
+  float4 fa[2][2], fb[2][kBN];
+  auto read_frags = [&](auto Qc, auto gc, auto slotc) {
+    constexpr int Q = decltype(Qc)::value, g = decltype(gc)::value, slot = decltype(slotc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[slot][i] = *reinterpret_cast<const float4*>(&As[Q][0] + fa_off[i][g]);
+#pragma unroll
+    for (int j = 0; j < kBN; ++j) fb[slot][j] = *reinterpret_cast<const float4*>(&Bs[Q][0] + fb_off[j][g]);
+  };
+
+  auto stage = [&](auto Qc, int st) {
+    constexpr int Q = decltype(Qc)::value;
+    const int ncc = st + 1 < stages ? st + 1 : st;         // (the last stage reloads itself into the idle buffer)
+    static_for<0, 4>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int cur = g & 1, nxt = cur ^ 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g + 1 < 4) read_frags(Qc, std::integral_constant<int, g + 1>{}, std::integral_constant<int, nxt>{});
+      else read_frags(std::integral_constant<int, Q ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g < kDmaGroups) {
+        static_for<0, (NPW + kDmaGroups - 1) / kDmaGroups>([&](auto jc) {
+          constexpr int j = g * ((NPW + kDmaGroups - 1) / kDmaGroups) + decltype(jc)::value;
+          if constexpr (j < NPW) dma_piece(std::integral_constant<int, j>{}, Q ^ 1, ncc);
+        });
+      }
+      static_for<0, 4>([&](auto sc) {
+        constexpr int sidx = decltype(sc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < kBN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][sidx], fb[cur][j][sidx], acc[i][j], 0, 0, 0);
+      });
+      if constexpr (g < kDmaGroups) {                     // deal the pieces' scalar instructions out between the MFMAs
+#pragma unroll
+        for (int q = 0; q < 8 * kBN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, (NPW * 16 / kDmaGroups + 8 * kBN - 1) / (8 * kBN), 0);
+        }
+      }
+      if constexpr (g == 2) { __builtin_amdgcn_sched_barrier(0); glds_wait(); __syncthreads(); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  static_for<0, NPW>([&](auto jc) { dma_piece(jc, 0, 0); });
+  glds_wait();
+  __syncthreads();
+  read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  for (int st = 0; st < stages; st += 2) {
+    stage(std::integral_constant<int, 0>{}, st);
+    if (st + 1 < stages) stage(std::integral_constant<int, 1>{}, st + 1);
+  }
+
+  // C/D layout: column (n) = lane % 32, row (m) = (reg % 4) + 8 * (reg / 4) + 4 * (lane / 32)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < a.M) {
+        float* dst = Cb + (size_t)m * a.N + n0 + wn * 32 * kBN + ln;
+#pragma unroll
+        for (int j = 0; j < kBN; ++j) dst[32 * j] = acc[i][j][r];
+      }
+    }
+}
+
 // wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci] (flip: the stride-1 data gradient is the forward kernel on dy with these
 // weights) or wt[ci][kh][kw][co] = w[co][kh][kw][ci] (no flip: the stride-2 data gradient indexes taps itself)
 // (taps = gridDim.z: 9 for the 3x3 layers, 1 for the 1x1 shortcuts -- a plain transpose)
@@ -1418,6 +1572,24 @@ int t2o_stem_wgrad(const float* x, const float* dy, float* dw, void* workspace, 
   const size_t n = (size_t)Co * 27, n4 = n / 4;
   k_conv_wgrad_reduce<<<(unsigned)((n4 + 31) / 32), kConvThreads, 0, st>>>(partial, dw, n4, rows, n, accumulate ? 1 : 0);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_wgrad launch failed");
+}
+
+int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, int M, int N, int K, void* stream) {
+  if (!A || !B || !C || misaligned16(A, B, C)) return set_error(T2O_EINVAL, "gemm_nt_batched: null or not 16-byte aligned pointer");
+  if (batches <= 0 || M <= 0 || N < 64 || N % 64 != 0 || K < 32 || K % 32 != 0 || (size_t)M * K * 4 >= ((size_t)1 << 32) ||
+      (size_t)N * K * 4 >= ((size_t)1 << 32))
+    return set_error(T2O_EUNSUPPORTED, "gemm_nt_batched: N must be a multiple of 64, K of 32, an operand matrix below 4 GiB");
+  GemmNtArgs a;
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.batches = batches;
+  a.tiles_m = (M + 255) / 256;
+  const int bn = N % 128 == 0 ? 2 : 1;
+  a.tiles_n = N / (64 * bn);
+  const long long rows = (long long)batches * a.tiles_m;
+  const long long grid = ((rows + 7) / 8) * 8 * a.tiles_n;
+  if (grid >= ((long long)1 << 31)) return set_error(T2O_EUNSUPPORTED, "gemm_nt_batched: too many tiles");
+  if (bn == 2) k_gemm_nt<2><<<(unsigned)grid, kFwdThreads, 0, (hipStream_t)stream>>>(a);
+  else k_gemm_nt<1><<<(unsigned)grid, kFwdThreads, 0, (hipStream_t)stream>>>(a);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "gemm_nt_batched launch failed");
 }
 
 size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {

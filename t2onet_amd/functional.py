@@ -1270,6 +1270,21 @@ def wino_weight(w_taps_last, Cn, Ck):
     return U
 
 
+_OWN_WINO_GEMM = os.environ.get('T2O_WINO_GEMM', 'own') != 'lib'
+
+
+def gemm_nt_batched(A, B):
+    """C[b] = A[b] @ B[b]^T for dense fp32 (batches, M, K) x (batches, N, K): this library's matrix-core kernel
+    (t2o_gemm_nt_batched; N % 64 == 0, K % 32 == 0), T2O_WINO_GEMM=lib: the framework's batched GEMM (A/B reference)."""
+    if not _OWN_WINO_GEMM:
+        return torch.bmm(A, B.transpose(1, 2))
+    batches, M, K = A.shape
+    N = B.shape[1]
+    C = torch.empty((batches, M, N), dtype=torch.float32, device=A.device)
+    _lib.check(_lib.load().t2o_gemm_nt_batched(_ptr(A), _ptr(B), _ptr(C), batches, M, N, K, _stream(A.device)), 't2o_gemm_nt_batched')
+    return C
+
+
 def wino_input(x, N, H, W):
     """x (N,H,W,C) -> V (16, T, C), the transformed 4x4 input patches of the T = N*H/2*W/2 output tiles."""
     C = x.shape[-1]
@@ -1301,7 +1316,7 @@ def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_
     _lib.check(lib.t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, Ci, st), 't2o_wino_input_transform')
     if keep_v is not None:
         keep_v.append(V)
-    M = torch.bmm(V, U.transpose(1, 2))                   # 16 plain fp32 GEMMs (T x Ci) x (Ci x Co): the library's batched GEMM
+    M = gemm_nt_batched(V, U)                             # 16 GEMMs (T x Ci) x (Ci x Co)
     y = out if out is not None else torch.empty((N, H, W, Co), dtype=torch.float32, device=dev)
     stats = torch.empty((lib.t2o_wino_stats_rows(N, H, W, Co), 2, Co), dtype=torch.float32, device=dev) if want_stats else None
     _lib.check(lib.t2o_wino_output_transform(_ptr(M), _ptr(addend), _ptr(y), _ptr(stats), N, H, W, Co, st), 't2o_wino_output_transform')

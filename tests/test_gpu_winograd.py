@@ -130,3 +130,18 @@ def test_each_transform_kernel_matches_the_numpy_restatement():
     _lib.check(lib.t2o_wino_dw_transform(T._ptr(dUg), T._ptr(dw), Co, Ci, 0, st), 't2o_wino_dw_transform')
     ref = np.einsum('ai,aboc,bj->oijc', wg.G, dU.numpy().astype(np.float64).reshape(4, 4, Co, Ci), wg.G)
     np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=0, atol=4e-6)
+
+
+@pytest.mark.parametrize('shape', [(16, 1024, 512, 512), (16, 4096, 256, 256), (3, 5, 64, 32), (2, 300, 128, 96), (1, 257, 192, 64), (4, 8, 64, 160)])
+def test_own_batched_gemm_matches_fp64(shape):
+    """t2o_gemm_nt_batched (k_gemm_nt): both tile widths, ragged M (rows past M re-read the last row), one and many stages."""
+    import t2onet_amd.functional as T
+    b, M, N, K = shape
+    A = synth.uniform((b, M, K), 1751, -1.0, 1.0)
+    B = synth.uniform((b, N, K), 1752, -1.0, 1.0)
+    dev = torch.device('cuda:0')
+    C = T.gemm_nt_batched(A.to(dev), B.to(dev))
+    ref = torch.bmm(A.double(), B.double().transpose(1, 2))
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(C.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
+    assert torch.equal(C, T.gemm_nt_batched(A.to(dev), B.to(dev)))
