@@ -666,7 +666,7 @@ def conv_kernel_table(B, H, W, device, reps=40):
     and the data gradient of the stride-1 3x3 convolutions of the encoder's 64- and 128-channel stages
     (models/actor_resnet.py:27-44) at this batch / image size -- 60 launches per train step, each 2 * 9 * C * C * pixels
     FLOP (19.33 GFLOP at bs=64 256x256 in every stage).  The 256- and 512-channel stages run Winograd F(2x2,3x3) in the
-    train step (t2o_winograd.hip: transform kernels around 16 library GEMMs of 8.6 GFLOP); their direct kernels and the
+    train step (t2o_winograd.hip transform kernels around the 16 GEMMs of k_gemm_nt / k_gemm_tn, 8.6 GFLOP); their direct kernels and the
     Winograd pipeline are both listed, the latter with the DIRECT convolution's FLOP as the numerator ("effective")."""
     import torch
     from t2onet_amd import _lib
@@ -726,8 +726,8 @@ def conv_kernel_table(B, H, W, device, reps=40):
             ms = sum(a.elapsed_time(b) for a, b in evs) / (len(evs) * 10)
             rows['%s_c%d_%dx%d' % (name, C, h, w)] = {
                 'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2), 'effective': True,
-                'kernel': ('k_wino_input + 16 library GEMMs + k_wino_output<stats>' if name == 'wino_fwd'
-                           else 'k_wino_dy + 16 library GEMMs + k_wino_dw (V kept from the forward)')}
+                'kernel': ('k_wino_input + k_gemm_nt (16 GEMMs) + k_wino_output<stats>' if name == 'wino_fwd'
+                           else 'k_wino_dy + k_gemm_tn (16 GEMMs over the tiles) + k_wino_dw (V kept from the forward)')}
     dom = [v for k, v in rows.items() if v['kernel'] == 'k_conv3x3_fwd<2,1>' and ('_c64_' in k or '_c128_' in k)]
     avg_ms = sum(v['ms'] for v in dom) / len(dom)
     flop = dom[0]['GFLOP'] * 1e9

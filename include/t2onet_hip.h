@@ -403,30 +403,38 @@ size_t t2o_conv3x3_any_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co
 int t2o_conv3x3_any_wgrad_nhwc(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                                int N, int H, int W, int Ci, int Co, int stride, int accumulate, void* stream);
 
-/* ---- Winograd F(2x2, 3x3) transforms for the stride-1 3x3 convolutions of the deep encoder stages (t2o_winograd.hip;
- * models/actor_resnet.py:24-44, the 256- and 512-channel BasicBlocks).  y = conv2d(x, w, None, 1, 1), NHWC, H and W even:
- *   U (16, Co, Ci) = t2o_wino_weight_transform(w (Co,3,3,Ci), Cn = Co, Ck = Ci)          once per weight update
- *   V (16, T, Ci)  = t2o_wino_input_transform(x (N,H,W,Ci)),  T = N * H/2 * W/2
- *   M (16, T, Co)  = 16 plain GEMMs  M[xi] = V[xi] * U[xi]^T                               (caller: any fp32 GEMM)
- *   y (N,H,W,Co)   = t2o_wino_output_transform(M, addend, y, stats)
+/* ---- Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the deep encoder stages (t2o_winograd.hip transforms,
+ * t2o_conv.hip GEMMs; models/actor_resnet.py:24-44, the 256- and 512-channel BasicBlocks).  y = conv2d(x, w, None, 1, 1),
+ * NHWC, H and W even, T = N * H/2 * W/2 output tiles, Tpad = t2o_wino_padded_tiles(N,H,W) (T rounded up to 256):
+ *   U (16, Co, Ci)   = t2o_wino_weight_transform(w (Co,3,3,Ci), Cn = Co, Ck = Ci)                once per weight update
+ *   V (16, Tpad, Ci) = t2o_wino_input_transform(x (N,H,W,Ci))                                     rows T.. are zero
+ *   M (16, T, Co)    = t2o_gemm_nt_batched(V, U, M, 16, T, Co, Ci, Tpad)                          M[xi] = V[xi] U[xi]^T
+ *   y (N,H,W,Co)     = t2o_wino_output_transform(M, addend, y, stats)
  * addend: null or (N,H,W,Co), added to y (the gradient through a block's identity shortcut, as in
  * t2o_conv3x3_dgrad_pre_nhwc); stats: null or (t2o_wino_stats_rows(N,H,W,Co), 2, Co) per-workgroup channel sums / sums
  * of squares of y for t2o_bn_relu_nhwc_fwd_partials (as t2o_conv3x3_fwd_stats_nhwc).  The data gradient is the same
  * pipeline on dy with U = t2o_wino_weight_transform(wt, Cn = Ci, Ck = Co), wt = t2o_conv_weight_transform(w, ., Co, Ci, 9, 1).
- * C: a power of two in [4, 1024]; all tensors 16-byte aligned. */
+ * Weight gradient (in the transformed domain, deterministic):
+ *   Ad (16, Tpad, Co)      = t2o_wino_dy_transform(dy (N,H,W,Co))                                 A dY A^T, rows T.. zero
+ *   dU (splits, 16, Co, Ci) = t2o_gemm_tn_batched(Ad, V, dU, 16, Tpad, Co, Ci, splits)            dU[xi] = Ad[xi]^T V[xi]
+ *                            splits = t2o_gemm_tn_splits(16, Tpad, Co, Ci): pieces of the tile range (fixed partition)
+ *   dw (Co,3,3,Ci)  (+)=   t2o_wino_dw_transform(dU, dw, Co, Ci, splits, accumulate)              G^T (sum of the pieces) G
+ * C: a power of two in [4, 1024] for the transforms; the GEMMs: t2o_gemm_nt_batched N % 64 == 0, K % 32 == 0;
+ * t2o_gemm_tn_batched M, N % 128 == 0, rows % (64 * splits) == 0; all tensors 16-byte aligned. */
+int t2o_wino_padded_tiles(int N, int H, int W);
 int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* stream);
-/* the 16 GEMMs of the pipeline on this library's fp32 matrix-core kernel (t2o_conv.hip k_gemm_nt: the forward convolution's
- * LDS-DMA machinery without taps): C[b] (M,N) = A[b] (M,K) * B[b] (N,K)^T for b < batches, all row-major and dense;
- * N a multiple of 64, K of 32, 16-byte aligned.  M[xi] = V[xi] U[xi]^T is (A, B, C) = (V, U, M), batches = 16. */
-int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, int M, int N, int K, void* stream);
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
 int t2o_wino_stats_rows(int N, int H, int W, int C);
-/* weight gradient in the transformed domain: Ad (16,T,Co) = t2o_wino_dy_transform(dy (N,H,W,Co));
- * dU[xi] (Co,Ci) = Ad[xi]^T * V[xi] (16 plain GEMMs over the tiles, V as in the forward);
- * dw (Co,3,3,Ci) (+)= t2o_wino_dw_transform(dU) = G^T dU G. */
-int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream);
-int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int accumulate, void* stream);
 int t2o_wino_output_transform(const float* M, const float* addend, float* y, float* stats, int N, int H, int W, int C, void* stream);
+int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream);
+int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int splits, int accumulate, void* stream);
+/* the batched fp32 matrix-core GEMMs behind them (t2o_conv.hip k_gemm_nt / k_gemm_tn: the forward convolution's LDS-DMA
+ * machinery without taps), dense row-major operands:
+ *   nt: C[b] (M,N) = A[b] (a_rows >= M rows of K) * B[b] (N,K)^T          for b < batches
+ *   tn: C[s][b] (M,N) = sum over the rows t of piece s of A[b] (rows,M)[t]^T B[b] (rows,N)[t]   for s < splits, b < batches */
+int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, int M, int N, int K, int a_rows, void* stream);
+int t2o_gemm_tn_splits(int batches, int rows, int M, int N);
+int t2o_gemm_tn_batched(const float* A, const float* B, float* C, int batches, int rows, int M, int N, int splits, void* stream);
 
 /* ---- LSTM layers of the request encoder (models/lang_encoder.py:70-113: 2-layer bidirectional LSTM over packed, i.e.
  * per-sample-length, sequences; nn.LSTM gate order i, f, g, o), one launch per time step for both directions (t2o_rnn.hip).

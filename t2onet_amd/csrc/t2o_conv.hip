@@ -691,10 +691,10 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 //   wave: 16 kBN MFMAs per group of 8 k, 4 groups; 4 + kBN DMA pieces dealt over groups 0 and 1; no vector-ALU instruction
 //   in the loop besides the MFMAs.  Rows past M re-read row M - 1 (their results are not stored).
 struct GemmNtArgs {
-  const float* A;       // (batches, M, K)
+  const float* A;       // (batches, a_rows >= M, K): rows past M are never read
   const float* B;       // (batches, N, K)
   float* C;             // (batches, M, N)
-  int M, N, K, batches;
+  int M, N, K, batches, a_rows;
   int tiles_m, tiles_n;
 };
 
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_gemm_nt(GemmNtArgs a) {
   if (R >= a.batches * a.tiles_m) return;
   const int batch = R / a.tiles_m, mt = R - batch * a.tiles_m;
   const int m0 = mt * kTM, n0 = nt * kTN;
-  const char* const Ab = (const char*)(a.A + (size_t)batch * a.M * a.K);
+  const char* const Ab = (const char*)(a.A + (size_t)batch * a.a_rows * a.K);
   const char* const Bb = (const char*)(a.B + (size_t)batch * a.N * a.K);
   float* const Cb = a.C + (size_t)batch * a.M * a.N;
 
@@ -833,6 +833,134 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_gemm_nt(GemmNtArgs a) {
         for (int j = 0; j < kBN; ++j) dst[32 * j] = acc[i][j][r];
       }
     }
+}
+
+// BATCHED GEMM over the rows   C[s][b][m][n] = sum_{t in split s} A[b][t][m] * B[b][t][n]     ("TN": K = the row index)
+//   The weight gradient of a Winograd layer: A = A dY A^T (tiles x Co), B = V (tiles x Ci), C = dU[xi] (Co x Ci), the tile
+//   range cut into `splits` pieces (fixed partition, partial results added in order by k_wino_dw: deterministic).
+//   Tile 128 x 128, K stage = 64 rows of both operands (2 x 32 KiB, double-buffered: 128 KiB), 8 waves = 4 (m) x 2 (n),
+//   wave tile 32 x 64.  Rows are m / n contiguous, which is the MFMA operand order already: lane (i, k) of a k-step reads
+//   word (row 2 step + k, column base + i) -- plain ds_read_b32, conflict-free without a swizzle, immediate row offsets.
+//   Both operands are padded with zero rows to a multiple of 64 * splits by their producers (no edge handling here).
+struct GemmTnArgs {
+  const float* A;       // (batches, Tpad, M)
+  const float* B;       // (batches, Tpad, N)
+  float* C;             // (splits, batches, M, N)
+  int M, N, Tpad, batches, splits;
+  int tiles_m, tiles_n;
+};
+
+__global__ __launch_bounds__(kFwdThreads, 1) void k_gemm_tn(GemmTnArgs a) {
+  constexpr int kT = 128, kRows = 64, kBuf = kRows * kT * 4;      // 32 KiB per operand and stage
+  __shared__ __attribute__((aligned(16))) char As[2][kBuf];
+  __shared__ __attribute__((aligned(16))) char Bs[2][kBuf];
+
+  const int blk = blockIdx.x;
+  const int xcd = blk % 8, k8 = blk / 8;
+  const int R = (k8 / a.tiles_n) * 8 + xcd, nt = k8 % a.tiles_n;
+  if (R >= a.splits * a.batches * a.tiles_m) return;
+  const int sb = R / a.tiles_m, mt = R - sb * a.tiles_m;          // sb = split * batches + batch
+  const int split = sb / a.batches, batch = sb - split * a.batches;
+  const int m0 = mt * kT, n0 = nt * kT;
+  const int rows_per_split = a.Tpad / a.splits, t0 = split * rows_per_split;
+  const char* const Ab = (const char*)(a.A + ((size_t)batch * a.Tpad + t0) * a.M + m0);
+  const char* const Bb = (const char*)(a.B + ((size_t)batch * a.Tpad + t0) * a.N + n0);
+  float* const Cb = a.C + (size_t)sb * a.M * a.N;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ln = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+  // ---- LDS-DMA: a piece = 2 rows x 512 bytes; lane l fetches row l / 32, bytes 16 (l % 32) .., lands at LDS 16 l (row-major tile)
+  const unsigned lds_a = lds_addr(&As[0][0]), lds_b = lds_addr(&Bs[0][0]);
+  const unsigned voffA = (unsigned)(lane >> 5) * (unsigned)a.M * 4u + (unsigned)((lane & 31) << 4);
+  const unsigned voffB = (unsigned)(lane >> 5) * (unsigned)a.N * 4u + (unsigned)((lane & 31) << 4);
+  const long long arow = (long long)a.M * 4, brow = (long long)a.N * 4;
+  const int stages = rows_per_split / kRows;
+  // pieces of this wave: A pieces wave, wave + 8, +16, +24 (rows 2 piece ..), the same of B
+  auto dma_piece = [&](auto jc, int buf, int st) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < 4) {
+      const int piece = wave + 8 * j;
+      glds16(voffA, Ab + ((long long)st * kRows + 2 * piece) * arow, lds_a + (unsigned)(buf * kBuf + piece * 1024));
+    } else {
+      const int piece = wave + 8 * (j - 4);
+      glds16(voffB, Bb + ((long long)st * kRows + 2 * piece) * brow, lds_b + (unsigned)(buf * kBuf + piece * 1024));
+    }
+  };
+  constexpr int NPW = 8, kDmaGroups = 2;
+
+  // ---- fragment addresses: word (row lh, column base + ln) of the stage tile; k-step s adds 2 s rows = 1024 s bytes
+  const unsigned fa_off = (unsigned)(lh * 512 + (wm * 32 + ln) * 4);
+  const unsigned fb_off0 = (unsigned)(lh * 512 + (wn * 64 + ln) * 4), fb_off1 = fb_off0 + 128;
+
+  float fa[2][8], fb[2][2][8];
+  auto read_frags = [&](auto Qc, auto gc, auto slotc) {
+    constexpr int Q = decltype(Qc)::value, g = decltype(gc)::value, slot = decltype(slotc)::value;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      fa[slot][s] = *reinterpret_cast<const float*>(&As[Q][0] + fa_off + (g * 8 + s) * 1024);
+      fb[slot][0][s] = *reinterpret_cast<const float*>(&Bs[Q][0] + fb_off0 + (g * 8 + s) * 1024);
+      fb[slot][1][s] = *reinterpret_cast<const float*>(&Bs[Q][0] + fb_off1 + (g * 8 + s) * 1024);
+    }
+  };
+
+  auto stage = [&](auto Qc, int st) {
+    constexpr int Q = decltype(Qc)::value;
+    const int nst = st + 1 < stages ? st + 1 : st;         // (the last stage reloads itself into the idle buffer)
+    static_for<0, 4>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int cur = g & 1, nxt = cur ^ 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g + 1 < 4) read_frags(Qc, std::integral_constant<int, g + 1>{}, std::integral_constant<int, nxt>{});
+      else read_frags(std::integral_constant<int, Q ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, nxt>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (g < kDmaGroups) {
+        static_for<0, NPW / kDmaGroups>([&](auto jc) {
+          constexpr int j = g * (NPW / kDmaGroups) + decltype(jc)::value;
+          dma_piece(std::integral_constant<int, j>{}, Q ^ 1, nst);
+        });
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][0][s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fb[cur][1][s], acc[1], 0, 0, 0);
+      }
+      if constexpr (g < kDmaGroups) {                     // deal the pieces' scalar instructions out between the MFMAs
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+        }
+      }
+      if constexpr (g == 2) { __builtin_amdgcn_sched_barrier(0); glds_wait(); __syncthreads(); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  static_for<0, NPW>([&](auto jc) { dma_piece(jc, 0, 0); });
+  glds_wait();
+  __syncthreads();
+  read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  for (int st = 0; st < stages; st += 2) {
+    stage(std::integral_constant<int, 0>{}, st);
+    if (st + 1 < stages) stage(std::integral_constant<int, 1>{}, st + 1);
+  }
+
+  // C/D layout: column (n) = lane % 32, row (m) = (reg % 4) + 8 * (reg / 4) + 4 * (lane / 32)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    float* dst = Cb + (size_t)m * a.N + n0 + wn * 64 + ln;
+    dst[0] = acc[0][r];
+    dst[32] = acc[1][r];
+  }
 }
 
 // wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci] (flip: the stride-1 data gradient is the forward kernel on dy with these
@@ -1574,13 +1702,13 @@ int t2o_stem_wgrad(const float* x, const float* dy, float* dw, void* workspace, 
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "stem_wgrad launch failed");
 }
 
-int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, int M, int N, int K, void* stream) {
+int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, int M, int N, int K, int a_rows, void* stream) {
   if (!A || !B || !C || misaligned16(A, B, C)) return set_error(T2O_EINVAL, "gemm_nt_batched: null or not 16-byte aligned pointer");
-  if (batches <= 0 || M <= 0 || N < 64 || N % 64 != 0 || K < 32 || K % 32 != 0 || (size_t)M * K * 4 >= ((size_t)1 << 32) ||
+  if (batches <= 0 || M <= 0 || a_rows < M || N < 64 || N % 64 != 0 || K < 32 || K % 32 != 0 || (size_t)M * K * 4 >= ((size_t)1 << 32) ||
       (size_t)N * K * 4 >= ((size_t)1 << 32))
     return set_error(T2O_EUNSUPPORTED, "gemm_nt_batched: N must be a multiple of 64, K of 32, an operand matrix below 4 GiB");
   GemmNtArgs a;
-  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.batches = batches;
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.batches = batches; a.a_rows = a_rows;
   a.tiles_m = (M + 255) / 256;
   const int bn = N % 128 == 0 ? 2 : 1;
   a.tiles_n = N / (64 * bn);
@@ -1590,6 +1718,30 @@ int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, i
   if (bn == 2) k_gemm_nt<2><<<(unsigned)grid, kFwdThreads, 0, (hipStream_t)stream>>>(a);
   else k_gemm_nt<1><<<(unsigned)grid, kFwdThreads, 0, (hipStream_t)stream>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "gemm_nt_batched launch failed");
+}
+
+int t2o_gemm_tn_splits(int batches, int Tpad, int M, int N) {
+  // enough workgroups for every CU, stages of 64 rows: 1, 2 or 4 pieces of the row range
+  if (batches <= 0 || Tpad <= 0 || Tpad % 256 != 0 || M % 128 != 0 || N % 128 != 0) return 0;
+  const long long tiles = (long long)batches * (M / 128) * (N / 128);
+  int s = 1;
+  while (s < 4 && tiles * s < 256) s *= 2;
+  return s;
+}
+
+int t2o_gemm_tn_batched(const float* A, const float* B, float* C, int batches, int Tpad, int M, int N, int splits, void* stream) {
+  if (!A || !B || !C || misaligned16(A, B, C)) return set_error(T2O_EINVAL, "gemm_tn_batched: null or not 16-byte aligned pointer");
+  if (batches <= 0 || M < 128 || M % 128 != 0 || N < 128 || N % 128 != 0 || Tpad <= 0 || (splits != 1 && splits != 2 && splits != 4) ||
+      Tpad % (64 * splits) != 0 || (size_t)Tpad * (M > N ? M : N) * 4 >= ((size_t)1 << 40))
+    return set_error(T2O_EUNSUPPORTED, "gemm_tn_batched: M, N multiples of 128, rows a multiple of 64 * splits (1, 2, 4)");
+  GemmTnArgs a;
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.Tpad = Tpad; a.batches = batches; a.splits = splits;
+  a.tiles_m = M / 128; a.tiles_n = N / 128;
+  const long long rows = (long long)splits * batches * a.tiles_m;
+  const long long grid = ((rows + 7) / 8) * 8 * a.tiles_n;
+  if (grid >= ((long long)1 << 31)) return set_error(T2O_EUNSUPPORTED, "gemm_tn_batched: too many tiles");
+  k_gemm_tn<<<(unsigned)grid, kFwdThreads, 0, (hipStream_t)stream>>>(a);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "gemm_tn_batched launch failed");
 }
 
 size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {

@@ -5,7 +5,7 @@
 //   at (2 th, 2 tw); it reads the 4 x 4 input patch at rows 2 th - 1 .. 2 th + 2, columns 2 tw - 1 .. 2 tw + 2.
 //       V[xi][t][ci]  = (B^T d B)[xi]           xi = 4 r + c, the 16 positions of the transformed patch
 //       U[xi][co][ci] = (G g G^T)[xi]
-//       M[xi][t][co]  = sum_ci V[xi][t][ci] * U[xi][co][ci]        16 GEMMs  (T x Ci) x (Ci x Co)
+//       M[xi][t][co]  = sum_ci V[xi][t][ci] * U[xi][co][ci]        16 GEMMs  (T x Ci) x (Ci x Co): t2o_conv.hip k_gemm_nt
 //       y tile        = A^T M A
 //   36 multiplies per output pixel and channel pair become 16: the direct kernel needs 19.3 GFLOP per layer and runs at
 //   115-120 TFLOP/s (160 us); the 16 GEMMs are 8.6 GFLOP.  What the transforms move decides where it pays: V and M are
@@ -35,14 +35,21 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-// x (N,H,W,C) -> V (16, T, C), T = N * H/2 * W/2
-__global__ __launch_bounds__(kThreads) void k_wino_input(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C) {
+// x (N,H,W,C) -> V (16, Tpad, C), T = N * H/2 * W/2 tiles, rows T .. Tpad - 1 zero (the weight gradient's GEMM runs over
+// whole 64-row stages of the tile index)
+__global__ __launch_bounds__(kThreads) void k_wino_input(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C, int Tpad) {
   const int q = C >> 2, TH = H >> 1, TW = W >> 1;
   const size_t T = (size_t)N * TH * TW;
   const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= T * q) return;
+  if (idx >= (size_t)Tpad * q) return;
   const size_t t = idx / q;
   const int cq = (int)(idx - t * q);
+  if (t >= T) {
+    float* o = V + t * C + 4 * cq;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st4(o + (size_t)k * Tpad * C, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    return;
+  }
   const int n = (int)(t / (TH * TW)), rem = (int)(t - (size_t)n * TH * TW), th = rem / TW, tw = rem - th * TW;
   const int h0 = 2 * th - 1, w0 = 2 * tw - 1;
   float4 d[4][4];
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void k_wino_input(const float* __restrict
     r[2][j] = sub4(d[2][j], d[1][j]);
     r[3][j] = sub4(d[1][j], d[3][j]);
   }
-  const size_t plane = T * C;
+  const size_t plane = (size_t)Tpad * C;
   float* o = V + t * C + 4 * cq;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -158,20 +165,26 @@ __global__ __launch_bounds__(kThreads) void k_wino_weight(const float* __restric
 //   Ad (16, T, Co) = A dY A^T of the 2 x 2 output-gradient tiles (A = [[1,0],[1,1],[1,-1],[0,-1]])
 //   dU[xi] (Co, Ci) = Ad[xi]^T * V[xi]       16 GEMMs with K = T, V = the forward's transformed input (kept, or redone)
 //   dw (Co,3,3,Ci) (+)= G^T dU G
-__global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ Ad, int N, int H, int W, int C) {
+__global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ Ad, int N, int H, int W, int C, int Tpad) {
   const int q = C >> 2, TH = H >> 1, TW = W >> 1;
   const size_t T = (size_t)N * TH * TW;
   const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= T * q) return;
+  if (idx >= (size_t)Tpad * q) return;
   const size_t t = idx / q;
   const int cq = (int)(idx - t * q);
+  if (t >= T) {                                            // zero rows up to Tpad (as k_wino_input)
+    float* o = Ad + t * C + 4 * cq;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st4(o + (size_t)k * Tpad * C, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    return;
+  }
   const int n = (int)(t / (TH * TW)), rem = (int)(t - (size_t)n * TH * TW), th = rem / TW, tw = rem - th * TW;
   const float* p = dy + (((size_t)n * H + 2 * th) * W + 2 * tw) * C + 4 * cq;
   const float4 d00 = ld4(p), d01 = ld4(p + C), d10 = ld4(p + (size_t)W * C), d11 = ld4(p + (size_t)W * C + C);
   // A d: rows (d0, d0 + d1, d0 - d1, -d1)
   const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   const float4 r[4][2] = {{d00, d01}, {add4(d00, d10), add4(d01, d11)}, {sub4(d00, d10), sub4(d01, d11)}, {sub4(zero, d10), sub4(zero, d11)}};
-  const size_t plane = T * C;
+  const size_t plane = (size_t)Tpad * C;
   float* o = Ad + t * C + 4 * cq;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ 
 }
 
 // dU (16, Co, Ci) -> dw (Co,3,3,Ci) = G^T dU G (acc: added to dw)
-__global__ __launch_bounds__(kThreads) void k_wino_dw(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci, int acc) {
+__global__ __launch_bounds__(kThreads) void k_wino_dw(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci, int acc, int splits) {
   const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x, total = (size_t)Co * Ci;
   if (idx >= total) return;
   const int co = (int)(idx / Ci), ci = (int)(idx - (size_t)co * Ci);
@@ -191,7 +204,11 @@ __global__ __launch_bounds__(kThreads) void k_wino_dw(const float* __restrict__ 
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) u[a][b] = dU[(size_t)(4 * a + b) * total + idx];
+    for (int b = 0; b < 4; ++b) {
+      float v = dU[(size_t)(4 * a + b) * total + idx];
+      for (int sp = 1; sp < splits; ++sp) v += dU[((size_t)sp * 16 + 4 * a + b) * total + idx];       // the split-K pieces, in order
+      u[a][b] = v;
+    }
   // G^T u: rows (u0 + (u1 + u2)/2, (u1 - u2)/2, (u1 + u2)/2 + u3)
   float r[3][4];
 #pragma unroll
@@ -235,26 +252,37 @@ int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* st
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_weight_transform: launch failed");
 }
 
+int t2o_wino_padded_tiles(int N, int H, int W) {
+  if (N <= 0 || H < 2 || W < 2 || H % 2 || W % 2) return 0;
+  const long long T = (long long)N * (H / 2) * (W / 2);
+  const long long Tp = (T + 255) / 256 * 256;
+  return Tp < ((long long)1 << 31) ? (int)Tp : 0;
+}
+
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream) {
   if (!x || !V || !wino_shape_ok(N, H, W, C)) return set_error(T2O_EINVAL, "wino_input_transform: null pointer or bad shape (H, W even; C a power of two in [4, 1024])");
   if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(V)) & 15) return set_error(T2O_EINVAL, "wino_input_transform: tensors must be 16-byte aligned");
-  const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  k_wino_input<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(x, V, N, H, W, C);
+  const int Tpad = t2o_wino_padded_tiles(N, H, W);
+  if (Tpad <= 0) return set_error(T2O_EUNSUPPORTED, "wino_input_transform: too many tiles");
+  const size_t work = (size_t)Tpad * (C / 4);
+  k_wino_input<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(x, V, N, H, W, C, Tpad);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_input_transform: launch failed");
 }
 
 int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream) {
   if (!dy || !Ad || !wino_shape_ok(N, H, W, C)) return set_error(T2O_EINVAL, "wino_dy_transform: null pointer or bad shape (H, W even; C a power of two in [4, 1024])");
   if ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(Ad)) & 15) return set_error(T2O_EINVAL, "wino_dy_transform: tensors must be 16-byte aligned");
-  const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  k_wino_dy<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, Ad, N, H, W, C);
+  const int Tpad = t2o_wino_padded_tiles(N, H, W);
+  if (Tpad <= 0) return set_error(T2O_EUNSUPPORTED, "wino_dy_transform: too many tiles");
+  const size_t work = (size_t)Tpad * (C / 4);
+  k_wino_dy<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, Ad, N, H, W, C, Tpad);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transform: launch failed");
 }
 
-int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int accumulate, void* stream) {
-  if (!dU || !dw || Co <= 0 || Ci <= 0) return set_error(T2O_EINVAL, "wino_dw_transform: null pointer or bad shape");
+int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int splits, int accumulate, void* stream) {
+  if (!dU || !dw || Co <= 0 || Ci <= 0 || splits < 1) return set_error(T2O_EINVAL, "wino_dw_transform: null pointer or bad shape");
   const size_t total = (size_t)Co * Ci;
-  k_wino_dw<<<(unsigned)((total + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dU, dw, Co, Ci, accumulate ? 1 : 0);
+  k_wino_dw<<<(unsigned)((total + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dU, dw, Co, Ci, accumulate ? 1 : 0, splits);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dw_transform: launch failed");
 }
 

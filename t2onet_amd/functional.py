@@ -1273,35 +1273,54 @@ def wino_weight(w_taps_last, Cn, Ck):
 _OWN_WINO_GEMM = os.environ.get('T2O_WINO_GEMM', 'own') != 'lib'
 
 
-def gemm_nt_batched(A, B):
-    """C[b] = A[b] @ B[b]^T for dense fp32 (batches, M, K) x (batches, N, K): this library's matrix-core kernel
-    (t2o_gemm_nt_batched; N % 64 == 0, K % 32 == 0), T2O_WINO_GEMM=lib: the framework's batched GEMM (A/B reference)."""
+def gemm_nt_batched(A, B, M=None):
+    """C[b] (M,N) = A[b][:M] @ B[b]^T for dense fp32 A (batches, rows >= M, K), B (batches, N, K): this library's matrix-core
+    kernel (t2o_gemm_nt_batched; N % 64 == 0, K % 32 == 0).  T2O_WINO_GEMM=lib: the framework's batched GEMM (A/B reference)."""
+    batches, rows, K = A.shape
+    M = rows if M is None else M
     if not _OWN_WINO_GEMM:
-        return torch.bmm(A, B.transpose(1, 2))
-    batches, M, K = A.shape
+        return torch.bmm(A[:, :M], B.transpose(1, 2))
     N = B.shape[1]
     C = torch.empty((batches, M, N), dtype=torch.float32, device=A.device)
-    _lib.check(_lib.load().t2o_gemm_nt_batched(_ptr(A), _ptr(B), _ptr(C), batches, M, N, K, _stream(A.device)), 't2o_gemm_nt_batched')
+    _lib.check(_lib.load().t2o_gemm_nt_batched(_ptr(A), _ptr(B), _ptr(C), batches, M, N, K, rows, _stream(A.device)), 't2o_gemm_nt_batched')
+    return C
+
+
+def gemm_tn_batched(A, B):
+    """(splits, batches, M, N) pieces of C[b] = A[b]^T @ B[b] for A (batches, rows, M), B (batches, rows, N) (rows % 256 == 0,
+    M, N % 128 == 0: t2o_gemm_tn_batched); the caller adds the pieces in order (t2o_wino_dw_transform does)."""
+    batches, rows, M = A.shape
+    N = B.shape[2]
+    if not _OWN_WINO_GEMM:
+        return torch.bmm(A.transpose(1, 2), B).unsqueeze(0)
+    lib = _lib.load()
+    splits = lib.t2o_gemm_tn_splits(batches, rows, M, N)
+    if splits <= 0:
+        raise RuntimeError('gemm_tn_batched: M, N must be multiples of 128 and the row count of 256 (got %d x %d over %d rows)' % (M, N, rows))
+    C = torch.empty((splits, batches, M, N), dtype=torch.float32, device=A.device)
+    _lib.check(lib.t2o_gemm_tn_batched(_ptr(A), _ptr(B), _ptr(C), batches, rows, M, N, splits, _stream(A.device)), 't2o_gemm_tn_batched')
     return C
 
 
 def wino_input(x, N, H, W):
-    """x (N,H,W,C) -> V (16, T, C), the transformed 4x4 input patches of the T = N*H/2*W/2 output tiles."""
+    """x (N,H,W,C) -> V (16, Tpad, C): the transformed 4x4 input patches of the T = N*H/2*W/2 output tiles, zero rows up to
+    Tpad = t2o_wino_padded_tiles (a multiple of 256)."""
+    lib = _lib.load()
     C = x.shape[-1]
-    V = torch.empty((16, N * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, C, _stream(x.device)), 't2o_wino_input_transform')
+    V = torch.empty((16, lib.t2o_wino_padded_tiles(N, H, W), C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, C, _stream(x.device)), 't2o_wino_input_transform')
     return V
 
 
 def wino_wgrad_nhwc(V, dy, dw, N, H, W, accumulate):
-    """dw (Co,3,3,Ci) (+)= weight gradient of the convolution whose transformed input is V (16,T,Ci), for dy (N,H,W,Co)."""
+    """dw (Co,3,3,Ci) (+)= weight gradient of the convolution whose transformed input is V (16,Tpad,Ci), for dy (N,H,W,Co)."""
     lib = _lib.load()
     st = _stream(dy.device)
     Co, Ci = dy.shape[-1], V.shape[2]
     Ad = torch.empty((16, V.shape[1], Co), dtype=torch.float32, device=dy.device)
     _lib.check(lib.t2o_wino_dy_transform(_ptr(dy), _ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transform')
-    dU = torch.bmm(Ad.transpose(1, 2), V)                 # 16 plain fp32 GEMMs (Co x T) x (T x Ci)
-    _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, 1 if accumulate else 0, st), 't2o_wino_dw_transform')
+    dU = gemm_tn_batched(Ad, V)                           # 16 GEMMs over the tiles (Co x T) x (T x Ci), in `splits` pieces
+    _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, dU.shape[0], 1 if accumulate else 0, st), 't2o_wino_dw_transform')
 
 
 def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_v=None):
@@ -1310,13 +1329,11 @@ def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_
     lib = _lib.load()
     dev = x.device
     st = _stream(dev)
-    Co, Ci = U.shape[1], U.shape[2]
-    T = N * (H // 2) * (W // 2)
-    V = torch.empty((16, T, Ci), dtype=torch.float32, device=dev)
-    _lib.check(lib.t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, Ci, st), 't2o_wino_input_transform')
+    Co = U.shape[1]
+    V = wino_input(x, N, H, W)
     if keep_v is not None:
         keep_v.append(V)
-    M = gemm_nt_batched(V, U)                             # 16 GEMMs (T x Ci) x (Ci x Co)
+    M = gemm_nt_batched(V, U, N * (H // 2) * (W // 2))    # 16 GEMMs (T x Ci) x (Ci x Co)
     y = out if out is not None else torch.empty((N, H, W, Co), dtype=torch.float32, device=dev)
     stats = torch.empty((lib.t2o_wino_stats_rows(N, H, W, Co), 2, Co), dtype=torch.float32, device=dev) if want_stats else None
     _lib.check(lib.t2o_wino_output_transform(_ptr(M), _ptr(addend), _ptr(y), _ptr(stats), N, H, W, Co, st), 't2o_wino_output_transform')

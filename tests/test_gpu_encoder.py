@@ -153,7 +153,8 @@ def test_trunk_matches_per_layer_path_and_fp64(monkeypatch, bias, size):
     if tight:
         _close(dimg1, dimg0, 1e-4)
         for n in g1:
-            _close(g1[n], g0[n], 1e-4)
+            _close(g1[n], g0[n], 2e-4)                      # (the trunk's deep stages run Winograd, the per-layer path the direct
+                                                            # kernels: two fp32 algorithms, each within 2e-4 of fp64 below)
     for trunk in (True, False):
         net, out, dimg, g = nets[trunk]
         _close(out, ref_out, 2e-4)

@@ -79,7 +79,11 @@ def test_transforms_refuse_shapes_they_do_not_take():
         T.wino_conv_nhwc(torch.zeros(1, 4, 4, 96, device=dev), torch.zeros(16, 64, 96, device=dev), 1, 4, 4)
 
 
-@pytest.mark.parametrize('shape', SHAPES)
+# (the weight gradient's GEMM takes channel counts that are multiples of 128; T = 5 * 1 and 3 * 15 tiles: all padding / ragged)
+WGRAD_SHAPES = [(4, 256, 256, 16, 16), (3, 512, 512, 8, 8), (2, 256, 512, 6, 10), (5, 128, 128, 2, 2), (1, 128, 256, 2, 12), (40, 256, 256, 16, 16)]
+
+
+@pytest.mark.parametrize('shape', WGRAD_SHAPES)
 @pytest.mark.parametrize('accumulate', [False, True])
 def test_winograd_weight_gradient_matches_fp64(shape, accumulate):
     import t2onet_amd.functional as T
@@ -109,16 +113,19 @@ def test_each_transform_kernel_matches_the_numpy_restatement():
     x = synth.uniform((N, H, W, Ci), 1741, -1.0, 1.0)
     w = synth.uniform((Co, 3, 3, Ci), 1742, -1.0, 1.0)
     dy = synth.uniform((N, H, W, Co), 1743, -1.0, 1.0)
+    Tt = N * (H // 2) * (W // 2)
     V = T.wino_input(x.to(dev), N, H, W).cpu().numpy()
-    np.testing.assert_allclose(V, wg.input_transform(x.numpy().astype(np.float64)), rtol=0, atol=1e-6)
+    assert V.shape[1] % 256 == 0 and not V[:, Tt:].any()                       # zero rows up to the padded tile count
+    np.testing.assert_allclose(V[:, :Tt], wg.input_transform(x.numpy().astype(np.float64)), rtol=0, atol=1e-6)
     U = T.wino_weight(w.to(dev), Co, Ci).cpu().numpy()
     np.testing.assert_allclose(U, wg.weight_transform(w.numpy()), rtol=0, atol=1e-6)
     lib = _lib.load()
     st = T._stream(dev)
-    Ad = torch.empty(16, N * (H // 2) * (W // 2), Co, device=dev)
+    Ad = torch.empty(16, V.shape[1], Co, device=dev)
     dyg = dy.to(dev)
     _lib.check(lib.t2o_wino_dy_transform(T._ptr(dyg), T._ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transform')
-    np.testing.assert_allclose(Ad.cpu().numpy(), wg.dy_transform(dy.numpy()), rtol=0, atol=1e-6)
+    assert not Ad[:, Tt:].any()
+    np.testing.assert_allclose(Ad[:, :Tt].cpu().numpy(), wg.dy_transform(dy.numpy()), rtol=0, atol=1e-6)
     M = synth.uniform((16, N * (H // 2) * (W // 2), Co), 1744, -1.0, 1.0)
     y = torch.empty(N, H, W, Co, device=dev)
     Mg = M.to(dev)
@@ -127,7 +134,7 @@ def test_each_transform_kernel_matches_the_numpy_restatement():
     dU = synth.uniform((16, Co, Ci), 1745, -1.0, 1.0)
     dw = torch.empty(Co, 3, 3, Ci, device=dev)
     dUg = dU.to(dev)
-    _lib.check(lib.t2o_wino_dw_transform(T._ptr(dUg), T._ptr(dw), Co, Ci, 0, st), 't2o_wino_dw_transform')
+    _lib.check(lib.t2o_wino_dw_transform(T._ptr(dUg), T._ptr(dw), Co, Ci, 1, 0, st), 't2o_wino_dw_transform')
     ref = np.einsum('ai,aboc,bj->oijc', wg.G, dU.numpy().astype(np.float64).reshape(4, 4, Co, Ci), wg.G)
     np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=0, atol=4e-6)
 
@@ -145,3 +152,20 @@ def test_own_batched_gemm_matches_fp64(shape):
     scale = float(ref.abs().max())
     np.testing.assert_allclose(C.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5 * scale)
     assert torch.equal(C, T.gemm_nt_batched(A.to(dev), B.to(dev)))
+
+
+@pytest.mark.parametrize('shape', [(16, 1024, 512, 512), (16, 4096, 256, 256), (2, 256, 128, 384), (16, 256, 128, 128), (1, 768, 256, 128)])
+def test_own_row_gemm_matches_fp64(shape):
+    """t2o_gemm_tn_batched (k_gemm_tn): C = A^T B over the rows, 1 / 2 / 4 pieces of the row range added in order."""
+    import t2onet_amd.functional as T
+    b, rows, M, N = shape
+    A = synth.uniform((b, rows, M), 1761, -1.0, 1.0)
+    B = synth.uniform((b, rows, N), 1762, -1.0, 1.0)
+    dev = torch.device('cuda:0')
+    C = T.gemm_tn_batched(A.to(dev), B.to(dev))
+    assert C.shape[1:] == (b, M, N) and C.shape[0] in (1, 2, 4)
+    got = C.double().sum(0).cpu()
+    ref = torch.bmm(A.double().transpose(1, 2), B.double())
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * scale)
+    assert torch.equal(C, T.gemm_tn_batched(A.to(dev), B.to(dev)))

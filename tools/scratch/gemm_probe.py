@@ -15,3 +15,8 @@ for (Tt, C) in ((1024, 512), (4096, 256), (16384, 128)):
     fl = 16 * Tt * C * C * 2
     a = t(lambda: T.gemm_nt_batched(V, U)); b = t(lambda: torch.bmm(V, U.transpose(1, 2)))
     print('T=%6d C=%4d  own %7.1f us %6.1f TF/s   library %7.1f us %6.1f TF/s' % (Tt, C, a, fl / a / 1e6, b, fl / b / 1e6))
+for (Tt, C) in ((1024, 512), (4096, 256)):
+    Ad = torch.randn(16, Tt, C, device=dev); V = torch.randn(16, Tt, C, device=dev)
+    fl = 16 * Tt * C * C * 2
+    a = t(lambda: T.gemm_tn_batched(Ad, V)); b = t(lambda: torch.bmm(Ad.transpose(1, 2), V))
+    print('TN T=%6d C=%4d  own %7.1f us %6.1f TF/s   library %7.1f us %6.1f TF/s' % (Tt, C, a, fl / a / 1e6, b, fl / b / 1e6))
