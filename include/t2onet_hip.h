@@ -427,6 +427,8 @@ int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int 
 int t2o_wino_stats_rows(int N, int H, int W, int C);
 int t2o_wino_output_transform(const float* M, const float* addend, float* y, float* stats, int N, int H, int W, int C, void* stream);
 int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream);
+/* t2o_wino_input_transform(dy) and t2o_wino_dy_transform(dy) in one pass over dy (a layer's backward needs both) */
+int t2o_wino_dy_transforms(const float* dy, float* V, float* Ad, int N, int H, int W, int C, void* stream);
 int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int splits, int accumulate, void* stream);
 /* the batched fp32 matrix-core GEMMs behind them (t2o_conv.hip k_gemm_nt / k_gemm_tn: the forward convolution's LDS-DMA
  * machinery without taps), dense row-major operands:

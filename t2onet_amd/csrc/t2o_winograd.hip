@@ -195,6 +195,63 @@ __global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ 
   }
 }
 
+// Both transforms of an output gradient in one pass over dy: V = B^T d B of the 4 x 4 patches (the data gradient's GEMM
+// operand) and Ad = A dY A^T of their inner 2 x 2 blocks (the weight gradient's); rows T .. Tpad - 1 of both are zero.
+__global__ __launch_bounds__(kThreads) void k_wino_dy_both(const float* __restrict__ dy, float* __restrict__ V, float* __restrict__ Ad,
+                                                           int N, int H, int W, int C, int Tpad) {
+  const int q = C >> 2, TH = H >> 1, TW = W >> 1;
+  const size_t T = (size_t)N * TH * TW;
+  const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= (size_t)Tpad * q) return;
+  const size_t t = idx / q;
+  const int cq = (int)(idx - t * q);
+  const size_t plane = (size_t)Tpad * C;
+  float* ov = V + t * C + 4 * cq;
+  float* oa = Ad + t * C + 4 * cq;
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (t >= T) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { st4(ov + (size_t)k * plane, zero); st4(oa + (size_t)k * plane, zero); }
+    return;
+  }
+  const int n = (int)(t / (TH * TW)), rem = (int)(t - (size_t)n * TH * TW), th = rem / TW, tw = rem - th * TW;
+  const int h0 = 2 * th - 1, w0 = 2 * tw - 1;
+  float4 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int h = h0 + i, w = w0 + j;
+      d[i][j] = ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? ld4(dy + (((size_t)n * H + h) * W + w) * C + 4 * cq) : zero;
+    }
+  {
+    const float4 r[4][2] = {{d[1][1], d[1][2]}, {add4(d[1][1], d[2][1]), add4(d[1][2], d[2][2])},
+                            {sub4(d[1][1], d[2][1]), sub4(d[1][2], d[2][2])}, {sub4(zero, d[2][1]), sub4(zero, d[2][2])}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st4(oa + (size_t)(4 * i + 0) * plane, r[i][0]);
+      st4(oa + (size_t)(4 * i + 1) * plane, add4(r[i][0], r[i][1]));
+      st4(oa + (size_t)(4 * i + 2) * plane, sub4(r[i][0], r[i][1]));
+      st4(oa + (size_t)(4 * i + 3) * plane, sub4(zero, r[i][1]));
+    }
+  }
+  float4 r[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[0][j] = sub4(d[0][j], d[2][j]);
+    r[1][j] = add4(d[1][j], d[2][j]);
+    r[2][j] = sub4(d[2][j], d[1][j]);
+    r[3][j] = sub4(d[1][j], d[3][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st4(ov + (size_t)(4 * i + 0) * plane, sub4(r[i][0], r[i][2]));
+    st4(ov + (size_t)(4 * i + 1) * plane, add4(r[i][1], r[i][2]));
+    st4(ov + (size_t)(4 * i + 2) * plane, sub4(r[i][2], r[i][1]));
+    st4(ov + (size_t)(4 * i + 3) * plane, sub4(r[i][1], r[i][3]));
+  }
+}
+
 // dU (16, Co, Ci) -> dw (Co,3,3,Ci) = G^T dU G (acc: added to dw)
 __global__ __launch_bounds__(kThreads) void k_wino_dw(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci, int acc, int splits) {
   const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x, total = (size_t)Co * Ci;
@@ -277,6 +334,16 @@ int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C
   const size_t work = (size_t)Tpad * (C / 4);
   k_wino_dy<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, Ad, N, H, W, C, Tpad);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transform: launch failed");
+}
+
+int t2o_wino_dy_transforms(const float* dy, float* V, float* Ad, int N, int H, int W, int C, void* stream) {
+  if (!dy || !V || !Ad || !wino_shape_ok(N, H, W, C)) return set_error(T2O_EINVAL, "wino_dy_transforms: null pointer or bad shape (H, W even; C a power of two in [4, 1024])");
+  if ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(V) | reinterpret_cast<size_t>(Ad)) & 15) return set_error(T2O_EINVAL, "wino_dy_transforms: tensors must be 16-byte aligned");
+  const int Tpad = t2o_wino_padded_tiles(N, H, W);
+  if (Tpad <= 0) return set_error(T2O_EUNSUPPORTED, "wino_dy_transforms: too many tiles");
+  const size_t work = (size_t)Tpad * (C / 4);
+  k_wino_dy_both<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, V, Ad, N, H, W, C, Tpad);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transforms: launch failed");
 }
 
 int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int splits, int accumulate, void* stream) {

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from .functional import _need_gpu, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input
+from .functional import _need_gpu, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input, wino_backward_nhwc
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
@@ -286,6 +286,13 @@ class _TrunkFn(torch.autograd.Function):
             rc = lib.t2o_conv3x3_any_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(g(w)), _ptr(ws), need, N, Hi, Wi, Ci, Co, s, acc, st)
             _lib.check(rc, 't2o_conv3x3_any_wgrad_nhwc')
 
+        def wino_bwd(conv, x, dy, dx, addend, Hi, Wi):
+            """Both gradients of a Winograd layer: ONE transform pass over dy feeds the data gradient's and the weight gradient's GEMMs."""
+            V = ctx.kept_v.pop(id(conv), None)
+            if V is None:
+                V = wino_input(x, N, Hi, Wi)
+            wino_backward_nhwc(dy, V, wt['wino'][id(conv)], g(conv.weight), dx, N, Hi, Wi, addend, acc)
+
         def dgrad3(conv, dy, dx, addend, Hi, Wi, Hn, Wn):
             """dx (N,Hi,Wi,Ci) = data gradient of conv for dy (N,Hn,Wn,Co) (+ addend, stride 1 only)."""
             w = conv.weight
@@ -316,14 +323,21 @@ class _TrunkFn(torch.autograd.Function):
             # out = relu(bn2(y2) + sc)
             dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co)
             da1 = torch.empty_like(rec['a1'])
-            dgrad3(b.conv2, dy2, da1, None, Hn, Wn, Hn, Wn)
-            wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn, Hn, Wn)
+            if plan.wino(b.conv2, Hn, Wn):
+                wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
+            else:
+                dgrad3(b.conv2, dy2, da1, None, Hn, Wn, Hn, Wn)
+                wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn, Hn, Wn)
             del dy2
             # a1 = relu(bn1(y1))
             dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co)
             del da1
-            wgrad3(b.conv1, rec['x'], dy1, Hc, Wc, Hn, Wn)
             dx = torch.empty_like(rec['x'])
+            if plan.wino(b.conv1, Hc, Wc) and not len(b.shortcut):
+                wino_bwd(b.conv1, rec['x'], dy1, dx, dsc, Hc, Wc)
+                d = dx
+                continue
+            wgrad3(b.conv1, rec['x'], dy1, Hc, Wc, Hn, Wn)
             if len(b.shortcut):
                 sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
                 dys, _ = bn_bwd(sc_bn, rec['ys'], None, dsc, rec['ms'], rec['is_'], 0, 0, False, M, Co)

@@ -1323,6 +1323,24 @@ def wino_wgrad_nhwc(V, dy, dw, N, H, W, accumulate):
     _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, dU.shape[0], 1 if accumulate else 0, st), 't2o_wino_dw_transform')
 
 
+def wino_backward_nhwc(dy, Vx, Ud, dw, dx, N, H, W, addend, accumulate):
+    """Both gradients of a Winograd layer from one pass over dy (N,H,W,Co): dx (N,H,W,Ci) = data gradient (+ addend) with
+    Ud (16,Ci,Co) the transformed mirrored filter, dw (Co,3,3,Ci) (+)= weight gradient with Vx (16,Tpad,Ci) the forward's
+    transformed input."""
+    lib = _lib.load()
+    dev = dy.device
+    st = _stream(dev)
+    Co, Ci = dy.shape[-1], Vx.shape[2]
+    Tpad = Vx.shape[1]
+    Vd = torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
+    Ad = torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
+    _lib.check(lib.t2o_wino_dy_transforms(_ptr(dy), _ptr(Vd), _ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transforms')
+    M = gemm_nt_batched(Vd, Ud, N * (H // 2) * (W // 2))
+    _lib.check(lib.t2o_wino_output_transform(_ptr(M), _ptr(addend), _ptr(dx), None, N, H, W, Ci, st), 't2o_wino_output_transform')
+    dU = gemm_tn_batched(Ad, Vx)
+    _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, dU.shape[0], 1 if accumulate else 0, st), 't2o_wino_dw_transform')
+
+
 def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_v=None):
     """x (N,H,W,Ci) NHWC buffer, U (16,Co,Ci) -> y (N,H,W,Co) (+ addend) [, stats rows for the batch norm that follows].
     keep_v: a list that receives V (the weight gradient reuses it: wino_wgrad_nhwc)."""

@@ -169,3 +169,23 @@ def test_own_row_gemm_matches_fp64(shape):
     scale = float(ref.abs().max())
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * scale)
     assert torch.equal(C, T.gemm_tn_batched(A.to(dev), B.to(dev)))
+
+
+def test_combined_backward_equals_the_two_separate_pipelines():
+    """wino_backward_nhwc (one transform pass over dy for both gradients) == data gradient + weight gradient done separately, bit for bit."""
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = 3, 256, 128, 6, 10
+    dev = torch.device('cuda:0')
+    x = synth.uniform((N, H, W, Ci), 1771, -1.0, 1.0).to(dev)
+    dy = synth.uniform((N, H, W, Co), 1772, -1.0, 1.0).to(dev)
+    w = synth.uniform((Co, Ci, 3, 3), 1773, -1.0, 1.0).to(dev).contiguous(memory_format=torch.channels_last)
+    ad = synth.uniform((N, H, W, Ci), 1774, -1.0, 1.0).to(dev)
+    Ud = T.wino_weight(T.conv_weight_transform(w, 9, True), Ci, Co)
+    Vx = T.wino_input(x, N, H, W)
+    dx0, _ = T.wino_conv_nhwc(dy, Ud, N, H, W, ad)
+    dw0 = torch.zeros(Co, 3, 3, Ci, device=dev)
+    T.wino_wgrad_nhwc(Vx, dy, dw0, N, H, W, False)
+    dx1 = torch.empty_like(dx0)
+    dw1 = torch.zeros_like(dw0)
+    T.wino_backward_nhwc(dy, Vx, Ud, dw1, dx1, N, H, W, ad, False)
+    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
