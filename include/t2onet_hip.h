@@ -84,6 +84,17 @@ int t2o_l1_fwd(const float* pred, const float* target, float* loss, size_t n,
 int t2o_l1_bwd(const float* pred, const float* target, const float* gloss, float* gpred,
                size_t n, void* stream);
 
+/* ---- END select fused with the L1 loss (train_seq2seqL1.py:78-85): pred[b] = imgs[first[b]][b], first[b] = the step of
+ * sample b's first END token (else the last step), loss[0] = mean |pred - target| over B * row floats.  imgs / gimgs: HOST
+ * arrays of T <= 8 device pointers to (B, row) step images / their gradients; first: device int64 (B).  The backward
+ * writes all T gradients in one launch: sign(pred - target) * gloss[0] / (B row) where selected, zero elsewhere.
+ * Replaces torch.stack + advanced indexing + t2o_l1_* (and their zero-filled scatter in the backward); the loss equals
+ * t2o_l1_fwd on the gathered images bit for bit.  workspace: as t2o_l1_fwd for n = B * row. */
+int t2o_end_select_l1_fwd(const float* const* imgs, int T, const long long* first, const float* target, float* loss, int B,
+                          size_t row, void* workspace, size_t workspace_bytes, void* stream);
+int t2o_end_select_l1_bwd(const float* const* imgs, float* const* gimgs, int T, const long long* first, const float* target,
+                          const float* gloss, int B, size_t row, void* stream);
+
 /* ---- operator fused with the L1 loss on its output (last operator of a sequence) ----
  * forward also reads `target` and writes loss[0] = mean |out - target|;
  * backward takes the target instead of gout: gout = sign(out - target) * gloss[0] / (B*3*H*W). */

@@ -497,6 +497,61 @@ __global__ __launch_bounds__(kThreads) void k_l1_bwd(const float* pred, const fl
   }
 }
 
+// ------------------------------------------------------------------ END select fused with the L1 loss
+// train_seq2seqL1.py:78-85: the loss is taken on the image at each sample's first END token (else its last one):
+// pred[b] = imgs[first[b]][b].  Forward and backward read only that image of every sample (no (B,T,3,H,W) stack, no
+// gather, no zero-filled scatter target); the backward writes the gradient of ALL T step images in one launch
+// (sign(pred - target) * gloss / n where selected, zero elsewhere).  Same element -> workgroup partition and summation
+// order as k_l1_fwd on the gathered tensor: the loss is bit-identical to that path.
+struct EndSelArgs {
+  const float* img[8];
+  float* gimg[8];
+  int T;
+};
+
+__device__ __forceinline__ const float* end_sel_src(const EndSelArgs& s, int f) {
+  const float* p = s.img[0];
+#pragma unroll
+  for (int t = 1; t < 8; ++t) p = (f == t) ? s.img[t] : p;
+  return p;
+}
+
+template <int V>
+__global__ __launch_bounds__(kThreads) void k_end_l1_fwd(EndSelArgs s, const long long* first, const float* target, float* partial,
+                                                         size_t n, size_t row, int iters) {
+  float acc = 0.0f;
+  for (int it = 0; it < iters; ++it) {
+    const size_t g = ((size_t)blockIdx.x * iters + it) * kThreads + threadIdx.x;
+    if (g * V >= n) break;
+    const int f = (int)first[(g * V) / row];
+    float p[V], t[V];
+    load_vec<V>(end_sel_src(s, f) + g * V, p);
+    load_vec<V>(target + g * V, t);
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc += fabsf(p[i] - t[i]);
+  }
+  block_reduce_store1(acc, partial + blockIdx.x);
+}
+
+template <int V>
+__global__ __launch_bounds__(kThreads) void k_end_l1_bwd(EndSelArgs s, const long long* first, const float* target, const float* gloss,
+                                                         size_t n, size_t row, float inv_n, int iters) {
+  const float gs = gloss[0] * inv_n;
+  for (int it = 0; it < iters; ++it) {
+    const size_t g = ((size_t)blockIdx.x * iters + it) * kThreads + threadIdx.x;
+    if (g * V >= n) break;
+    const int f = (int)first[(g * V) / row];
+    float p[V], t[V], o[V], z[V];
+    load_vec<V>(end_sel_src(s, f) + g * V, p);
+    load_vec<V>(target + g * V, t);
+#pragma unroll
+    for (int i = 0; i < V; ++i) { o[i] = sign_of(p[i] - t[i]) * gs; z[i] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < s.T) store_vec<V>(s.gimg[k] + g * V, f == k ? o : z);
+  }
+}
+
 // ------------------------------------------------------------------ SSIM forward (evaluation)
 __global__ __launch_bounds__(kThreads) void k_ssim_fwd(SsimArgs s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1000,6 +1055,47 @@ int t2o_l1_bwd(const float* pred, const float* target, const float* gloss, float
   if (V == 4) k_l1_bwd<4><<<(unsigned)nblk, kThreads, 0, st>>>(pred, target, gloss, gpred, n, 1.0f / (float)n, iters);
   else k_l1_bwd<1><<<(unsigned)nblk, kThreads, 0, st>>>(pred, target, gloss, gpred, n, 1.0f / (float)n, iters);
   return check_launch("l1 backward");
+}
+
+int t2o_end_select_l1_fwd(const float* const* imgs, int T, const long long* first, const float* target, float* loss, int B,
+                          size_t row, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!imgs || !first || !target || !loss || T < 1 || T > 8 || B <= 0 || row == 0) return fail(T2O_EINVAL, "end_select_l1_fwd: null pointer or bad shape (1 <= T <= 8)");
+  EndSelArgs s = {};
+  s.T = T;
+  for (int t = 0; t < T; ++t) { if (!imgs[t]) return fail(T2O_EINVAL, "end_select_l1_fwd: null image"); s.img[t] = imgs[t]; }
+  const size_t n = (size_t)B * row;
+  const int V = (row % 4 == 0) ? 4 : 1;
+  const int iters = 8;
+  const size_t groups = n / V;
+  const size_t nblk = (groups + (size_t)kThreads * iters - 1) / ((size_t)kThreads * iters);
+  if (!workspace || workspace_bytes < nblk * sizeof(float)) return fail(T2O_EWORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  if (V == 4) k_end_l1_fwd<4><<<(unsigned)nblk, kThreads, 0, st>>>(s, first, target, partial, n, row, iters);
+  else k_end_l1_fwd<1><<<(unsigned)nblk, kThreads, 0, st>>>(s, first, target, partial, n, row, iters);
+  k_l1_finalize<<<1, kThreads, 0, st>>>(partial, (int)nblk, 1.0f / (float)n, loss);
+  return check_launch("END select + l1 forward");
+}
+
+int t2o_end_select_l1_bwd(const float* const* imgs, float* const* gimgs, int T, const long long* first, const float* target,
+                          const float* gloss, int B, size_t row, void* stream) {
+  if (!imgs || !gimgs || !first || !target || !gloss || T < 1 || T > 8 || B <= 0 || row == 0)
+    return fail(T2O_EINVAL, "end_select_l1_bwd: null pointer or bad shape (1 <= T <= 8)");
+  EndSelArgs s = {};
+  s.T = T;
+  for (int t = 0; t < T; ++t) {
+    if (!imgs[t] || !gimgs[t]) return fail(T2O_EINVAL, "end_select_l1_bwd: null image");
+    s.img[t] = imgs[t]; s.gimg[t] = gimgs[t];
+  }
+  const size_t n = (size_t)B * row;
+  const int V = (row % 4 == 0) ? 4 : 1;
+  const int iters = 4;
+  const size_t groups = n / V;
+  const size_t nblk = (groups + (size_t)kThreads * iters - 1) / ((size_t)kThreads * iters);
+  hipStream_t st = (hipStream_t)stream;
+  if (V == 4) k_end_l1_bwd<4><<<(unsigned)nblk, kThreads, 0, st>>>(s, first, target, gloss, n, row, 1.0f / (float)n, iters);
+  else k_end_l1_bwd<1><<<(unsigned)nblk, kThreads, 0, st>>>(s, first, target, gloss, n, row, 1.0f / (float)n, iters);
+  return check_launch("END select + l1 backward");
 }
 
 int t2o_sequence_fwd(const int* ops, int K, const float* img, const float* params, const float* target, float* acts,

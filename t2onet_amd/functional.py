@@ -187,6 +187,50 @@ def l1_loss(pred, target):
     return _L1Fn.apply(pred, target)
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _EndSelectL1Fn(torch.autograd.Function):
+    """mean |imgs[first[b]][b] - target[b]| over the list of step images (t2o_end_select_l1_*): no (B,T,3,H,W) stack."""
+
+    @staticmethod
+    def forward(ctx, first, target, *imgs):
+        _need_gpu(target, *imgs)
+        imgs = [t.contiguous() for t in imgs]
+        target = target.contiguous()
+        if any(t.shape != target.shape for t in imgs):
+            raise ValueError('end_select_l1: shape mismatch')
+        B = target.shape[0]
+        row = target.numel() // B
+        first = first.to(torch.int64).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=target.device)
+        n = target.numel()
+        ws = workspace(max(1, n // (3 * 64 * 64) + 1), 64, 64, target.device)
+        rc = _lib.load().t2o_end_select_l1_fwd(_ptr_array(imgs), len(imgs), _ptr(first), _ptr(target), _ptr(loss), B, row, _ptr(ws),
+                                               ws.numel(), _stream(target.device))
+        _lib.check(rc, 't2o_end_select_l1_fwd')
+        ctx.save_for_backward(first, target, *imgs)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        first, target = ctx.saved_tensors[:2]
+        imgs = list(ctx.saved_tensors[2:])
+        gloss = gloss.contiguous().to(torch.float32)
+        grads = [torch.empty_like(t) for t in imgs]
+        B = target.shape[0]
+        rc = _lib.load().t2o_end_select_l1_bwd(_ptr_array(imgs), _ptr_array(grads), len(imgs), _ptr(first), _ptr(target), _ptr(gloss), B,
+                                               target.numel() // B, _stream(target.device))
+        _lib.check(rc, 't2o_end_select_l1_bwd')
+        return (None, None) + tuple(grads)
+
+
+def end_select_l1(imgs, first, target):
+    """L1 between each sample's image of step first[b] (imgs: list of T (B,3,H,W) step images) and the target."""
+    return _EndSelectL1Fn.apply(first, target, *imgs)
+
+
 class _AttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, context):

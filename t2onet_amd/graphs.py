@@ -202,16 +202,15 @@ class GraphedEpisodeStep:
             trainer.grads.zero()
 
     def _body(self):
-        from .train import select_end_images
-        from . import functional as T
+        from .train import end_l1_loss
         tr = self.trainer
         model = tr.model
         if tr._trunk is not None:
             tr._trunk.weights_changed()                        # the weights were updated since the last step: transform them again
         tr.grads.zero()
         lengths = (self.s_x != tr.opt.null_id).sum(1)         # on the device, inside the graph: no host-side lengths to copy
-        _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, lengths, self.longest)
-        loss = T.l1_loss(select_end_images(imgs, ops, tr.opt.end_id), self.s_target)
+        _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, lengths, self.longest, stack=False)
+        loss = end_l1_loss(imgs, ops, tr.opt.end_id, self.s_target)
         loss.backward()
         return loss.detach()
 

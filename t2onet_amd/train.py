@@ -17,13 +17,26 @@ import torch.nn.functional as F
 from . import functional as T
 
 
-def select_end_images(pred_imgs, pred_ops, end_id):
-    """Image at the first END token, else the last one (train_seq2seqL1.py:78-84), without the
-    per-sample nonzero() host syncs."""
+def first_end_step(pred_ops, end_id):
+    """Step of each sample's first END token, else the last step (train_seq2seqL1.py:78-84), without the per-sample
+    nonzero() host syncs."""
     B, Tn = pred_ops.shape
     is_end = pred_ops == end_id
-    first = torch.where(is_end.any(1), is_end.int().argmax(1), torch.full((B,), Tn - 1, device=pred_ops.device))
-    return pred_imgs[torch.arange(B, device=pred_ops.device), first]
+    return torch.where(is_end.any(1), is_end.int().argmax(1), torch.full((B,), Tn - 1, device=pred_ops.device))
+
+
+def select_end_images(pred_imgs, pred_ops, end_id):
+    """Image at the first END token, else the last one; pred_imgs (B,T,3,H,W)."""
+    first = first_end_step(pred_ops, end_id)
+    return pred_imgs[torch.arange(pred_ops.shape[0], device=pred_ops.device), first]
+
+
+def end_l1_loss(pred_imgs, pred_ops, end_id, target):
+    """The episode loss (train_seq2seqL1.py:78-85) from the LIST of step images: on a GPU one kernel reads each sample's END
+    image where it lies (functional.end_select_l1); elsewhere the stacked gather + L1."""
+    if target.is_cuda and target.dtype == torch.float32 and 1 <= len(pred_imgs) <= 8:
+        return T.end_select_l1(pred_imgs, first_end_step(pred_ops, end_id), target)
+    return T.l1_loss(select_end_images(torch.stack(pred_imgs, 1), pred_ops, end_id), target)
 
 
 class FlatGradients:
@@ -226,9 +239,8 @@ class Trainer:
             if loss is not None:
                 return loss
         self._maybe_graph(img_x)
-        _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths)
-        pred = select_end_images(pred_imgs, pred_ops, self.opt.end_id)
-        loss = T.l1_loss(pred, target)
+        _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths, stack=False)
+        loss = end_l1_loss(pred_imgs, pred_ops, self.opt.end_id, target)
         self._finish(loss)
         return loss.detach()
 

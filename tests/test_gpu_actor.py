@@ -593,3 +593,23 @@ def test_step_graph_draws_fresh_samples_and_trains():
     losses = [float(tr.episode_step(x, img, tgt, lengths=lengths)) for _ in range(12)]
     assert all(bool(torch.isfinite(p).all()) for p in tr.model.parameters())
     assert min(losses[-4:]) < losses[0], losses
+
+
+def test_end_select_l1_equals_stack_gather_l1():
+    """functional.end_select_l1 (one kernel on the list of step images) == torch.stack + select_end_images + l1_loss
+    (train_seq2seqL1.py:78-85): loss and every step image's gradient bit for bit, END at any step or nowhere."""
+    import t2onet_amd.functional as T
+    from t2onet_amd.train import select_end_images, first_end_step, end_l1_loss
+    dev = torch.device('cuda:0')
+    B, Tn, H, W = 6, 5, 20, 12
+    imgs = [synth.uniform((B, 3, H, W), 2100 + t, 0.0, 1.0).to(dev).requires_grad_(True) for t in range(Tn)]
+    tgt = synth.uniform((B, 3, H, W), 2110, 0.0, 1.0).to(dev)
+    ops = torch.tensor([[5, 2, 4, 4, 4], [2, 3, 3, 3, 3], [3, 4, 5, 6, 8], [3, 4, 5, 6, 2], [3, 2, 2, 2, 2], [4, 4, 2, 5, 2]], device=dev)
+    assert first_end_step(ops, 2).tolist() == [1, 0, 4, 4, 1, 2]
+    loss0 = T.l1_loss(select_end_images(torch.stack(imgs, 1), ops, 2), tgt)
+    g0 = torch.autograd.grad(loss0 * 3.0, imgs)
+    loss1 = end_l1_loss(imgs, ops, 2, tgt)
+    g1 = torch.autograd.grad(loss1 * 3.0, imgs)
+    assert torch.equal(loss0, loss1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
