@@ -477,7 +477,12 @@ bool nhwc_channels_ok(int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0;
 // rows per workgroup (a multiple of the workgroup's R = 1024 / C row slots x the unroll) and the workgroup count
 void nhwc_partition(int M, int C, int unroll, int* rows_per_block, int* nblk) {
   const int R = kThreads / (C >> 2), step = R * unroll;
-  int rpb = (M + kNhwcMaxBlocks - 1) / kNhwcMaxBlocks;
+  // at most kNhwcMaxBlocks workgroups, and at least 16 Ki elements for each (the finalize kernel reads every partial row: with
+  // 1024 rows of 512 channels it read 4 MB to finish an 8 MB tensor -- 8.4 us; with 128 rows 5 us)
+  long long maxb = (long long)M * C / 16384;
+  if (maxb > kNhwcMaxBlocks) maxb = kNhwcMaxBlocks;
+  if (maxb < 64) maxb = 64;
+  int rpb = (int)((M + maxb - 1) / maxb);
   rpb = ((rpb + step - 1) / step) * step;
   *rows_per_block = rpb;
   *nblk = (M + rpb - 1) / rpb;
