@@ -586,7 +586,8 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             dist.broadcast(t.data, 0)
     want_graph = os.environ.get('T2O_GRAPH_ENCODER', '0') != '0'
     want_step_graph = os.environ.get('T2O_GRAPH_STEP', '0') != '0'
-    tr = Trainer(model, opt, graph_encoder=want_graph, graph_step=want_step_graph)
+    tune = os.environ.get('T2O_TUNE_GEMMS', '1') != '0'      # the decoder's small library GEMMs: the framework's own autotuner
+    tr = Trainer(model, opt, graph_encoder=want_graph, graph_step=want_step_graph, tune_gemms=tune)
     g = torch.Generator().manual_seed(10 + ctx['rank'])
     img = torch.rand(B, 3, H, W, generator=g).to(device)
     tgt = torch.rand(B, 3, H, W, generator=g).to(device)
@@ -646,7 +647,7 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 2),
             'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()), 'parameters_finite': finite,
             'encoder_hipgraphs': bool(tr.graph_encoder and '_graphed_encoders' in model.__dict__),
-            'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0,
+            'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0, 'library_gemms_tuned': bool(tune),
             'ms_per_step_over_ranks': spread, 'allreduce_ms': allreduce_ms, 'allreduce_bytes': tr.grads.flat.numel() * 4,
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,

@@ -129,12 +129,21 @@ class FlatAdam:
 class Trainer:
     """Drives the reference's alternation: odd iterations supervised, even iterations episode/L1."""
 
-    def __init__(self, model, opt, lr=None, graph_encoder=False, graph_step=False):
+    def __init__(self, model, opt, lr=None, graph_encoder=False, graph_step=False, tune_gemms=False):
         """graph_encoder: capture the image encoder's forward/backward as hipGraphs on the first step (fixed
         batch and image size from then on; other shapes run eagerly) -- see Actor.graph_image_encoder.
         graph_step: capture the WHOLE episode step behind the request encoder (all encoder passes, decoder steps,
         sampling, operators, L1, backward) as one hipGraph per (image shape, request length) --
-        graphs.GraphedEpisodeStep; takes precedence over graph_encoder for the episode step."""
+        graphs.GraphedEpisodeStep; takes precedence over graph_encoder for the episode step.
+        tune_gemms: let the framework time the library's candidates for every GEMM shape it meets (torch's TunableOp; the
+        decoder's ~20 shapes with M = batch, during the first steps) and keep the fastest -- PROCESS-WIDE and sticky, hence
+        opt-in.  The default pick is latency-bound at these sizes (5.5-9.5 us per call against 3.9-7 us for the best one)."""
+        if tune_gemms and next(model.parameters()).is_cuda:
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(True)
+            torch.cuda.tunable.set_max_tuning_duration(50)     # ms per candidate set
+            import tempfile                                    # (the result file torch writes at exit: not into the working directory)
+            torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), 't2o_tunableop_%d.csv' % os.getpid()), True)
         self.model, self.opt = model, opt
         self.grads = FlatGradients(model.parameters())
         lr = lr if lr is not None else opt.learning_rate
