@@ -594,7 +594,9 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
     x = synthetic_requests(B, g)
     lengths = (x != 0).sum(1)
     x = x.to(device)
-    for _ in range(warmup):
+    # (with --warmup 0 one untimed set-up step still runs: run-time kernel specialisation and the library GEMM selection happen
+    # on the first step and are initialisation, not steady-state work)
+    for _ in range(max(warmup, 1)):
         tr.episode_step(x, img, tgt, lengths=lengths)
     ctx['barrier']()
     t0 = time.perf_counter()
