@@ -72,10 +72,12 @@ class TrunkPlan:
         transform passes over 4x the activation beat the direct kernel's 19.3 GFLOP (t2o_winograd.hip)."""
         w = conv.weight
         return (_WINOGRAD and conv.stride[0] == 1 and H % 2 == 0 and W % 2 == 0 and w.shape[0] >= _WINO_MIN_C and w.shape[1] >= _WINO_MIN_C
-                and w.shape[0] <= 1024 and w.shape[1] <= 1024 and (w.shape[0] & (w.shape[0] - 1)) == 0 and (w.shape[1] & (w.shape[1] - 1)) == 0)
+                and w.shape[0] <= 1024 and w.shape[1] <= 1024 and (w.shape[0] & (w.shape[0] - 1)) == 0 and (w.shape[1] & (w.shape[1] - 1)) == 0
+                and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0)          # (t2o_gemm_tn_batched: 128-wide tiles)
 
     def wino_convs(self):
-        return [c for b in self.blocks for c in (b.conv1, b.conv2) if c.stride[0] == 1 and c.weight.shape[0] >= _WINO_MIN_C and c.weight.shape[1] >= _WINO_MIN_C]
+        return [c for b in self.blocks for c in (b.conv1, b.conv2) if c.stride[0] == 1 and c.weight.shape[0] >= _WINO_MIN_C and c.weight.shape[1] >= _WINO_MIN_C
+                and c.weight.shape[0] % 128 == 0 and c.weight.shape[1] % 128 == 0]
 
     def wino_forward(self, lib, st):
         """{id(conv): U (16,Co,Ci)} for the forward, refreshed once per weight update (persistent_wt) or per call."""
