@@ -356,6 +356,19 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize(BnArgs a, const f
   __shared__ double sm[2][kThreads / 64][4];
   const int sl = threadIdx.x >> 2, j = threadIdx.x & 3;
   const int c = blockIdx.x * 4 + j;
+  // the channel epilogue's own operands travel while the partial rows are being added (the kernel is one dependent chain:
+  // every microsecond of latency taken out of it is a microsecond of an otherwise idle GPU)
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+  if (threadIdx.x < 4) {
+    p0 = a.weight[c];
+    if (BWD) {
+      p1 = a.save_invstd[c];
+      if (a.acc) { p2 = a.dbias ? a.dbias[c] : 0.0f; p3 = a.dweight ? a.dweight[c] : 0.0f; }
+    } else {
+      p1 = a.bias[c];
+      if (a.running_mean) { p2 = a.running_mean[c]; p3 = a.running_var[c]; }
+    }
+  }
   double s0 = 0.0, s1 = 0.0;
   // (measured: issuing a slice's 16 row loads 8 at a time made this kernel SLOWER, 8.4 -> 12.5 us -- it is a 16-workgroup
   // launch whose time is the launch itself plus one dependent chain load -> reduce -> coefficient loads -> stores)
@@ -374,7 +387,29 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize(BnArgs a, const f
   if (threadIdx.x < 4) {
     s0 = (sm[0][0][j] + sm[0][1][j]) + (sm[0][2][j] + sm[0][3][j]);
     s1 = (sm[1][0][j] + sm[1][1][j]) + (sm[1][2][j] + sm[1][3][j]);
-    if (BWD) bn_bwd_finalize_channel(a, c, s0, s1); else bn_finalize_channel(a, c, s0, s1);
+    const double m = (double)a.N * a.HW;
+    if (BWD) {                                         // bn_bwd_finalize_channel on the prefetched operands
+      if (a.dbias) a.dbias[c] = a.acc ? p2 + (float)s0 : (float)s0;
+      if (a.dweight) a.dweight[c] = a.acc ? p3 + (float)s1 : (float)s1;
+      a.coef[c] = p0 * p1;
+      a.coef[a.C + c] = (float)(s0 / m);
+      a.coef[2 * a.C + c] = (float)(s1 / m);
+    } else {                                           // bn_finalize_channel on the prefetched operands
+      const double mean = s0 / m;
+      double var = s1 / m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+      a.save_mean[c] = (float)mean;
+      a.save_invstd[c] = invstd;
+      const float scale = p0 * invstd;
+      a.coef[c] = scale;
+      a.coef[a.C + c] = p1 - (float)mean * scale;
+      if (a.running_mean) {
+        const double unbiased = m > 1.0 ? var * m / (m - 1.0) : var;
+        a.running_mean[c] = (1.0f - a.momentum) * p2 + a.momentum * (float)mean;
+        a.running_var[c] = (1.0f - a.momentum) * p3 + a.momentum * (float)unbiased;
+      }
+    }
   }
 }
 
