@@ -140,7 +140,7 @@ class ResNet(nn.Module):
             if plan.supported(x):
                 from .encoder import trunk_forward
                 torch._foreach_add_(self._batch_counters(), 1)
-                x = trunk_forward(plan, x).mean((2, 3))
+                x = trunk_forward(plan, x, pool=True)
                 return T.linear_acc(x.view(x.size(0), -1), self.fc.weight, self.fc.bias)
         if self.conv1.weight.is_contiguous(memory_format=torch.channels_last) and x.is_cuda:
             # channels-last encoder (Actor.use_channels_last): one packed NHWC copy of the 3-channel image, then every

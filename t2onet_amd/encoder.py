@@ -57,6 +57,7 @@ class TrunkPlan:
         for i, p in enumerate(self.params):
             self.index[id(p)] = i
         self.bns = [resnet.bn1] + [m for b in blocks for m in ([b.bn1, b.bn2] + ([b.shortcut[1]] if len(b.shortcut) else []))]
+        self.pool = False                                      # trunk_forward(..., pool=True): the node returns the pooled (N, C) features
         self.persistent_wt = False                             # Trainer: transformed weights live until weights_changed()
         self._wt = None                                        # persistent buffers (fixed addresses: captured graphs read them)
         self._wt_valid = False
@@ -240,6 +241,10 @@ class _TrunkFn(torch.autograd.Function):
         ctx.into_grad = all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape
                             and p.grad.stride() == p.stride() for p in plan.params)
         ctx.grads = [p.grad for p in plan.params] if ctx.into_grad else None
+        ctx.pooled = plan.pool
+        if plan.pool:                                          # global average pool inside the node (models/actor_resnet.py:106):
+            ctx.hw = (x.shape[1], x.shape[2])                  # its backward then builds the NHWC gradient directly instead of
+            return x.mean((1, 2))                              # autograd's NCHW expand + a permuting copy (20 -> 7 us per pass)
         return x.permute(0, 3, 1, 2)                          # (N,C,h,w) view of the NHWC buffer = channels_last
 
     @staticmethod
@@ -315,7 +320,11 @@ class _TrunkFn(torch.autograd.Function):
                 rc = lib.t2o_conv3x3_any_dgrad_nhwc(_ptr(dy), _ptr(wt[id(conv)]), _ptr(addend), _ptr(dx), N, Hi, Wi, Ci, Co, s, st)
                 _lib.check(rc, 't2o_conv3x3_any_dgrad_nhwc')
 
-        d = dout.permute(0, 2, 3, 1).contiguous()              # NHWC (a no-op for a channels_last gradient)
+        if ctx.pooled:
+            h, w = ctx.hw
+            d = (dout * (1.0 / (h * w))).view(N, 1, 1, -1).expand(N, h, w, dout.shape[1]).contiguous()
+        else:
+            d = dout.permute(0, 2, 3, 1).contiguous()          # NHWC (a no-op for a channels_last gradient)
         for b, rec in zip(reversed(plan.blocks), reversed(ctx.saved)):
             s = b.conv1.stride[0]
             Co, Ci = b.conv1.weight.shape[0], b.conv1.weight.shape[1]
@@ -370,6 +379,7 @@ class _TrunkFn(torch.autograd.Function):
         return (None, dimg) + (tuple(None for _ in plan.params) if acc else tuple(grads))
 
 
-def trunk_forward(plan, img):
+def trunk_forward(plan, img, pool=False):
     """relu(bn(conv...)) trunk output (N,512,H/32,W/32), channels_last, for a supported training-mode call."""
+    plan.pool = bool(pool)                                 # (read by the node's forward only)
     return _TrunkFn.apply(plan, img, *plan.params)
