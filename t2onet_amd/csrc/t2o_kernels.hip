@@ -361,12 +361,15 @@ __global__ __launch_bounds__(kThreads) void k_chain_finalize(ChainArgs a, float*
 
 // ------------------------------------------------------------------ finalisation kernels
 // One workgroup per sample: sum the per-block raw sums in a fixed order, then raw sums -> gparam.
-// Thread t owns slot (t % 32) of every 8th block row starting at (t / 32): 96-byte coalesced reads.
+// Thread t owns slot (t % w) of every (256 / w)-th block row starting at (t / w), w = 1 / 8 / 32 for operators with 1 / <= 8 /
+// more sums per block: the one-parameter operators used 8 of the 256 threads before (w was always 32), which made their
+// finalize 10.5 us at 16 x 512^2 (256 block rows per sample) against 4.7 us at 64 x 256^2 -- the shape dependence the
+// round-2 review found in the materialised backward legs.
 __global__ __launch_bounds__(kThreads) void k_finalize_params(OpArgs a, float* gparam, int gparam_stride,
                                                               int nblk_point, int nblk_sharp) {
-  __shared__ float part[kThreads / 32][32];
+  __shared__ float part[kThreads];
   __shared__ float sums[kRedSlots];
-  const int b = blockIdx.x, slot = threadIdx.x & 31, chunk = threadIdx.x >> 5;
+  const int b = blockIdx.x;
   const int op = (a.op == OP_DYNAMIC) ? a.op_id[b] : a.op;
   float* grow = gparam + (size_t)b * gparam_stride;
   const int np = op_num_params(op);
@@ -377,15 +380,24 @@ __global__ __launch_bounds__(kThreads) void k_finalize_params(OpArgs a, float* g
   const int n = nred_of(op);
   const int nb = (op == OP_SHARPNESS) ? nblk_sharp : nblk_point;
   const float* base = a.partials + (size_t)b * a.nblk_max * kRedSlots;
+  const int w = n <= 1 ? 1 : (n <= 8 ? 8 : 32), nch = kThreads / w;           // (uniform per workgroup)
+  const int slot = threadIdx.x % w, chunk = threadIdx.x / w;
   float acc = 0.0f;
   if (slot < n)
-    for (int k = chunk; k < nb; k += kThreads / 32) acc += base[(size_t)k * kRedSlots + slot];
-  part[chunk][slot] = acc;
+    for (int k = chunk; k < nb; k += nch) acc += base[(size_t)k * kRedSlots + slot];
+  part[chunk * w + slot] = acc;
+  __syncthreads();
+  __shared__ float part2[8 * 32];
+  if ((int)threadIdx.x < 8 * w) {                                              // 8 lanes per slot, every 8th chunk each: fixed order
+    float s = 0.0f;
+    for (int c = threadIdx.x / w; c < nch; c += 8) s += part[c * w + slot];
+    part2[threadIdx.x] = s;
+  }
   __syncthreads();
   if ((int)threadIdx.x < n) {
     float s = 0.0f;
 #pragma unroll
-    for (int c = 0; c < kThreads / 32; ++c) s += part[c][threadIdx.x];
+    for (int j = 0; j < 8; ++j) s += part2[j * w + threadIdx.x];
     sums[threadIdx.x] = s;
   }
   __syncthreads();
@@ -406,10 +418,9 @@ struct MultiFinalize {
 };
 
 __global__ __launch_bounds__(kThreads) void k_finalize_params_multi(MultiFinalize m) {
-  __shared__ float part[kThreads / 32][32];
+  __shared__ float part[kThreads];
   __shared__ float sums[kRedSlots];
   const int k = blockIdx.x / m.B, b = blockIdx.x % m.B;
-  const int slot = threadIdx.x & 31, chunk = threadIdx.x >> 5;
   const int op = m.ops[k];
   float* grow = m.gparams + ((size_t)k * m.B + b) * kMaxParam;
   const int np = op_num_params(op);
@@ -419,15 +430,24 @@ __global__ __launch_bounds__(kThreads) void k_finalize_params_multi(MultiFinaliz
   }
   const int n = nred_of(op), nb = m.nblk[k];
   const float* base = m.partials + (size_t)k * m.region_floats + (size_t)b * m.nblk_max * kRedSlots;
+  const int w = n <= 1 ? 1 : (n <= 8 ? 8 : 32), nch = kThreads / w;           // (as k_finalize_params)
+  const int slot = threadIdx.x % w, chunk = threadIdx.x / w;
   float acc = 0.0f;
   if (slot < n)
-    for (int r = chunk; r < nb; r += kThreads / 32) acc += base[(size_t)r * kRedSlots + slot];
-  part[chunk][slot] = acc;
+    for (int r = chunk; r < nb; r += nch) acc += base[(size_t)r * kRedSlots + slot];
+  part[chunk * w + slot] = acc;
+  __syncthreads();
+  __shared__ float part2[8 * 32];
+  if ((int)threadIdx.x < 8 * w) {                                              // (as k_finalize_params)
+    float v = 0.0f;
+    for (int c = threadIdx.x / w; c < nch; c += 8) v += part[c * w + slot];
+    part2[threadIdx.x] = v;
+  }
   __syncthreads();
   if ((int)threadIdx.x < n) {
     float v = 0.0f;
 #pragma unroll
-    for (int c = 0; c < kThreads / 32; ++c) v += part[c][threadIdx.x];
+    for (int j = 0; j < 8; ++j) v += part2[j * w + threadIdx.x];
     sums[threadIdx.x] = v;
   }
   __syncthreads();
