@@ -700,9 +700,86 @@ __global__ __launch_bounds__(64) void k_choose_op(const float* logp, float* op_m
 }
 
 // ------------------------------------------------------------------ attention core
-// One workgroup (4 waves) per sample.  Scores: wave w takes encoder rows w, w+4, ... (lanes stride
-// the D columns, shuffle reduction); softmax over all L rows from LDS; mix / gradients: one thread
-// per column.  L <= 64, D <= 1024.
+// One workgroup (4 waves) per sample; L <= 64 encoder rows of D <= 1024 columns.
+// k_attn_fwd (any D % 64 == 0): wave w takes encoder rows w, w+4, ... (lanes stride the D columns, shuffle reduction); softmax
+// over all L rows from LDS; mix: one thread per column.  One memory round trip per encoder row of a wave: 22.8 us for the
+// actor's 2.2 MB (L = 17, D = 512).
+// k_attn_fwd_wide (D % 256 == 0): a row is D / 4 column quads = D / 256 whole waves; the 4 waves form R = 1 / 2 / 4 row groups,
+// thread t owns quad t % (D/4) of the rows of group t / (D/4).  16-byte loads, 8 rows' loads in flight per thread, a wave
+// reduction per row, the waves of a row meet in LDS; the mix keeps the same ownership.  Three round trips per launch.
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ __launch_bounds__(kThreads) void k_attn_fwd_wide(const float* q, const float* ctx, float* attn, float* mix,
+                                                            int B, int L, int D) {
+  __shared__ float ws[4][64];                                         // per wave: its part of every row's score
+  __shared__ float sc[64];
+  __shared__ float4 red[kThreads];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Q = D >> 2, wpr = Q >> 6;                                 // column quads per row; waves per row (1, 2, 3, 4)
+  const int R = (kThreads / 64) / wpr;                                // row groups (4, 2, 1, 1); waves >= R * wpr idle in the row phases
+  const int rg = wave / wpr, cq = (wave % wpr) * 64 + lane;
+  const bool active = rg < R;
+  const float* qb = q + (size_t)b * D;
+  const float* cb = ctx + (size_t)b * L * D;
+  const float4 qv = active ? ld4g(qb + 4 * cq) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (int l0 = rg; l0 < L; l0 += 8 * R) {                           // (wave-uniform bounds)
+    float4 cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int l = l0 + R * k;
+      cv[k] = (active && l < L) ? ld4g(cb + (size_t)l * D + 4 * cq) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int l = l0 + R * k;
+      const float s = wave_sum((qv.x * cv[k].x + qv.y * cv[k].y) + (qv.z * cv[k].z + qv.w * cv[k].w));
+      if (active && lane == 0 && l < L) ws[wave][l] = s;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < L) {                                         // the waves of a row, in order
+    const int l = threadIdx.x, g = l % R;
+    float s = 0.0f;
+    for (int w = 0; w < wpr; ++w) s += ws[g * wpr + w][l];
+    sc[l] = s;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int l = 0; l < L; ++l) mx = fmaxf(mx, sc[l]);
+  float den = 0.0f;
+  for (int l = 0; l < L; ++l) den += expf(sc[l] - mx);
+  __syncthreads();
+  if ((int)threadIdx.x < L) {
+    const float pr = expf(sc[threadIdx.x] - mx) / den;
+    sc[threadIdx.x] = pr;
+    attn[(size_t)b * L + threadIdx.x] = pr;
+  }
+  __syncthreads();
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (active)
+    for (int l0 = rg; l0 < L; l0 += 8 * R) {
+      float4 cv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int l = l0 + R * k;
+        cv[k] = l < L ? ld4g(cb + (size_t)l * D + 4 * cq) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int l = l0 + R * k;
+        const float pl = l < L ? sc[l] : 0.0f;
+        acc.x += pl * cv[k].x; acc.y += pl * cv[k].y; acc.z += pl * cv[k].z; acc.w += pl * cv[k].w;
+      }
+    }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < Q) {                                         // the row groups of a column quad, in order
+    float4 a = red[threadIdx.x];                                      // (group 0's thread for quad t is thread t)
+    for (int g = 1; g < R; ++g) { const float4 v = red[g * Q + threadIdx.x]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    *reinterpret_cast<float4*>(mix + (size_t)b * D + 4 * threadIdx.x) = a;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_attn_fwd(const float* q, const float* ctx, float* attn, float* mix,
                                                        int B, int L, int D) {
   __shared__ float sc[64];
@@ -731,6 +808,77 @@ __global__ __launch_bounds__(kThreads) void k_attn_fwd(const float* q, const flo
     float acc = 0.0f;
     for (int l = 0; l < L; ++l) acc += sc[l] * cb[(size_t)l * D + e];
     mix[(size_t)b * D + e] = acc;
+  }
+}
+
+// backward in the same layout (D % 256 == 0): d loss / d prob_l as the forward's scores with gmix in place of q, the softmax
+// backward from LDS, then every thread writes its column quad of gctx for its rows and adds up its part of gq
+__global__ __launch_bounds__(kThreads) void k_attn_bwd_wide(const float* q, const float* ctx, const float* attn, const float* gmix,
+                                                            const float* gattn, float* gq, float* gctx, int B, int L, int D) {
+  __shared__ float ws[4][64];
+  __shared__ float pr[64], ga[64], gs[64];
+  __shared__ float4 red[kThreads];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Q = D >> 2, wpr = Q >> 6;
+  const int R = (kThreads / 64) / wpr;
+  const int rg = wave / wpr, cq = (wave % wpr) * 64 + lane;
+  const bool active = rg < R;
+  const float* cb = ctx + (size_t)b * L * D;
+  const float4 gv = active ? ld4g(gmix + (size_t)b * D + 4 * cq) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const float4 qv = active ? ld4g(q + (size_t)b * D + 4 * cq) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if ((int)threadIdx.x < L) pr[threadIdx.x] = attn[(size_t)b * L + threadIdx.x];
+  for (int l0 = rg; l0 < L; l0 += 8 * R) {
+    float4 cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int l = l0 + R * k;
+      cv[k] = (active && l < L) ? ld4g(cb + (size_t)l * D + 4 * cq) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int l = l0 + R * k;
+      const float s = wave_sum((gv.x * cv[k].x + gv.y * cv[k].y) + (gv.z * cv[k].z + gv.w * cv[k].w));
+      if (active && lane == 0 && l < L) ws[wave][l] = s;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < L) {
+    const int l = threadIdx.x, g = l % R;
+    float s = 0.0f;
+    for (int w = 0; w < wpr; ++w) s += ws[g * wpr + w][l];
+    ga[l] = s + (gattn ? gattn[(size_t)b * L + l] : 0.0f);
+  }
+  __syncthreads();
+  float dot = 0.0f;
+  for (int l = 0; l < L; ++l) dot += pr[l] * ga[l];
+  if ((int)threadIdx.x < L) gs[threadIdx.x] = pr[threadIdx.x] * (ga[threadIdx.x] - dot);   // softmax backward
+  __syncthreads();
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (active)
+    for (int l0 = rg; l0 < L; l0 += 8 * R) {
+      float4 cv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int l = l0 + R * k;
+        cv[k] = l < L ? ld4g(cb + (size_t)l * D + 4 * cq) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int l = l0 + R * k;
+        if (l < L) {
+          const float pl = pr[l], sl = gs[l];
+          acc.x += sl * cv[k].x; acc.y += sl * cv[k].y; acc.z += sl * cv[k].z; acc.w += sl * cv[k].w;
+          *reinterpret_cast<float4*>(gctx + ((size_t)b * L + l) * D + 4 * cq) =
+              make_float4(pl * gv.x + sl * qv.x, pl * gv.y + sl * qv.y, pl * gv.z + sl * qv.z, pl * gv.w + sl * qv.w);
+        }
+      }
+    }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < Q) {
+    float4 a = red[threadIdx.x];
+    for (int g = 1; g < R; ++g) { const float4 v = red[g * Q + threadIdx.x]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    *reinterpret_cast<float4*>(gq + (size_t)b * D + 4 * threadIdx.x) = a;
   }
 }
 
@@ -1470,7 +1618,9 @@ int t2o_attn_fwd(const float* q, const float* ctx, float* attn, float* mix, int 
   if (!q || !ctx || !attn || !mix) return fail(T2O_EINVAL, "attn_fwd: null pointer");
   if (B <= 0 || L <= 0 || L > 64 || D <= 0 || D % 64 != 0 || D > 1024)
     return fail(T2O_EINVAL, "attn: need 1 <= L <= 64, D % 64 == 0, D <= 1024");
-  k_attn_fwd<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, mix, B, L, D);
+  const bool aligned = ((reinterpret_cast<size_t>(q) | reinterpret_cast<size_t>(ctx) | reinterpret_cast<size_t>(mix)) & 15) == 0;
+  if (D % 256 == 0 && aligned) k_attn_fwd_wide<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, mix, B, L, D);
+  else k_attn_fwd<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, mix, B, L, D);
   return check_launch("attention forward");
 }
 
@@ -1479,7 +1629,10 @@ int t2o_attn_bwd(const float* q, const float* ctx, const float* attn, const floa
   if (!q || !ctx || !attn || !gmix || !gq || !gctx) return fail(T2O_EINVAL, "attn_bwd: null pointer");
   if (B <= 0 || L <= 0 || L > 64 || D <= 0 || D % 64 != 0 || D > 1024)
     return fail(T2O_EINVAL, "attn: need 1 <= L <= 64, D % 64 == 0, D <= 1024");
-  k_attn_bwd<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, gmix, gattn, gq, gctx, B, L, D);
+  const bool aligned = ((reinterpret_cast<size_t>(q) | reinterpret_cast<size_t>(ctx) | reinterpret_cast<size_t>(gmix) |
+                         reinterpret_cast<size_t>(gq) | reinterpret_cast<size_t>(gctx)) & 15) == 0;
+  if (D % 256 == 0 && aligned) k_attn_bwd_wide<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, gmix, gattn, gq, gctx, B, L, D);
+  else k_attn_bwd<<<(unsigned)B, kThreads, 0, (hipStream_t)stream>>>(q, ctx, attn, gmix, gattn, gq, gctx, B, L, D);
   return check_launch("attention backward");
 }
 

@@ -458,7 +458,7 @@ def test_fused_sequence_golden_chain6(executor, gold, dev):
 
 def test_attention_core(dev):
     import t2onet_amd.functional as T
-    for (B, L, D) in [(4, 14, 512), (64, 17, 512), (3, 1, 64), (5, 64, 1024)]:
+    for (B, L, D) in [(4, 14, 512), (64, 17, 512), (3, 1, 64), (5, 64, 1024), (2, 9, 256), (3, 5, 768), (2, 33, 128)]:
         q = synth.uniform((B, D), 91, -1, 1)
         ctx = synth.uniform((B, L, D), 92, -0.2, 0.2)
         ctx[:, L // 2:] *= 0.0 if L > 2 else 1.0          # zero-padded encoder rows take part in the softmax
