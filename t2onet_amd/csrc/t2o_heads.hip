@@ -115,10 +115,27 @@ __global__ __launch_bounds__(kHT) void k_heads_fc1(HeadArgs a) {
   constexpr int kRows = kSliceW / (kHT / 64);                  // rows per wave
   const int j0 = sl * kSliceW + wave * kRows;
   const float* w1 = a.w1[op] + (size_t)j0 * kD;
-#pragma unroll 4
+  // a wave's 16 rows: all 32 weight loads and the 16 bias loads in flight before the first reduction (one memory round trip,
+  // not four); the arithmetic of every row is row_dot's
+  const float4 v0 = *reinterpret_cast<const float4*>(ctx + 4 * lane), v1 = *reinterpret_cast<const float4*>(ctx + 256 + 4 * lane);
+  float4 a0[kRows], a1[kRows];
+#pragma unroll
   for (int k = 0; k < kRows; ++k) {
-    const float s = row_dot(w1 + (size_t)k * kD, ctx, lane) + a.b1[op][j0 + k];
-    if (lane == 0) hid[wave * kRows + k] = s > 0.0f ? s : 0.01f * s;
+    a0[k] = *reinterpret_cast<const float4*>(w1 + (size_t)k * kD + 4 * lane);
+    a1[k] = *reinterpret_cast<const float4*>(w1 + (size_t)k * kD + 256 + 4 * lane);
+  }
+  const float bias = lane < kRows ? a.b1[op][j0 + lane] : 0.0f;
+  float mine = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {
+    float s = (a0[k].x * v0.x + a0[k].y * v0.y) + (a0[k].z * v0.z + a0[k].w * v0.w);
+    s += (a1[k].x * v1.x + a1[k].y * v1.y) + (a1[k].z * v1.z + a1[k].w * v1.w);
+    s = wave_sum(s);
+    if (lane == k) mine = s;
+  }
+  if (lane < kRows) {
+    const float s = mine + bias;
+    hid[wave * kRows + lane] = s > 0.0f ? s : 0.01f * s;
   }
 }
 
