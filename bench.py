@@ -649,7 +649,7 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 2),
             'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()), 'parameters_finite': finite,
             'encoder_hipgraphs': bool(tr.graph_encoder and '_graphed_encoders' in model.__dict__),
-            'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0, 'library_gemms_tuned': bool(tune),
+            'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0, 'library_gemms_tuned': bool(tr.gemms_tuned),
             'ms_per_step_over_ranks': spread, 'allreduce_ms': allreduce_ms, 'allreduce_bytes': tr.grads.flat.numel() * 4,
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,

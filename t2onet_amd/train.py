@@ -138,12 +138,18 @@ class Trainer:
         tune_gemms: let the framework time the library's candidates for every GEMM shape it meets (torch's TunableOp; the
         decoder's ~20 shapes with M = batch, during the first steps) and keep the fastest -- PROCESS-WIDE and sticky, hence
         opt-in.  The default pick is latency-bound at these sizes (5.5-9.5 us per call against 3.9-7 us for the best one)."""
+        self.gemms_tuned = False
         if tune_gemms and next(model.parameters()).is_cuda:
-            torch.cuda.tunable.enable(True)
-            torch.cuda.tunable.tuning_enable(True)
-            torch.cuda.tunable.set_max_tuning_duration(50)     # ms per candidate set
-            import tempfile                                    # (the result file torch writes at exit: not into the working directory)
-            torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), 't2o_tunableop_%d.csv' % os.getpid()), True)
+            try:
+                import tempfile                                # (the result file torch writes at exit: not into the working directory)
+                torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), 't2o_tunableop_%d.csv' % os.getpid()), True)
+                torch.cuda.tunable.set_max_tuning_duration(50)     # ms per candidate set
+                torch.cuda.tunable.enable(True)
+                torch.cuda.tunable.tuning_enable(True)
+                self.gemms_tuned = True
+            except (AttributeError, RuntimeError) as e:        # a framework build without the autotuner: the default picks stay
+                import warnings
+                warnings.warn('library GEMM tuning unavailable (%s: %s)' % (type(e).__name__, e))
         self.model, self.opt = model, opt
         self.grads = FlatGradients(model.parameters())
         lr = lr if lr is not None else opt.learning_rate
