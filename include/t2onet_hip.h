@@ -362,6 +362,9 @@ int t2o_conv3x3_wgrad_acc_nhwc(const float* x, const float* dy, float* dw, void*
  * weight the stride-1 data gradient runs the forward kernel with; taps = 9, flip = 0: the stride-2 data gradient's;
  * taps = 1: the transposed 1x1 shortcut weight.  Co, Ci multiples of 32. */
 int t2o_conv_weight_transform(const float* w, float* wt, int Co, int Ci, int taps, int flip, void* stream);
+/* n <= 32 of them in one launch (HOST arrays of length n): an encoder's 20 weights once per optimiser step */
+int t2o_conv_weight_transform_batch(const float* const* w, float* const* wt, const int* Co, const int* Ci, const int* taps,
+                                    const int* flip, int n, void* stream);
 
 /* t2o_conv3x3_dgrad_nhwc with the transformed weight supplied (wt from t2o_conv_weight_transform(w, wt, Co, Ci, 9, 1))
  * and an optional addend (N,H,W,Ci) added to dx in the kernel's epilogue: the gradient a BasicBlock's input receives
@@ -434,6 +437,7 @@ int t2o_conv3x3_any_wgrad_nhwc(const float* x, const float* dy, float* dw, void*
  * t2o_gemm_tn_batched M, N % 128 == 0, rows % (64 * splits) == 0; all tensors 16-byte aligned. */
 int t2o_wino_padded_tiles(int N, int H, int W);
 int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* stream);
+int t2o_wino_weight_transform_batch(const float* const* w, float* const* U, const int* Cn, const int* Ck, int n, void* stream);   /* n <= 32 banks, one launch */
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
 int t2o_wino_stats_rows(int N, int H, int W, int C);
 int t2o_wino_output_transform(const float* M, const float* addend, float* y, float* stats, int N, int H, int W, int C, void* stream);

@@ -1435,6 +1435,35 @@ __global__ __launch_bounds__(256) void k_stem_wgrad(const float* __restrict__ x,
   }
 }
 
+// every layer's weight transform of an optimiser step in ONE launch (the encoder has 20: 5 us each when launched one by one)
+constexpr int kMaxWtJobs = 32;
+struct WtJobs {
+  const float* w[kMaxWtJobs];
+  float* wt[kMaxWtJobs];
+  int Co[kMaxWtJobs], Ci[kMaxWtJobs], taps[kMaxWtJobs], flip[kMaxWtJobs];
+  unsigned first[kMaxWtJobs + 1];       // first workgroup of job j; first[n] = the grid
+  int n;
+};
+
+__global__ __launch_bounds__(kConvThreads) void k_conv_flip_weight_batch(WtJobs jb) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < jb.n && blockIdx.x >= jb.first[j + 1]) ++j;                 // (uniform)
+  const unsigned local = blockIdx.x - jb.first[j];
+  const int Co = jb.Co[j], Ci = jb.Ci[j], taps = jb.taps[j], flip = jb.flip[j];
+  const int nci = Ci / 32, nco = Co / 32;
+  const int tap = (int)(local / (unsigned)(nci * nco)), rem = (int)(local % (unsigned)(nci * nco));
+  const int ci0 = (rem % nci) * 32, co0 = (rem / nci) * 32;
+  const float* w = jb.w[j];
+  float* wt = jb.wt[j];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((size_t)(co0 + r) * taps + tap) * Ci + ci0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) wt[((size_t)(ci0 + r) * taps + (flip ? taps - 1 - tap : tap)) * Co + co0 + tx] = tile[tx][r];
+}
+
 // 16-byte accesses (LDS-DMA pieces, float4 loads) straight from caller storage: every tensor base must be 16-byte aligned
 bool misaligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
   return ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(c) | reinterpret_cast<size_t>(d)) & 15) != 0;
@@ -1611,6 +1640,25 @@ int t2o_conv_weight_transform(const float* w, float* wt, int Co, int Ci, int tap
     return set_error(T2O_EUNSUPPORTED, "conv_weight_transform: channel counts must be multiples of 32, 1..9 taps");
   k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), (unsigned)taps), kConvThreads, 0, (hipStream_t)stream>>>(w, wt, Co, Ci, flip ? 1 : 0);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv_weight_transform launch failed");
+}
+
+int t2o_conv_weight_transform_batch(const float* const* w, float* const* wt, const int* Co, const int* Ci, const int* taps,
+                                    const int* flip, int n, void* stream) {
+  if (!w || !wt || !Co || !Ci || !taps || !flip || n < 1 || n > kMaxWtJobs) return set_error(T2O_EINVAL, "conv_weight_transform_batch: null pointer or more than 32 jobs");
+  WtJobs jb = {};
+  jb.n = n;
+  unsigned total = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!w[j] || !wt[j]) return set_error(T2O_EINVAL, "conv_weight_transform_batch: null pointer");
+    if (Co[j] < 32 || Ci[j] < 32 || Co[j] % 32 != 0 || Ci[j] % 32 != 0 || taps[j] < 1 || taps[j] > 9)
+      return set_error(T2O_EUNSUPPORTED, "conv_weight_transform_batch: channel counts must be multiples of 32, 1..9 taps");
+    jb.w[j] = w[j]; jb.wt[j] = wt[j]; jb.Co[j] = Co[j]; jb.Ci[j] = Ci[j]; jb.taps[j] = taps[j]; jb.flip[j] = flip[j] ? 1 : 0;
+    jb.first[j] = total;
+    total += (unsigned)(Ci[j] / 32) * (unsigned)(Co[j] / 32) * (unsigned)taps[j];
+  }
+  jb.first[n] = total;
+  k_conv_flip_weight_batch<<<total, kConvThreads, 0, (hipStream_t)stream>>>(jb);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv_weight_transform_batch launch failed");
 }
 
 size_t t2o_conv3x3_fwd_workspace_bytes(int N, int H, int W, int Ci, int Co) {

@@ -285,6 +285,47 @@ __global__ __launch_bounds__(kThreads) void k_wino_dw(const float* __restrict__ 
   }
 }
 
+// the filter transforms of several layers in ONE launch (once per optimiser step: 6 forward + 6 data-gradient banks)
+constexpr int kMaxUJobs = 32;
+struct UJobs {
+  const float* w[kMaxUJobs];
+  float* U[kMaxUJobs];
+  int Cn[kMaxUJobs], Ck[kMaxUJobs];
+  unsigned first[kMaxUJobs + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(kThreads) void k_wino_weight_batch(UJobs jb) {
+  int j = 0;
+  while (j + 1 < jb.n && blockIdx.x >= jb.first[j + 1]) ++j;
+  const size_t idx = (size_t)(blockIdx.x - jb.first[j]) * kThreads + threadIdx.x, total = (size_t)jb.Cn[j] * jb.Ck[j];
+  if (idx >= total) return;
+  const int Ck = jb.Ck[j];
+  const int n = (int)(idx / Ck), k = (int)(idx - (size_t)n * Ck);
+  const float* w = jb.w[j];
+  float* U = jb.U[j];
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) g[a][b] = w[((size_t)n * 9 + a * 3 + b) * Ck + k];
+  float r[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    r[0][b] = g[0][b];
+    r[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
+    r[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
+    r[3][b] = g[2][b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    U[(size_t)(4 * a + 0) * total + idx] = r[a][0];
+    U[(size_t)(4 * a + 1) * total + idx] = 0.5f * ((r[a][0] + r[a][2]) + r[a][1]);
+    U[(size_t)(4 * a + 2) * total + idx] = 0.5f * ((r[a][0] + r[a][2]) - r[a][1]);
+    U[(size_t)(4 * a + 3) * total + idx] = r[a][2];
+  }
+}
+
 bool wino_shape_ok(int N, int H, int W, int C) {
   return N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C >= 4 && C <= 1024 && (C & (C - 1)) == 0 &&
          (size_t)N * H * W * C < ((size_t)1 << 40);
@@ -307,6 +348,22 @@ int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* st
   const size_t total = (size_t)Cn * Ck;
   k_wino_weight<<<(unsigned)((total + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(w, U, Cn, Ck);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_weight_transform: launch failed");
+}
+
+int t2o_wino_weight_transform_batch(const float* const* w, float* const* U, const int* Cn, const int* Ck, int n, void* stream) {
+  if (!w || !U || !Cn || !Ck || n < 1 || n > kMaxUJobs) return set_error(T2O_EINVAL, "wino_weight_transform_batch: null pointer or more than 32 jobs");
+  UJobs jb = {};
+  jb.n = n;
+  unsigned total = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!w[j] || !U[j] || Cn[j] <= 0 || Ck[j] <= 0) return set_error(T2O_EINVAL, "wino_weight_transform_batch: null pointer or bad shape");
+    jb.w[j] = w[j]; jb.U[j] = U[j]; jb.Cn[j] = Cn[j]; jb.Ck[j] = Ck[j];
+    jb.first[j] = total;
+    total += (unsigned)(((size_t)Cn[j] * Ck[j] + kThreads - 1) / kThreads);
+  }
+  jb.first[n] = total;
+  k_wino_weight_batch<<<total, kThreads, 0, (hipStream_t)stream>>>(jb);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_weight_transform_batch: launch failed");
 }
 
 int t2o_wino_padded_tiles(int N, int H, int W) {

@@ -37,6 +37,17 @@ def _fast_direct(stride, Hi, Wi, Wo):
     return Wo % 8 == 0 and (stride == 1 or (Hi % 2 == 0 and Wi % 2 == 0))
 
 
+def _batched(fn, name, st, srcs, dsts, int_lists):
+    """fn(src pointers, dst pointers, int arrays..., n, stream) for up to 32 jobs per launch (host arrays)."""
+    import ctypes
+    for i in range(0, len(srcs), 32):
+        n = min(32, len(srcs) - i)
+        a = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs[i:i + n]])
+        b = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts[i:i + n]])
+        ints = [(ctypes.c_int * n)(*lst[i:i + n]) for lst in int_lists]
+        _lib.check(fn(a, b, *ints, n, st), name)
+
+
 def _nhwc(N, H, W, C, dev):
     return torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
 
@@ -85,14 +96,18 @@ class TrunkPlan:
         if self.persistent_wt and self._uf_valid:
             return self._uf
         uf = self._uf if (self.persistent_wt and self._uf is not None) else {}
+        ujobs = []
         for conv in self.wino_convs():
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             u = uf.get(id(conv))
             if u is None or u.device != w.device:
                 u = torch.empty((16, Co, Ci), dtype=torch.float32, device=w.device)
-            _lib.check(lib.t2o_wino_weight_transform(_ptr(w), _ptr(u), Co, Ci, st), 't2o_wino_weight_transform')
+            ujobs.append((w, u, Co, Ci))
             uf[id(conv)] = u
+        if ujobs:
+            _batched(lib.t2o_wino_weight_transform_batch, 't2o_wino_weight_transform_batch', st,
+                     [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
         if self.persistent_wt:
             self._uf, self._uf_valid = uf, True
         return uf
@@ -119,6 +134,7 @@ class TrunkPlan:
         if self.persistent_wt and self._wt_valid:
             return self._wt
         wt = self._wt if (self.persistent_wt and self._wt is not None) else {}
+        jobs = []                                              # every layer's transform in ONE launch
         for b in self.blocks:
             convs = [(b.conv1, 9, 1 if b.conv1.stride[0] == 1 else 0), (b.conv2, 9, 1)]
             if len(b.shortcut):
@@ -129,18 +145,23 @@ class TrunkPlan:
                 t = wt.get(id(conv))
                 if t is None or t.device != w.device:
                     t = torch.empty(Ci * taps * Co, dtype=torch.float32, device=w.device)
-                _lib.check(lib.t2o_conv_weight_transform(_ptr(w), _ptr(t), Co, Ci, taps, flip, st), 't2o_conv_weight_transform')
+                jobs.append((w, t, Co, Ci, taps, flip))
                 wt[id(conv)] = t
+        _batched(lib.t2o_conv_weight_transform_batch, 't2o_conv_weight_transform_batch', st,
+                 [j[0] for j in jobs], [j[1] for j in jobs], [[j[2] for j in jobs], [j[3] for j in jobs], [j[4] for j in jobs], [j[5] for j in jobs]])
         ub = self._ub if self.persistent_wt else {}
-        if _WINOGRAD:
+        if _WINOGRAD and self.wino_convs():
+            ujobs = []
             for conv in self.wino_convs():                     # data gradient: the same transform of the mirrored transpose
                 w = conv.weight
                 Co, Ci = w.shape[0], w.shape[1]
                 u = ub.get(id(conv))
                 if u is None or u.device != w.device:
                     u = torch.empty((16, Ci, Co), dtype=torch.float32, device=w.device)
-                _lib.check(lib.t2o_wino_weight_transform(_ptr(wt[id(conv)]), _ptr(u), Ci, Co, st), 't2o_wino_weight_transform')
+                ujobs.append((wt[id(conv)], u, Ci, Co))
                 ub[id(conv)] = u
+            _batched(lib.t2o_wino_weight_transform_batch, 't2o_wino_weight_transform_batch', st,
+                     [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
         wt['wino'] = ub
         if self.persistent_wt:
             self._wt, self._wt_valid, self._ub = wt, True, ub

@@ -189,3 +189,28 @@ def test_combined_backward_equals_the_two_separate_pipelines():
     dw1 = torch.zeros_like(dw0)
     T.wino_backward_nhwc(dy, Vx, Ud, dw1, dx1, N, H, W, ad, False)
     assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+
+
+def test_batched_weight_transforms_equal_the_single_ones():
+    """t2o_conv_weight_transform_batch / t2o_wino_weight_transform_batch (every layer of a step in one launch) == the per-layer calls."""
+    import ctypes
+    import t2onet_amd.functional as T
+    from t2onet_amd import _lib
+    from t2onet_amd.encoder import _batched
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    st = T._stream(dev)
+    specs = [(64, 64, 9, 1), (128, 64, 9, 0), (128, 64, 1, 0), (256, 256, 9, 1), (512, 256, 9, 0), (64, 128, 9, 1)]
+    ws = [synth.uniform((co, taps, ci), 1900 + i, -1.0, 1.0).to(dev) for i, (co, ci, taps, flip) in enumerate(specs)]
+    outs = [torch.empty(ci * taps * co, device=dev) for (co, ci, taps, flip) in specs]
+    _batched(lib.t2o_conv_weight_transform_batch, 'batch', st, ws, outs,
+             [[s[0] for s in specs], [s[1] for s in specs], [s[2] for s in specs], [s[3] for s in specs]])
+    for w, o, (co, ci, taps, flip) in zip(ws, outs, specs):
+        ref = torch.empty_like(o)
+        _lib.check(lib.t2o_conv_weight_transform(T._ptr(w), T._ptr(ref), co, ci, taps, flip, st), 'single')
+        assert torch.equal(o, ref)
+    banks = [synth.uniform((cn, 3, 3, ck), 1950 + i, -1.0, 1.0).to(dev) for i, (cn, ck) in enumerate([(64, 128), (256, 256), (32, 512)])]
+    us = [torch.empty(16, b.shape[0], b.shape[3], device=dev) for b in banks]
+    _batched(lib.t2o_wino_weight_transform_batch, 'batch', st, banks, us, [[b.shape[0] for b in banks], [b.shape[3] for b in banks]])
+    for b, u in zip(banks, us):
+        assert torch.equal(u, T.wino_weight(b, b.shape[0], b.shape[3]))
