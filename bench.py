@@ -474,10 +474,11 @@ def _host_info():
 
 
 def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
-    """configs[0] (one image, brightness->contrast->saturation), configs[1] (6-op
-    sequence fwd + L1 + bwd) and a bounded sample of configs[2] (the episode/L1 train step), each through
-    oracle/cpu_ref.py -- the eager-PyTorch restatement of the reference, validated against it by the
-    committed goldens -- on this node's host cores."""
+    """BASELINE.md section 3 through oracle/cpu_ref.py -- the eager-PyTorch restatement of the reference, validated against
+    it by the committed goldens -- on this node's host cores.  The object's own value is configs[2], the headline's
+    workload (the episode/L1 train step at its full batch); `configs_0` (one image, brightness->contrast->saturation) and
+    `configs_1` (6-op sequence fwd + L1 + bwd, bs=64) are sub-objects.  `cores` = `threads` = torch threads used (chosen by
+    a probe: all hardware threads are far slower on eager 50 MB ops), `physical_cores` = what the node has."""
     import torch
     from oracle import cpu_ref, synth
     opt = cpu_ref.default_opt()
@@ -492,21 +493,23 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
     img, tgt, params = make_inputs(CFG2_OPS, sample_cfg2, H, W, 'cpu')
     threads = _pick_threads(lambda: seq_once(CFG2_OPS, img[:8], tgt[:8], params[:, :8]))
     med2, n2 = _median_time(lambda: seq_once(CFG2_OPS, img, tgt, params), 7, 25.0)
-    res = {'value': round(sample_cfg2 / med2, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-           'config': 'configs[1]',
-           'sample': 'oracle/cpu_ref.py eager fp32, ops %s fwd+L1+bwd, bs=%d %dx%d, median of %d reps (%.2f s each), '
-                     '%d torch threads (chosen by a probe)' % (CFG2_OPS, sample_cfg2, H, W, n2, med2, threads),
-           'host': host}
+    cfg1 = {'value': round(sample_cfg2 / med2, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'config': 'configs[1]',
+            'sample': 'oracle/cpu_ref.py eager fp32, ops %s fwd+L1+bwd, bs=%d %dx%d, median of %d reps (%.2f s each), '
+                      '%d torch threads (chosen by a probe)' % (CFG2_OPS, sample_cfg2, H, W, n2, med2, threads)}
     # configs[0]: single 256x256 image, 3-op sequence, forward + L1 + backward
     ops1 = [0, 1, 2]
     i1, t1, p1 = make_inputs(ops1, 1, H, W, 'cpu')
     torch.set_num_threads(min(threads, 8))
     med1, n1 = _median_time(lambda: seq_once(ops1, i1, t1, p1), 15, 5.0)
-    res['cfg1'] = {'value': round(1.0 / med1, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-                   'config': 'configs[0]', 'sample': 'one %dx%d image, ops %s fwd+L1+bwd, median of %d reps (%.4f s each)'
-                                                     % (H, W, ops1, n1, med1)}
+    cfg0 = {'value': round(1.0 / med1, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'config': 'configs[0]', 'sample': 'one %dx%d image, ops %s fwd+L1+bwd, median of %d reps (%.4f s each)'
+                                              % (H, W, ops1, n1, med1)}
     torch.set_num_threads(threads)
-    # configs[2]: episode/L1 train step on a bounded sample (fwd + END select + L1 + bwd + Adam), 1 warm-up + 1..2 reps
+    # configs[2] -- the HEADLINE's own baseline: the episode/L1 train step at its full batch (fwd + END select + L1 + bwd +
+    # Adam), 1 warm-up + 1..2 reps
+    res = {'value': None, 'unit': 'images/sec', 'cores': threads, 'threads': threads, 'physical_cores': host['physical_cores'],
+           'logical_cpus': host['logical_cpus'], 'kind': 'port', 'config': 'configs[2]', 'sample': None, 'host': host}
     try:
         B3 = sample_cfg3
         sd = cpu_ref.make_leaf_params(synth.fill_state_dict(cpu_ref.actor_state_skeleton(opt)))
@@ -523,12 +526,14 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
             cpu_ref.l1_loss(pred, xtgt).backward()
             adam.step()
         med3, n3 = _median_time(train_once, 2, 12.0)
-        res['cfg3'] = {'value': round(B3 / med3, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-                       'config': 'configs[2]',
-                       'sample': 'oracle episode_forward (training mode, sampled ops) + END select + L1 + backward + Adam, '
-                                 'bs=%d %dx%d, median of %d reps after 1 warm-up (%.2f s each)' % (B3, H, W, n3, med3)}
+        res['value'] = round(B3 / med3, 3)
+        res['sample'] = ('oracle/cpu_ref.py episode_forward (training mode, sampled ops) + END select + L1 + backward + Adam, '
+                         'bs=%d %dx%d fp32, median of %d reps after 1 warm-up (%.2f s each), %d torch threads (chosen by a probe) of '
+                         '%s physical cores' % (B3, H, W, n3, med3, threads, host['physical_cores']))
     except Exception as e:                     # noqa: BLE001
-        res['cfg3'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        res['error'] = '%s: %s' % (type(e).__name__, e)
+    res['configs_0'] = cfg0
+    res['configs_1'] = cfg1
     if with_gpu_parity:
         # parity gate reported with the numbers: the GPU path against the oracle on 4 images
         try:

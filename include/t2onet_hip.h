@@ -473,6 +473,75 @@ int t2o_lstm_layer_bwd(const float* whh, const long long* len, const float* cnew
                        const float* dhn, const float* dcn, float* dgates, float* carry_h, float* dc,
                        int B, int L, int H, int D, void* stream);
 
+/* ---- image feature head: models/actor.py:50,142-143,215-216  feat = relu(bn1(vis_encoder.fc(pooled))) -- Linear(K -> D),
+ * BatchNorm1d(D) in training (batch statistics over the B rows, running statistics updated as torch does: momentum,
+ * unbiased variance, num_batches_tracked += 1) or evaluation mode, ReLU -- one launch (a workgroup owns 16 feature
+ * columns of the whole batch, so the statistics never leave it).  B <= 64, K % 4 == 0; rows 16-byte aligned.
+ * Backward: g_feat -> d_fc (gradient of the Linear's output, kept for the caller's weight-gradient product
+ * d_fc^T . pooled), d_bn (2, D) = [d weight; d bias] of the batch norm, d_pooled = d_fc . fc_w (skipped when NULL). */
+typedef struct t2o_image_feature {
+  const float *fc_w, *fc_b;                    /* (D, K), (D) nullable */
+  const float *bn_w, *bn_b;                    /* (D) nullable (affine=False) */
+  float *running_mean, *running_var;           /* (D); nullable in training mode (no update) */
+  long long* num_batches_tracked;              /* nullable */
+  const float* pooled;                         /* (B, K) */
+  float* pooled_copy;                          /* nullable: (B, K) copy for the caller's weight-gradient product */
+  float *fc_out, *stats, *feat;                /* (B, D) pre-norm, (2, D) = mean, 1/std, (B, D) */
+  const float* g_feat;                         /* backward: (B, D) */
+  float *d_fc, *d_bn, *d_pooled;               /* (B, D), (2, D), (B, K) nullable */
+  float momentum, eps;
+  int training, B, K, D;
+} t2o_image_feature_t;
+int t2o_image_feature_fwd(const t2o_image_feature_t* args, void* stream);
+int t2o_image_feature_bwd(const t2o_image_feature_t* args, void* stream);
+
+/* ---- one decoding step: models/action_decoder.py:38-64 Decoder.forward_step with models/attention.py:17-44 inside --
+ *   step_in = [embedding[prev_op] (E) | relu(vis_linear(feat)) (D)]
+ *   2-layer LSTM(E + D -> D) one step (gate order i, f, g, o; biases nullable)  ->  q = h1n
+ *   attn = softmax_l(q . enc_l) over ALL L rows, mix = sum_l attn_l enc_l          (t2o_attn_fwd)
+ *   ctx = tanh(linear_out([mix | q]));  logp = log_softmax(out_linear(ctx))
+ * as 6 launches.  Everything a backward needs is left in caller storage (`saved`): the activated gates, both new
+ * states, copies hp0 / hp1 of the previous hidden states (nullable), mix, ctx, logp.
+ * Backward (9 launches): gradients of logp / ctx / the new states (each nullable; at least one of g_ctx, g_logp) ->
+ * d_feat, d_h0, d_c0, d_h1, d_c1, d_enc.  Only DATA gradients: the pre-activation gradients d_logits (B, V; written
+ * only when g_logp is given), d_lin (B, D), d_gates1, d_gates0 (B, 4D), d_step_in (B, E + D), d_vis (B, D) stay in
+ * caller storage and the caller forms each weight gradient as ONE product over all the steps of a train step
+ * (out_linear: d_logits^T ctx; linear_out: d_lin^T [mix | h1n]; LSTM layer 1: d_gates1^T h0n, d_gates1^T hp1; layer 0:
+ * d_gates0^T step_in, d_gates0^T hp0; vis_linear: d_vis^T feat_copy; embedding: rows prev_op += d_step_in[:, :E]).
+ * D % 64 == 0, D <= 1024, E % 4 == 0, V <= 16, L <= 64; every buffer 16-byte aligned, rows dense. */
+typedef struct t2o_decoder_step {
+  /* parameters */
+  const float *emb;                            /* (V, E) */
+  const float *vis_w, *vis_b;                  /* (D, D), (D) nullable */
+  const float *w_ih0, *w_hh0, *b_ih0, *b_hh0;  /* (4D, E + D), (4D, D), (4D), (4D) */
+  const float *w_ih1, *w_hh1, *b_ih1, *b_hh1;  /* (4D, D), (4D, D), (4D), (4D) */
+  const float *lo_w, *lo_b;                    /* attention.linear_out (D, 2D), (D) nullable */
+  const float *out_w, *out_b;                  /* out_linear (V, D), (V) nullable */
+  /* forward inputs */
+  const long long* prev_op;                    /* (B) token of the previous operator */
+  const float *feat, *h0, *c0, *h1, *c1;       /* (B, D) each */
+  const float* enc;                            /* (B, L, D) request encoding */
+  /* forward outputs and saved values */
+  float *step_in;                              /* (B, E + D) */
+  float *feat_copy, *hp0, *hp1;                /* (B, D) each, nullable: copies of feat / h0 / h1 (the X of their products) */
+  long long* prev_op_copy;                     /* (B) nullable */
+  float *gates0, *gates1;                      /* (B, 4D) activated i, f, g, o */
+  float *h0n, *c0n, *h1n, *c1n;                /* (B, D) new states */
+  float *attn, *mix, *ctx, *logp;              /* (B, L), (B, D), (B, D), (B, V) */
+  /* backward inputs (nullable) */
+  const float *g_logp, *g_ctx, *g_h0n, *g_c0n, *g_h1n, *g_c1n;
+  /* backward: kept for the weight gradients */
+  float *d_logits, *d_lin, *d_gates1, *d_gates0, *d_step_in, *d_vis;
+  /* backward scratch */
+  float *d_ctx, *d_mix, *d_qa, *d_q, *d_x1;    /* (B, D) each */
+  /* backward outputs */
+  float *d_feat, *d_h0, *d_c0, *d_h1, *d_c1;   /* (B, D) each */
+  float* d_enc;                                /* (B, L, D) */
+  int B, L, D, E, V;
+} t2o_decoder_step_t;
+int t2o_decoder_step_fwd(const t2o_decoder_step_t* args, void* stream);
+int t2o_decoder_step_bwd(const t2o_decoder_step_t* args, void* stream);
+
 /* Rewrites a captured, not yet instantiated hipGraph (hipGraph_t) in place: every memset node becomes a kernel node
  * doing the same fill, with the same dependencies and dependents; *replaced = how many.  Memset nodes were seen to
  * run out of order with neighbouring kernel nodes on replay (ROCm 7.2 / gfx950): t2onet_amd/graphs.py calls this on

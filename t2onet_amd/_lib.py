@@ -116,7 +116,29 @@ SIGNATURES = {
     't2o_conv3x3_any_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     't2o_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     't2o_lstm_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    't2o_image_feature_fwd': (_I, [_P, _P]),
+    't2o_image_feature_bwd': (_I, [_P, _P]),
+    't2o_decoder_step_fwd': (_I, [_P, _P]),
+    't2o_decoder_step_bwd': (_I, [_P, _P]),
 }
+
+
+class ImageFeatureArgs(ctypes.Structure):
+    """t2o_image_feature_t of include/t2onet_hip.h (field for field)."""
+    _fields_ = ([(n, _P) for n in ('fc_w', 'fc_b', 'bn_w', 'bn_b', 'running_mean', 'running_var', 'num_batches_tracked', 'pooled',
+                                   'pooled_copy', 'fc_out', 'stats', 'feat', 'g_feat', 'd_fc', 'd_bn', 'd_pooled')]
+                + [('momentum', _F), ('eps', _F), ('training', _I), ('B', _I), ('K', _I), ('D', _I)])
+
+
+class DecoderStepArgs(ctypes.Structure):
+    """t2o_decoder_step_t of include/t2onet_hip.h (field for field)."""
+    _fields_ = ([(n, _P) for n in ('emb', 'vis_w', 'vis_b', 'w_ih0', 'w_hh0', 'b_ih0', 'b_hh0', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1',
+                                   'lo_w', 'lo_b', 'out_w', 'out_b', 'prev_op', 'feat', 'h0', 'c0', 'h1', 'c1', 'enc', 'step_in',
+                                   'feat_copy', 'hp0', 'hp1', 'prev_op_copy', 'gates0', 'gates1', 'h0n', 'c0n', 'h1n', 'c1n', 'attn', 'mix', 'ctx', 'logp',
+                                   'g_logp', 'g_ctx', 'g_h0n', 'g_c0n', 'g_h1n', 'g_c1n', 'd_logits', 'd_lin', 'd_gates1',
+                                   'd_gates0', 'd_step_in', 'd_vis', 'd_ctx', 'd_mix', 'd_qa', 'd_q', 'd_x1', 'd_feat', 'd_h0',
+                                   'd_c0', 'd_h1', 'd_c1', 'd_enc')]
+                + [(n, _I) for n in ('B', 'L', 'D', 'E', 'V')])
 
 _lib = None
 

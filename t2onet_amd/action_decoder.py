@@ -6,8 +6,11 @@ the sub-module names (`embedding`, `rnn`, `out_linear`, `vis_linear`, `attention
 
 Per step:  [operator embedding (300) | relu(vis_linear(image feature)) (512)]  ->  2-layer LSTM
 (812 -> 512)  ->  dot-product attention over the request encoding (HIP kernel, attention.py)
-->  out_linear  ->  log-softmax over the 11 operator tokens.  The LSTM cell and the Linear layers are
-library GEMMs (hipBLASLt through PyTorch-ROCm) plus PyTorch's fused gate kernel.
+->  out_linear  ->  log-softmax over the 11 operator tokens.  On the GPU the step is 7 launches of this library
+(decoder_step.py / t2o_decoder.hip: every Linear, the LSTM cells with their gates, tanh and log-softmax fused into small-M
+matrix-core products); the per-layer path below (library GEMMs plus PyTorch's fused gate kernel) remains for
+configurations the fused step does not take (GRU, active dropout, attention with a weight) and for host tensors, which
+only the multi-process CPU tests of the data-parallel logic use.
 """
 import torch
 import torch.nn as nn
@@ -15,6 +18,9 @@ import torch.nn.functional as F
 
 from . import functional as T
 from .attention import Attention
+
+
+_FUSED_STEP = True        # module switch for the tests: False sends GPU calls through the per-layer path below
 
 
 def merge_directions(state):
@@ -46,6 +52,16 @@ class Decoder(nn.Module):
         None, context (B,d))."""
         n = input_var.shape[0]
         gpu = img_feat.is_cuda and img_feat.dtype == torch.float32
+        if gpu and _FUSED_STEP:
+            from . import decoder_step as DS
+            if DS.step_supported(self, input_var, hidden, encoder_outputs, img_feat):
+                # the whole step on this library's small-M kernels: 7 launches forward, 10 backward (t2o_decoder.hip)
+                stacked = torch.is_tensor(hidden[0])
+                state = (hidden[0].unbind(0), hidden[1].unbind(0)) if stacked else hidden
+                logp, state, attn, context = DS.decoder_step(self, input_var, state, encoder_outputs, img_feat, self.__dict__.get('_tape'))
+                if stacked:
+                    state = (torch.stack(state[0], 0), torch.stack(state[1], 0))
+                return logp, state, attn, context
         token = self.embedding(input_var)                                   # (B,1,300)
         vis = T.linear_acc(img_feat, self.vis_linear.weight, self.vis_linear.bias) if gpu else self.vis_linear(img_feat)
         visual = F.relu(vis).unsqueeze(1)                                   # (B,1,d)

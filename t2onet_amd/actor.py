@@ -26,6 +26,7 @@ from .actor_resnet import ResNet
 from .executor import Executor, PARAM_PAD
 from .lang_encoder import RNNEncoder
 
+_FUSED_FEATURE = True         # relu(bn1(fc(pooled))) as one launch (decoder_step.image_feature); module switch for the tests
 _OVERLAP_LANG = True          # request encoder on a side stream (Actor._encode_request); module switch for A/B runs
 _SIDE_STREAMS = {}
 
@@ -96,6 +97,12 @@ class Actor(nn.Module):
         graphed = self.__dict__.get('_graphed_encoders')
         if graphed is not None and self.training and graphed.usable(img, call):
             return F.relu(self.bn1(graphed(img, call)))
+        if img.is_cuda and img.dtype == torch.float32 and _FUSED_FEATURE:
+            from . import decoder_step as DS
+            pooled = self.vis_encoder.pooled_features(img)
+            if DS.feature_supported(pooled, self.vis_encoder.fc, self.bn1):
+                return DS.image_feature(pooled, self.vis_encoder.fc, self.bn1, self.__dict__.get('_tape'))     # fc + bn1 + ReLU: one launch
+            return F.relu(self.bn1(T.linear_acc(pooled, self.vis_encoder.fc.weight, self.vis_encoder.fc.bias)))
         return F.relu(self.bn1(self.vis_encoder(img)))
 
     def graph_image_encoder(self, sample_img, calls):

@@ -135,13 +135,20 @@ class ResNet(nn.Module):
         return plan
 
     def forward(self, x):
+        pooled = self.pooled_features(x)
+        if pooled.is_cuda and pooled.dtype == torch.float32 and torch.is_grad_enabled():
+            return T.linear_acc(pooled, self.fc.weight, self.fc.bias)
+        return self.fc(pooled)
+
+    def pooled_features(self, x):
+        """Everything before `fc` (models/actor_resnet.py:98-106): the convolutional trunk and the global mean, (N, 512)."""
         if _TRUNK and _FUSED and _OWN_WGRAD and self.training and x.is_cuda and torch.is_grad_enabled():
             plan = self.trunk_plan()
             if plan.supported(x):
                 from .encoder import trunk_forward
                 torch._foreach_add_(self._batch_counters(), 1)
                 x = trunk_forward(plan, x, pool=True)
-                return T.linear_acc(x.view(x.size(0), -1), self.fc.weight, self.fc.bias)
+                return x.view(x.size(0), -1)
         if self.conv1.weight.is_contiguous(memory_format=torch.channels_last) and x.is_cuda:
             # channels-last encoder (Actor.use_channels_last): one packed NHWC copy of the 3-channel image, then every
             # convolution and every fused batch-norm pass runs NHWC -- no layout transposes inside the encoder
@@ -157,4 +164,4 @@ class ResNet(nn.Module):
             for block in layer:
                 x = block(x, counted)
         x = x.mean((2, 3))
-        return self.fc(x.view(x.size(0), -1))
+        return x.view(x.size(0), -1)

@@ -26,9 +26,6 @@
 #include "t2o_jit.h"
 #include "t2o_jit_embedded.h"
 
-#ifndef T2O_SRC_DIGEST
-#define T2O_SRC_DIGEST "unknown"
-#endif
 
 namespace t2o {
 int set_error(int code, const char* msg);
@@ -164,7 +161,7 @@ int jit_prepare(const int* ops, int K) {
   if (jit_lookup(ops, K, &have)) return T2O_OK;
   const std::string src = chain_source(ops, K);
   char key[64];
-  snprintf(key, sizeof(key), "%016llx", fnv64(std::string(T2O_SRC_DIGEST) + "|gfx950|O3|nocontract|" + src));
+  snprintf(key, sizeof(key), "%016llx", fnv64(std::string(t2o_source_digest()) + "|gfx950|O3|nocontract|" + src));
   std::string cache_dir;
   { std::lock_guard<std::mutex> lk(g_mu); cache_dir = g_cache_dir; }
   const std::string path = cache_dir.empty() ? std::string() : cache_dir + "/chain_" + key + ".hsaco";

@@ -1131,12 +1131,7 @@ __global__ __launch_bounds__(256) void k_zero_floats(float* p, size_t n) {
 extern "C" {
 
 int t2o_abi_version(void) { return 4; }   // 4: round 3 additions (accumulate forms, 1x1 / any-size convolutions, LSTM, choose_op, run-time specialisation)
-#ifndef T2O_SRC_DIGEST
-#define T2O_SRC_DIGEST "unstamped"
-#endif
-// the tag lets build.py read the digest out of the file without loading it
-static const char k_src_digest[] = "t2o-src-digest:" T2O_SRC_DIGEST;
-const char* t2o_source_digest(void) { return k_src_digest + 15; }
+// (t2o_source_digest: t2o_stamp.hip -- the only file compiled with the digest, so that an edit elsewhere recompiles one file)
 const char* t2o_last_error(void) { return g_err; }
 
 int t2o_op_num_params(int op) { return (op >= 0 && op <= 7) ? op_num_params(op) : -1; }

@@ -117,6 +117,24 @@ def load_image_short_side(path, short_size=600):
     return torch.from_numpy(img.astype(np.float32).transpose(2, 0, 1) / 255.0)
 
 
+def parse_sent(desc):
+    """Request text -> tokens as utils/text_utils.py:9-26 cleans them: whitespace split, lower case, punctuation removed
+    from every token, one-letter tokens and tokens with non-letters dropped."""
+    import string
+    table = str.maketrans('', '', string.punctuation)
+    words = [w.lower().translate(table) for w in desc.split()]
+    return [w for w in words if len(w) > 1 and w.isalpha()]
+
+
+def txt2idx(sent, vocab2id, max_len):
+    """utils/text_utils.py:42-67: (1, max_len) token ids = START (1), the request's tokens (unknown words -> 3) cut to
+    max_len - 2, END (2) right behind them, zero padding."""
+    body = max_len - 2
+    ids = [vocab2id.get(tok, 3) for tok in parse_sent(sent)][:body]
+    row = [1] + ids + [2] + [0] * (body - len(ids))
+    return torch.tensor(row, dtype=torch.long).unsqueeze(0)
+
+
 class FiveKAct(Dataset):
     """(img_x, img_ys (6,3,S,S), req_idx, ops (7,), params (5,24), req) per item, like
     datasets/FiveKdataset.py:67-135.  Directory layout as the reference's:

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from .functional import _need_gpu, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input, wino_backward_nhwc
+from .functional import _need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input, wino_backward_nhwc
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
@@ -258,9 +258,9 @@ class _TrunkFn(torch.autograd.Function):
         ctx.plan, ctx.img, ctx.stem, ctx.saved, ctx.planar = plan, img, stem, saved, planar
         ctx.a0 = a0
         ctx.kept_v = kept_v
-        # persistent, dense gradient buffers for every parameter: the kernels accumulate into them
-        ctx.into_grad = all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape
-                            and p.grad.stride() == p.stride() for p in plan.params)
+        # persistent, dense gradient buffers registered for every parameter (functional.enable_grad_accumulation -- the
+        # Trainer's flat buffer): the kernels accumulate into them.  Checked again in the backward.
+        ctx.into_grad = all(_persistent_grad(p) for p in plan.params)
         ctx.grads = [p.grad for p in plan.params] if ctx.into_grad else None
         ctx.pooled = plan.pool
         if plan.pool:                                          # global average pool inside the node (models/actor_resnet.py:106):
@@ -274,7 +274,7 @@ class _TrunkFn(torch.autograd.Function):
         lib = _lib.load()
         dev = dout.device
         st = _stream(dev)
-        acc = 1 if ctx.into_grad else 0
+        acc = 1 if (ctx.into_grad and all(p.grad is g_ for p, g_ in zip(plan.params, ctx.grads))) else 0
         N = ctx.img.shape[0]
         grads = ctx.grads if acc else [torch.empty_like(p) for p in plan.params]
 

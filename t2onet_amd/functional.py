@@ -408,6 +408,7 @@ class _ParamHeadsFn(torch.autograd.Function):
         if into_grad and all(t.grad is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32
                              and t.grad.shape == t.shape and t.is_contiguous() for t in flat):
             ctx.grad_targets = [t.grad for t in flat]
+        ctx.param_objs = flat
         features = features.contiguous()
         B, D = features.shape
         flat = [t.contiguous() for t in flat]
@@ -429,7 +430,8 @@ class _ParamHeadsFn(torch.autograd.Function):
         flat = ctx.saved_tensors[4:]
         B, D = features.shape
         tabs = [{op: flat[4 * k + j] for k, op in enumerate(HEAD_OPS)} for j in range(4)]
-        acc = ctx.grad_targets is not None
+        # (in place only while every parameter still carries the gradient tensor seen by the forward)
+        acc = ctx.grad_targets is not None and all(p.grad is g for p, g in zip(ctx.param_objs, ctx.grad_targets))
         grads = ctx.grad_targets if acc else [torch.empty_like(t) for t in flat]
         gtabs = [{op: grads[4 * k + j] for k, op in enumerate(HEAD_OPS)} for j in range(4)]
         gctx = torch.empty_like(features)
@@ -1107,7 +1109,7 @@ class _LstmLayerFn(torch.autograd.Function):
         dx = (dgi @ wih_cat).view(B, L, E) if ctx.needs_input_grad[0] else None
         dbias = dgi.sum(0) if has_bias else None
         per = 4 if has_bias else 2
-        if ctx.acc:                                                            # parameter gradients added in place by the GEMMs
+        if ctx.acc and all(_persistent_grad(q) for q in ctx.params):           # parameter gradients added in place by the GEMMs
             p, x2 = ctx.params, x.reshape(B * L, E)
             for d in range(D):
                 p[per * d].grad.addmm_(dgi[:, d * 4 * H:(d + 1) * 4 * H].t(), x2)
@@ -1228,9 +1230,28 @@ def conv1x1s2_supported(x, conv):
 # gradient buffers (the Trainer's flat buffer) the weight gradient is accumulated BY the GEMM that computes it (beta = 1)
 # and the bias gradient by one GEMV, so autograd hands out no parameter gradient and launches no accumulation kernel --
 # ~120 tiny launches per train step (each costs ~5 us of GPU time, inside a hipGraph as much as outside).
+_ACC = {}        # id(parameter) -> (weak reference to it, the .grad tensor registered for it)
+
+
+def enable_grad_accumulation(params):
+    """Opt in (Trainer / FlatGradients): the backward kernels of these parameters ADD into their current, persistent
+    .grad tensors and autograd is handed no parameter gradient.  Never inferred from `.grad is not None`: a caller that
+    runs forward, `optimizer.zero_grad()` (set_to_none) and then backward must get ordinary autograd gradients."""
+    import weakref
+    for p in params:
+        if p.grad is not None and p.grad.dtype == torch.float32 and p.grad.shape == p.shape and p.grad.stride() == p.stride():
+            _ACC[id(p)] = (weakref.ref(p), p.grad)
+
+
+def disable_grad_accumulation(params=None):
+    for key in ([id(p) for p in params] if params is not None else list(_ACC)):
+        _ACC.pop(key, None)
+
+
 def _persistent_grad(p):
-    g = p.grad
-    return g is not None and g.dtype == torch.float32 and g.shape == p.shape and g.stride() == p.stride() and g.is_cuda
+    """True while `p` is registered AND still carries the registered gradient tensor (checked again at backward time)."""
+    e = _ACC.get(id(p))
+    return e is not None and e[0]() is p and p.grad is e[1]
 
 _ones_cache = {}
 
@@ -1259,7 +1280,7 @@ class _LinearAccFn(torch.autograd.Function):
         weight, bias = ctx.params
         dy = dy.contiguous()
         dx = dy @ w if ctx.needs_input_grad[0] else None
-        if ctx.acc:
+        if ctx.acc and _persistent_grad(weight) and (bias is None or _persistent_grad(bias)):
             weight.grad.addmm_(dy.t(), x)
             if bias is not None:
                 bias.grad.addmv_(dy.t(), _ones(dy.shape[0], dy.device))
@@ -1293,7 +1314,7 @@ class _LstmCellAccFn(torch.autograd.Function):
         gg, gcx, gb = torch.ops.aten._thnn_fused_lstm_cell_backward_impl(ghy, gcy, c, cy, ws, has_bias)
         dx = gg @ w_ih if ctx.needs_input_grad[0] else None
         dh = gg @ w_hh if ctx.needs_input_grad[1] else None
-        if ctx.acc:
+        if ctx.acc and all(_persistent_grad(p) for p in ctx.params if p is not None):
             p_ih.grad.addmm_(gg.t(), x)
             p_hh.grad.addmm_(gg.t(), h)
             if has_bias:

@@ -56,6 +56,9 @@ class FlatGradients:
             # same strides as the parameter (channels-last convolution weights stay channels-last): optimiser and
             # gradient accumulation then run their dense fast paths; the flat all-reduce does not care about layout
             p.grad = _view_like(self.flat[off:off + p.numel()], p)
+        if self.flat.is_cuda:
+            # explicit opt-in: the backward kernels add into these buffers (functional.enable_grad_accumulation)
+            T.enable_grad_accumulation(self.params)
 
     def zero(self):
         self.flat.zero_()
@@ -172,6 +175,31 @@ class Trainer:
         executor = getattr(model, 'executor', None)
         if executor is not None and self.grads.flat.is_cuda:
             executor.__dict__['heads_grad_in_place'] = True
+        # the decoder steps and feature heads of a train step record into ONE persistent tape (decoder_step.DecoderTape,
+        # allocated for the first batch); their weight gradients are one product per weight over all steps, formed by
+        # _flush_tape() after the backward pass
+        self._tape_owner = model if (self.grads.flat.is_cuda and hasattr(model, 'decoder') and hasattr(model, 'bn1')) else None
+
+    def _tape(self, B):
+        """The persistent tape for batches of B rows (re-allocated when B changes; None for models without a decoder)."""
+        model = self._tape_owner
+        if model is None:
+            return None
+        tape = model.__dict__.get('_tape')
+        if tape is None or tape.B != B:
+            from .decoder_step import DecoderTape
+            dec = model.decoder
+            tape = DecoderTape(B, dec.hidden_size, dec.word_vec_dim, dec.output_size, model.vis_encoder.fc.in_features,
+                               self.opt.decoder_max_len + 1, self.grads.flat.device, persistent=True)
+            model.__dict__['_tape'] = model.decoder.__dict__['_tape'] = tape
+        tape.begin()
+        return tape
+
+    def _flush_tape(self):
+        model = self._tape_owner
+        tape = model.__dict__.get('_tape') if model is not None else None
+        if tape is not None:
+            tape.flush(model)
 
     def _maybe_graph(self, img):
         if self.graph_encoder and img.is_cuda and '_graphed_encoders' not in self.model.__dict__:
@@ -189,6 +217,7 @@ class Trainer:
     def _finish(self, loss):
         self.grads.zero()
         loss.backward()
+        self._flush_tape()
         self._update()
 
     def _update(self):
@@ -239,6 +268,7 @@ class Trainer:
         """train_seq2seqL1.py:51-65: NLL (mean, no ignore_index) + MSE(sum)/count_nonzero."""
         step = int((y != self.opt.null_id).sum(1).max())
         self._maybe_graph(img_x)
+        self._tape(img_x.shape[0])
         _, pred_params, logp = self.model.supervised_forward(x, y, img_x, img_y, gt_params, None, lengths)
         target = y[:, 1:step].contiguous().view(-1)
         op_loss = F.nll_loss(logp.reshape(-1, logp.shape[-1]), target)
@@ -254,6 +284,7 @@ class Trainer:
             if loss is not None:
                 return loss
         self._maybe_graph(img_x)
+        self._tape(img_x.shape[0])
         _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths, stack=False)
         loss = end_l1_loss(pred_imgs, pred_ops, self.opt.end_id, target)
         self._finish(loss)

@@ -395,3 +395,20 @@ def test_evaluation_loop_matches_the_reference_test_function(extra2):
     assert abs(avg - float(extra2['eval_avg_dist'])) < 1e-5
     res = evaluate.test(model, batches, opt, is_test=True, device=dev, verbose=False)      # + ImageEvaluator (L1 / SSIM running means)
     assert abs(res[1] - avg) < 1e-7
+
+
+def test_variance_loop_matches_the_reference(golden_dir):
+    """evaluate.test_variance() against the reference's test_variance() (experiments/t2onet/test_seq2seqL1.py:99-142): three
+    one-image batches, four requests given as text (tokenised by data.txt2idx) and, again, as token rows."""
+    from t2onet_amd import evaluate
+    var = np.load(os.path.join(golden_dir, 'variance.npz'))
+    dev = torch.device('cuda:0')
+    model, opt = make_model2(dev)
+    batches = [(synth.images(1, 48, 64, 181 + k), synth.images(1, 48, 64, 191 + k), synth.requests(1, L, 201 + k), ['req']) for k in range(3)]
+    vocab2id = {str(t): i for i, t in enumerate(var['var_vocab'])}
+    got = evaluate.test_variance(model, batches, opt, [str(t) for t in var['var_texts']], vocab2id, device=dev, verbose=False)
+    assert abs(got - float(var['var_avg'])) < 1e-5
+    got2 = evaluate.test_variance(model, batches, opt, list(torch.as_tensor(var['var_x'])), device=dev, verbose=False)
+    assert got2 == got
+    with pytest.raises(ValueError):
+        evaluate.test_variance(model, batches, opt, ['darken it'], vocab2id, device=dev, verbose=False)

@@ -101,10 +101,7 @@ def test_supervised_step(gold, sd, mode):
     np.testing.assert_allclose(gn, gold[p + 'grad_norm'], rtol=2e-3, atol=1e-6 * gold[p + 'grad_norm'].max())
 
 
-def test_oracle_reproduces_the_reference_evaluation_loop(golden_dir):
-    """extra2.npz: the reference's test() (experiments/t2onet/test_seq2seqL1.py:28-95) over three synthetic batches,
-    restated with the oracle's episode_forward / select_end_images / l1_loss (eval mode, arg-max operators)."""
-    extra2 = np.load(os.path.join(golden_dir, 'extra2.npz'))
+def _eval_state_dict():
     sd2 = synth.fill_state_dict(cpu_ref.actor_state_skeleton(OPT), seed=7)
     # the fixture's batch-norm adjustment (tools/gen_golden.py tweak_batchnorms)
     for k in list(sd2.keys()):
@@ -119,6 +116,14 @@ def test_oracle_reproduces_the_reference_evaluation_loop(golden_dir):
     for k in list(sd2.keys()):
         if k.startswith('executor.') and k.endswith('.fc1.bias'):
             sd2[k] = sd2[k] + 3.0
+    return sd2
+
+
+def test_oracle_reproduces_the_reference_evaluation_loop(golden_dir):
+    """extra2.npz: the reference's test() (experiments/t2onet/test_seq2seqL1.py:28-95) over three synthetic batches,
+    restated with the oracle's episode_forward / select_end_images / l1_loss (eval mode, arg-max operators)."""
+    extra2 = np.load(os.path.join(golden_dir, 'extra2.npz'))
+    sd2 = _eval_state_dict()
     avg_init = avg = 0.0
     for k in range(3):
         img_x, img_y, x = synth.images(2, 48, 64, 151 + k), synth.images(2, 48, 64, 161 + k), synth.requests(2, L, 171 + k)
@@ -129,3 +134,25 @@ def test_oracle_reproduces_the_reference_evaluation_loop(golden_dir):
         avg += (cpu_ref.l1_loss(pred, img_y).item() - avg) / (k + 1)
     assert abs(avg_init - float(extra2['eval_avg_init_dist'])) < 1e-6
     assert abs(avg - float(extra2['eval_avg_dist'])) < 1e-5
+
+
+def test_oracle_reproduces_the_reference_variance_loop(golden_dir):
+    """variance.npz: the reference's test_variance() (experiments/t2onet/test_seq2seqL1.py:99-142) on three one-image batches
+    and four requests; the request rows are what its txt2idx (utils/text_utils.py:42-67) made of the texts, which the
+    host-side counterpart (t2onet_amd.data.txt2idx) must reproduce token for token."""
+    from t2onet_amd.data import txt2idx
+    var = np.load(os.path.join(golden_dir, 'variance.npz'))
+    vocab2id = {str(t): i for i, t in enumerate(var['var_vocab'])}
+    rows = torch.cat([txt2idx(str(t), vocab2id, L) for t in var['var_texts']])
+    assert rows.tolist() == var['var_x'].tolist()
+    sd2 = _eval_state_dict()
+    avg_var = 0.0
+    for k in range(3):
+        img_x = synth.images(1, 48, 64, 181 + k)
+        ends = []
+        for row in rows:
+            with torch.no_grad():
+                r = cpu_ref.episode_forward(sd2, row.view(1, -1), img_x, OPT, reinforce_sample=0, training=False)
+                ends.append(cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], OPT.end_id))
+        avg_var += (torch.var(torch.cat(ends), dim=0).mean().item() - avg_var) / (k + 1)
+    assert abs(avg_var - float(var['var_avg'])) < 1e-6

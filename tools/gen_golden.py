@@ -592,6 +592,49 @@ def gen_extra2(opt):
     print('extra2.npz: %d arrays' % len(g), 'episode loss', float(g['ep128_loss']), 'eval', avg_init, avg)
 
 
+def gen_variance(opt):
+    """variance.npz: the reference's test_variance() (experiments/t2onet/test_seq2seqL1.py:99-142) on three one-image
+    batches (its loader is batch_size = 1: the (1, L) request row only broadcasts against one image) and four requests.
+    It imports its request list from `core.utils.eval`, a module the repository does not contain: shimmed with the
+    list stored in the fixture.  Also stored: the token rows utils/text_utils.py:txt2idx made of them."""
+    from models.actor import Actor
+    torch.manual_seed(0)
+    opt.input_dropout_p = 0.0
+    opt.dropout_p = 0.0
+    model = Actor(opt)
+    model.load_state_dict(synth.fill_state_dict(model.state_dict(), seed=7))
+    tweak_batchnorms(model)
+    texts = ['Please make the image a bit brighter, and increase the contrast!', 'darken it', 'add more saturation to the colors of this photo',
+             'sharpen the picture slightly; remove the 2 blue-ish xyzzy tones']
+    for name in ('core', 'core.utils', 'core.utils.eval'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['core.utils.eval'].test_txts = texts
+
+    class _Stub(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return _Stub(self.__name__ + '.' + name)
+
+        def __call__(self, *a, **k):
+            return self
+    for name in ('dominate', 'dominate.tags', 'torchvision', 'torchvision.models', 'torchvision.models.utils',
+                 'utils.FID', 'utils.FID.inception', 'utils.FID.fid_score'):
+        if name not in sys.modules:
+            sys.modules[name] = _Stub(name)
+    import experiments.t2onet.test_seq2seqL1 as ref_test
+    from utils.text_utils import load_vocab, txt2idx
+    opt.print_every = 1000
+    L = opt.encoder_max_len
+    batches = [(synth.images(1, 48, 64, 181 + k), synth.images(1, 48, 64, 191 + k), synth.requests(1, L, 201 + k), ['req']) for k in range(3)]
+    avg_var = ref_test.test_variance(model, batches, opt)
+    vocab2id = load_vocab(opt.vocab_dir, opt.dataset, opt.session)[0]
+    g = {'var_avg': np.array(avg_var), 'var_texts': np.array(texts), 'var_x': torch.cat([txt2idx(t, vocab2id, L) for t in texts]).numpy(),
+         'var_vocab': np.array(list(vocab2id.keys()))}
+    np.savez_compressed(os.path.join(OUT, 'variance.npz'), **g)
+    print('variance.npz: avg var', avg_var, g['var_x'])
+
+
 def gen_planner(opt):
     """utils/beam_search.py: get_param (Nelder-Mead) and beam_search on one 32x32 pair, operations [0,1,2]."""
     import utils.beam_search as bs
@@ -633,6 +676,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'extra2':
         gen_extra2(opt)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'variance':
+        gen_variance(opt)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'extra':          # extra.npz / planner.npz only (the others are unchanged)
         gen_extra(opt)
         gen_planner(opt)
@@ -644,3 +690,4 @@ if __name__ == '__main__':
     gen_extra(reference_opt())
     gen_planner(reference_opt())
     gen_extra2(reference_opt())
+    gen_variance(reference_opt())
