@@ -21,10 +21,14 @@
 //             storage together with its X, and the weight gradients are ONE product per weight over all steps of a
 //             train step (K = steps x batch; host side, t2onet_amd/decoder_tape.py).
 //
-// The product itself: fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds), a workgroup = 16 output
-// columns x up to 64 rows, its four waves split K in 32-wide chunks (wave w takes chunks w, w+4, ...: a lane reads
-// whole 16-byte pieces of a 128-byte line of its row), one chunk of A / B fragments prefetched while the previous one
-// feeds 8 MFMAs per 16 rows; the four partial tiles meet in LDS and are added in wave order (deterministic).
+// The product itself: fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds) on 16 x 16 output tiles.
+// What binds these kernels is neither arithmetic nor bandwidth but MEMORY-LEVEL PARALLELISM: the operands arrive from
+// L2 / MALL / HBM (the encoder passes between two decoder steps sweep the caches) with 1-2 us of latency, a CU pulls
+// ~60 GB/s, and the first version (4 waves per workgroup, 64 rows x 16 columns, one 32-wide K chunk prefetched: 40 KB
+// in flight per CU, 64-128 workgroups on 256 CUs) took 16-28 us per product.  Now a workgroup is 16 WAVES that split K
+// in 32-wide chunks (wave w takes chunks w, w+16, ...: a lane reads whole 16-byte pieces of a 128-byte line of its
+// row) and keep up to 4 chunks of fragments in flight each, row tiles of 16 go to separate workgroups (grid.y) so
+// that every CU has work, and the 16 partial tiles meet in LDS and are added in wave order (deterministic).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -37,7 +41,8 @@ using t2o::set_error;
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kT = 256;             // 4 waves: the K split
+constexpr int kW = 16;              // waves per workgroup: the K split
+constexpr int kT = 64 * kW;
 
 enum { A_PLAIN = 0, A_TANH_BWD = 1, A_RELU_BWD = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -132,9 +137,9 @@ __device__ __forceinline__ void mma_frag(f32x4* acc, const Frag<RB>& f) {
       for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[rb][h][i], f.b[h][i], acc[rb], 0, 0, 0);
 }
 
-// The workgroup's (16 RB) x 16 tile of  sum_seg A_seg . W_seg  as four per-wave partial tiles in LDS:
-// red[wave][row * 16 + col].  Ends with a barrier.  nseg == 1: s1 is never read.
-template <int RB, bool TN, int AMODE>
+// The workgroup's (16 RB) x 16 tile of  sum_seg A_seg . W_seg  as kW per-wave partial tiles in LDS:
+// red[wave][row * 16 + col].  Ends with a barrier.  nseg == 1: s1 is never read.  PD = chunks in flight per wave.
+template <int RB, bool TN, int AMODE, int PD>
 __device__ __forceinline__ void gemm_core(const GSeg& s0, const GSeg& s1, int nseg, const float* w0, const float* w1, int ldw0, int ldw1,
                                           int nrow, int row0, int M, bool store_a, float* red) {
   const int tid = threadIdx.x, lane = tid & 63, kg = lane >> 4, li = lane & 15;
@@ -152,16 +157,17 @@ __device__ __forceinline__ void gemm_core(const GSeg& s0, const GSeg& s1, int ns
   f32x4 acc[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  Frag<RB> f0, f1;
-  int c = wave;
-  if (c < C) load_frag<RB, TN, AMODE>(f0, s0, s1, C0, w0, w1, ldw0, ldw1, c, arow, astore, nrow, kg);
-  for (; c < C; c += 8) {
-    const bool more = c + 4 < C;
-    if (more) load_frag<RB, TN, AMODE>(f1, s0, s1, C0, w0, w1, ldw0, ldw1, c + 4, arow, astore, nrow, kg);
-    mma_frag<RB>(acc, f0);
-    if (more) {
-      if (c + 8 < C) load_frag<RB, TN, AMODE>(f0, s0, s1, C0, w0, w1, ldw0, ldw1, c + 8, arow, astore, nrow, kg);
-      mma_frag<RB>(acc, f1);
+  Frag<RB> f[PD];
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+    if (wave + p * kW < C) load_frag<RB, TN, AMODE>(f[p], s0, s1, C0, w0, w1, ldw0, ldw1, wave + p * kW, arow, astore, nrow, kg);
+  for (int c = wave; c < C; c += PD * kW) {
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      if (c + p * kW < C) {
+        mma_frag<RB>(acc, f[p]);
+        if (c + (p + PD) * kW < C) load_frag<RB, TN, AMODE>(f[p], s0, s1, C0, w0, w1, ldw0, ldw1, c + (p + PD) * kW, arow, astore, nrow, kg);
+      }
     }
   }
   float* mine = red + wave * (RB * 256);
@@ -174,13 +180,17 @@ __device__ __forceinline__ void gemm_core(const GSeg& s0, const GSeg& s1, int ns
 
 template <int RB>
 __device__ __forceinline__ float red_sum(const float* red, int e) {
-  return ((red[e] + red[RB * 256 + e]) + red[2 * RB * 256 + e]) + red[3 * RB * 256 + e];
+  float s = red[e];
+#pragma unroll
+  for (int w = 1; w < kW; ++w) s += red[w * (RB * 256) + e];
+  return s;
 }
 
 // ---- generic product with bias / activation epilogue --------------------------------------------------------------
-template <int RB, bool TN, int AMODE, int ACT>
+template <bool TN, int AMODE, int ACT>
 __global__ __launch_bounds__(kT) void k_dec_gemm(GemmArgs a) {
-  __shared__ float red[4 * RB * 256];
+  constexpr int RB = 1;
+  __shared__ float red[kW * RB * 256];
   const int tid = threadIdx.x, li = tid & 15;
   int bx = blockIdx.x;
   const bool g1 = a.ngrp > 1 && bx >= a.grp[0].tiles;       // (block-uniform: scalar selects of the group's fields)
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(kT) void k_dec_gemm(GemmArgs a) {
       for (int r = tid; r < a.M; r += kT) a.idx_copy[r] = a.idx[r];
   }
   const int n = col0 + li;
-  gemm_core<RB, TN, AMODE>(a.seg[0], a.seg[1], a.nseg, w0, w1, ldw0, ldw1, n < N ? n : N - 1, row0, a.M, blockIdx.x == 0, red);
+  gemm_core<RB, TN, AMODE, 4>(a.seg[0], a.seg[1], a.nseg, w0, w1, ldw0, ldw1, n < N ? n : N - 1, row0, a.M, blockIdx.x == 0, red);
   for (int e = tid; e < RB * 256; e += kT) {
     const int row = row0 + (e >> 4), col = col0 + (e & 15);
     if (row < a.M && col < N) {
@@ -232,14 +242,14 @@ struct LstmArgs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int RB>
 __global__ __launch_bounds__(kT) void k_dec_lstm(LstmArgs a) {
-  __shared__ float red[4 * RB * 256];
+  constexpr int RB = 1;
+  __shared__ float red[kW * RB * 256];
   const int tid = threadIdx.x, li = tid & 15;
   const int u0 = blockIdx.x * 4, row0 = blockIdx.y * (16 * RB), H = a.H;
   // column j of the tile = gate (j >> 2) of hidden unit u0 + (j & 3)
-  gemm_core<RB, false, A_PLAIN>(a.seg[0], a.seg[1], 2, a.w[0], a.w[1], a.ldw[0], a.ldw[1], (li >> 2) * H + u0 + (li & 3), row0, a.M,
-                                blockIdx.x == 0, red);
+  gemm_core<RB, false, A_PLAIN, 4>(a.seg[0], a.seg[1], 2, a.w[0], a.w[1], a.ldw[0], a.ldw[1], (li >> 2) * H + u0 + (li & 3), row0, a.M,
+                                   blockIdx.x == 0, red);
   for (int t = tid; t < RB * 64; t += kT) {
     const int r = t >> 2, u = t & 3, row = row0 + r, unit = u0 + u;
     if (row >= a.M) continue;
@@ -270,9 +280,9 @@ struct LstmBwdArgs {
   int M, H;
 };
 
-__global__ __launch_bounds__(kT) void k_dec_lstm_bwd(LstmBwdArgs a) {
+__global__ __launch_bounds__(256) void k_dec_lstm_bwd(LstmBwdArgs a) {
   const int H = a.H, q = H >> 2;
-  const int i = blockIdx.x * kT + threadIdx.x;
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.M * q) return;
   const int row = i / q, u = (i - row * q) * 4;
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -313,103 +323,110 @@ struct FeatArgs {
 
 template <int RB>
 __global__ __launch_bounds__(kT) void k_dec_feat(FeatArgs a) {
-  __shared__ float red[4 * RB * 256];
-  __shared__ float st[2][16];
+  __shared__ float red[kW * RB * 256];
+  __shared__ float part[16][16];
   const int tid = threadIdx.x, li = tid & 15;
   const int col0 = blockIdx.x * 16, M = a.M;
   const int n = col0 + li;
-  gemm_core<RB, false, A_PLAIN>(a.seg, a.seg, 1, a.w, nullptr, a.seg.K, 0, n < a.D ? n : a.D - 1, 0, M, blockIdx.x == 0, red);
-  float x[RB];
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int e = tid + j * kT, row = e >> 4, col = col0 + (e & 15);
-    float v = red_sum<RB>(red, e);
-    if (a.b && col < a.D) v += a.b[col];
-    x[j] = v;
-    if (row < M && col < a.D) a.fc_out[(size_t)row * a.D + col] = v;
+  gemm_core<RB, false, A_PLAIN, 2>(a.seg, a.seg, 1, a.w, nullptr, a.seg.K, 0, n < a.D ? n : a.D - 1, 0, M, blockIdx.x == 0, red);
+  // the tile (+ bias) into red[0 .. RB*256): element e = row * 16 + col; threads 0 .. RB*256-1 own one element each
+  const bool owner = tid < RB * 256;
+  const int row = tid >> 4, c = tid & 15, col = col0 + c;
+  float x = 0.0f;
+  if (owner) {
+    x = red_sum<RB>(red, tid);
+    if (a.b && col < a.D) x += a.b[col];
+    if (row < M && col < a.D) a.fc_out[(size_t)row * a.D + col] = x;
   }
   __syncthreads();
-#pragma unroll
-  for (int j = 0; j < RB; ++j) red[tid + j * kT] = x[j];
+  if (owner) red[tid] = x;
   __syncthreads();
-  if (tid < 16) {
-    const int col = col0 + tid;
-    float mean = 0.0f, invstd = 1.0f;
-    if (col < a.D) {
-      if (a.training) {
-        float s = 0.0f;
-        for (int r = 0; r < M; ++r) s += red[r * 16 + tid];
-        mean = s / (float)M;
-        float v = 0.0f;
-        for (int r = 0; r < M; ++r) { const float d = red[r * 16 + tid] - mean; v += d * d; }
-        const float var = v / (float)M;
-        invstd = 1.0f / sqrtf(var + a.eps);
-        if (a.rmean) a.rmean[col] = (1.0f - a.momentum) * a.rmean[col] + a.momentum * mean;
-        if (a.rvar) a.rvar[col] = (1.0f - a.momentum) * a.rvar[col] + a.momentum * (v / (float)(M > 1 ? M - 1 : 1));
-      } else {
-        mean = a.rmean[col];
-        invstd = 1.0f / sqrtf(a.rvar[col] + a.eps);
-      }
-      a.stats[col] = mean;
-      a.stats[a.D + col] = invstd;
+  // column statistics over the M rows: 16 row groups x 16 columns of partial sums, two passes (mean, then variance)
+  float mean = 0.0f, invstd = 1.0f;
+  if (a.training) {
+    if (tid < 256) {
+      float sacc = 0.0f;
+      for (int r = tid >> 4; r < M; r += 16) sacc += red[r * 16 + c];
+      part[tid >> 4][c] = sacc;
     }
-    st[0][tid] = mean;
-    st[1][tid] = invstd;
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) sum += part[g][c];
+    mean = sum / (float)M;
+    __syncthreads();
+    if (tid < 256) {
+      float vacc = 0.0f;
+      for (int r = tid >> 4; r < M; r += 16) { const float d = red[r * 16 + c] - mean; vacc += d * d; }
+      part[tid >> 4][c] = vacc;
+    }
+    __syncthreads();
+    float v = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += part[g][c];
+    invstd = 1.0f / sqrtf(v / (float)M + a.eps);
+    if (tid < 16 && col < a.D) {
+      if (a.rmean) a.rmean[col] = (1.0f - a.momentum) * a.rmean[col] + a.momentum * mean;
+      if (a.rvar) a.rvar[col] = (1.0f - a.momentum) * a.rvar[col] + a.momentum * (v / (float)(M > 1 ? M - 1 : 1));
+    }
+  } else if (col < a.D) {
+    mean = a.rmean[col];
+    invstd = 1.0f / sqrtf(a.rvar[col] + a.eps);
   }
+  if (tid < 16 && col < a.D) { a.stats[col] = mean; a.stats[a.D + col] = invstd; }
   if (blockIdx.x == 0 && tid == 0 && a.training && a.nbt) *a.nbt += 1;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int e = tid + j * kT, row = e >> 4, c = e & 15, col = col0 + c;
-    if (row < M && col < a.D) {
-      float y = (x[j] - st[0][c]) * st[1][c];
-      if (a.bn_w) y *= a.bn_w[col];
-      if (a.bn_b) y += a.bn_b[col];
-      a.feat[(size_t)row * a.D + col] = fmaxf(y, 0.0f);
-    }
+  if (owner && row < M && col < a.D) {
+    float y = (x - mean) * invstd;
+    if (a.bn_w) y *= a.bn_w[col];
+    if (a.bn_b) y += a.bn_b[col];
+    a.feat[(size_t)row * a.D + col] = fmaxf(y, 0.0f);
   }
 }
 
-// backward of relu(bn(x)) over the batch: thread = (column, row group of 4); two passes over the column (L2-resident)
+// backward of relu(bn(x)) over the batch.  Workgroup = 16 columns; thread = (column, row group g of 16): its rows g,
+// g+16, ... (at most 4 for M <= 64) stay in registers between the sums and the result -- one memory round trip.
 struct FeatBwdArgs {
   const float *g_feat, *feat, *fc_out, *stats, *bn_w;
   float *d_fc, *d_bn;                        // (M, D), (2, D) = d weight, d bias
   int training, M, D;
 };
 
-__global__ __launch_bounds__(kT) void k_dec_feat_bwd(FeatBwdArgs a) {
-  __shared__ float sg[4][64], sgx[4][64];
-  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6, col = blockIdx.x * 64 + c, D = a.D, M = a.M;
+__global__ __launch_bounds__(256) void k_dec_feat_bwd(FeatBwdArgs a) {
+  __shared__ float sg[16][16], sgx[16][16];
+  const int tid = threadIdx.x, c = tid & 15, rg = tid >> 4, col = blockIdx.x * 16 + c, D = a.D, M = a.M;
   const bool ok = col < D;
   const float mean = ok ? a.stats[col] : 0.0f, invstd = ok ? a.stats[D + col] : 0.0f;
+  float g[4], xh[4];
   float s1 = 0.0f, s2 = 0.0f;
-  if (ok)
-    for (int r = rg; r < M; r += 4) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = rg + 16 * j;
+    g[j] = 0.0f; xh[j] = 0.0f;
+    if (ok && r < M) {
       const size_t i = (size_t)r * D + col;
-      const float g = a.feat[i] > 0.0f ? a.g_feat[i] : 0.0f;
-      s1 += g;
-      s2 += g * ((a.fc_out[i] - mean) * invstd);
+      g[j] = a.feat[i] > 0.0f ? a.g_feat[i] : 0.0f;
+      xh[j] = (a.fc_out[i] - mean) * invstd;
     }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s1 += g[j]; s2 += g[j] * xh[j]; }
   sg[rg][c] = s1;
   sgx[rg][c] = s2;
   __syncthreads();
-  const float sum_g = ((sg[0][c] + sg[1][c]) + sg[2][c]) + sg[3][c];
-  const float sum_gx = ((sgx[0][c] + sgx[1][c]) + sgx[2][c]) + sgx[3][c];
+  float sum_g = 0.0f, sum_gx = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { sum_g += sg[q][c]; sum_gx += sgx[q][c]; }
   if (!ok) return;
   if (rg == 0) { a.d_bn[col] = sum_gx; a.d_bn[D + col] = sum_g; }
   const float w = a.bn_w ? a.bn_w[col] : 1.0f;
   const float inv_m = 1.0f / (float)M;
-  for (int r = rg; r < M; r += 4) {
-    const size_t i = (size_t)r * D + col;
-    const float g = a.feat[i] > 0.0f ? a.g_feat[i] : 0.0f;
-    float d;
-    if (a.training) {
-      const float xh = (a.fc_out[i] - mean) * invstd;
-      d = (g - sum_g * inv_m - xh * (sum_gx * inv_m)) * invstd * w;
-    } else {
-      d = g * invstd * w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = rg + 16 * j;
+    if (r < M) {
+      const float d = a.training ? (g[j] - sum_g * inv_m - xh[j] * (sum_gx * inv_m)) * invstd * w : g[j] * invstd * w;
+      a.d_fc[(size_t)r * D + col] = d;
     }
-    a.d_fc[i] = d;
   }
 }
 
@@ -421,11 +438,11 @@ struct LogitArgs {
   int M, V;
 };
 
-template <int RB>
 __global__ __launch_bounds__(kT) void k_dec_logits(LogitArgs a) {
-  __shared__ float red[4 * RB * 256];
+  constexpr int RB = 1;
+  __shared__ float red[kW * RB * 256];
   const int tid = threadIdx.x, li = tid & 15, row0 = blockIdx.y * (16 * RB);
-  gemm_core<RB, false, A_PLAIN>(a.seg, a.seg, 1, a.w, nullptr, a.seg.K, 0, li < a.V ? li : a.V - 1, row0, a.M, false, red);
+  gemm_core<RB, false, A_PLAIN, 2>(a.seg, a.seg, 1, a.w, nullptr, a.seg.K, 0, li < a.V ? li : a.V - 1, row0, a.M, false, red);
   if (tid < RB * 16 && row0 + tid < a.M) {
     float s[16];
     float mx = -INFINITY;
@@ -447,7 +464,7 @@ struct LogitBwdArgs {
   int M, V, D;
 };
 
-__global__ __launch_bounds__(kT) void k_dec_logits_bwd(LogitBwdArgs a) {
+__global__ __launch_bounds__(256) void k_dec_logits_bwd(LogitBwdArgs a) {
   __shared__ float dl[16];
   const int row = blockIdx.x, tid = threadIdx.x;
   if (tid < a.V) {
@@ -458,7 +475,7 @@ __global__ __launch_bounds__(kT) void k_dec_logits_bwd(LogitBwdArgs a) {
     a.d_logits[(size_t)row * a.V + tid] = d;
   }
   __syncthreads();
-  for (int col = tid; col < a.D; col += kT) {
+  for (int col = tid; col < a.D; col += 256) {
     float s = a.g_ctx ? a.g_ctx[(size_t)row * a.D + col] : 0.0f;
     for (int v = 0; v < a.V; ++v) s += dl[v] * a.w[(size_t)v * a.D + col];
     a.d_ctx[(size_t)row * a.D + col] = s;
@@ -476,8 +493,8 @@ int check_launch(const char* what) {
   return T2O_OK;
 }
 
-inline int rb_for(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
-inline unsigned row_tiles(int M, int rb) { return (unsigned)((M + 16 * rb - 1) / (16 * rb)); }
+inline int rb_for(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }         // the feature head: all rows in one workgroup
+inline unsigned row_tiles(int M) { return (unsigned)((M + 15) / 16); }
 inline bool al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 GSeg seg_of(const float* x, int ldx, int K, const float* x2 = nullptr, int ldx2 = 0, float* a_store = nullptr, int lds = 0) {
@@ -498,19 +515,13 @@ void set_group(GGroup& g, const float* w0, int ldw0, const float* w1, int ldw1, 
 
 template <bool TN, int AMODE, int ACT>
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  const int rb = rb_for(g.M);
-  const dim3 grid((unsigned)(g.grp[0].tiles + (g.ngrp > 1 ? g.grp[1].tiles : 0)), row_tiles(g.M, rb));
-  if (rb == 1) k_dec_gemm<1, TN, AMODE, ACT><<<grid, kT, 0, st>>>(g);
-  else if (rb == 2) k_dec_gemm<2, TN, AMODE, ACT><<<grid, kT, 0, st>>>(g);
-  else k_dec_gemm<4, TN, AMODE, ACT><<<grid, kT, 0, st>>>(g);
+  const dim3 grid((unsigned)(g.grp[0].tiles + (g.ngrp > 1 ? g.grp[1].tiles : 0)), row_tiles(g.M));
+  k_dec_gemm<TN, AMODE, ACT><<<grid, kT, 0, st>>>(g);
 }
 
 void launch_lstm(const LstmArgs& a, hipStream_t st) {
-  const int rb = rb_for(a.M);
-  const dim3 grid((unsigned)(a.H / 4), row_tiles(a.M, rb));
-  if (rb == 1) k_dec_lstm<1><<<grid, kT, 0, st>>>(a);
-  else if (rb == 2) k_dec_lstm<2><<<grid, kT, 0, st>>>(a);
-  else k_dec_lstm<4><<<grid, kT, 0, st>>>(a);
+  const dim3 grid((unsigned)(a.H / 4), row_tiles(a.M));
+  k_dec_lstm<<<grid, kT, 0, st>>>(a);
 }
 
 }  // namespace
@@ -552,7 +563,7 @@ int t2o_image_feature_bwd(const t2o_image_feature_t* p, void* stream) {
   FeatBwdArgs b;
   b.g_feat = p->g_feat; b.feat = p->feat; b.fc_out = p->fc_out; b.stats = p->stats; b.bn_w = p->bn_w;
   b.d_fc = p->d_fc; b.d_bn = p->d_bn; b.training = p->training; b.M = p->B; b.D = p->D;
-  k_dec_feat_bwd<<<(unsigned)((p->D + 63) / 64), kT, 0, st>>>(b);
+  k_dec_feat_bwd<<<(unsigned)((p->D + 15) / 16), 256, 0, st>>>(b);
   if (p->d_pooled) {                                         // d pooled = d fc . W_fc
     GemmArgs g;
     clear(g);
@@ -615,11 +626,7 @@ int t2o_decoder_step_fwd(const t2o_decoder_step_t* p, void* stream) {
   LogitArgs q;
   q.seg = seg_of(p->ctx, D, D);
   q.w = p->out_w; q.b = p->out_b; q.logp = p->logp; q.M = B; q.V = p->V;
-  const int rb = rb_for(B);
-  const dim3 grid(1, row_tiles(B, rb));
-  if (rb == 1) k_dec_logits<1><<<grid, kT, 0, st>>>(q);
-  else if (rb == 2) k_dec_logits<2><<<grid, kT, 0, st>>>(q);
-  else k_dec_logits<4><<<grid, kT, 0, st>>>(q);
+  k_dec_logits<<<dim3(1, row_tiles(B)), kT, 0, st>>>(q);
   return check_launch("decoder_step_fwd");
 }
 
@@ -639,7 +646,7 @@ int t2o_decoder_step_bwd(const t2o_decoder_step_t* p, void* stream) {
     LogitBwdArgs q;
     q.g_logp = p->g_logp; q.logp = p->logp; q.w = p->out_w; q.g_ctx = p->g_ctx; q.d_logits = p->d_logits; q.d_ctx = p->d_ctx;
     q.M = B; q.V = p->V; q.D = D;
-    k_dec_logits_bwd<<<(unsigned)B, kT, 0, st>>>(q);
+    k_dec_logits_bwd<<<(unsigned)B, 256, 0, st>>>(q);
     dctx = p->d_ctx;
   }
   // d lin = d ctx * (1 - ctx^2) (kept for the weight gradient);  d mix, d q (its part) = d lin . W_lo
@@ -658,8 +665,8 @@ int t2o_decoder_step_bwd(const t2o_decoder_step_t* p, void* stream) {
   LstmBwdArgs c;
   c.dh_a = p->g_h1n; c.ld_a = D; c.dh_b = p->d_q; c.ld_b = D; c.dh_c = p->d_qa; c.ld_c = D; c.dc_next = p->g_c1n;
   c.gates = p->gates1; c.c_prev = p->c1; c.c_new = p->c1n; c.dgates = p->d_gates1; c.dc_prev = p->d_c1; c.M = B; c.H = D;
-  const unsigned pw = (unsigned)((B * (D / 4) + kT - 1) / kT);
-  k_dec_lstm_bwd<<<pw, kT, 0, st>>>(c);
+  const unsigned pw = (unsigned)((B * (D / 4) + 255) / 256);
+  k_dec_lstm_bwd<<<pw, 256, 0, st>>>(c);
   clear(g);
   g.M = B; g.ngrp = 2;
   g.seg[0] = seg_of(p->d_gates1, 4 * D, 4 * D);
@@ -669,7 +676,7 @@ int t2o_decoder_step_bwd(const t2o_decoder_step_t* p, void* stream) {
   // layer 0: d h0n = g_h0n + d x1
   c.dh_a = p->g_h0n; c.ld_a = D; c.dh_b = p->d_x1; c.ld_b = D; c.dh_c = nullptr; c.ld_c = 0; c.dc_next = p->g_c0n;
   c.gates = p->gates0; c.c_prev = p->c0; c.c_new = p->c0n; c.dgates = p->d_gates0; c.dc_prev = p->d_c0;
-  k_dec_lstm_bwd<<<pw, kT, 0, st>>>(c);
+  k_dec_lstm_bwd<<<pw, 256, 0, st>>>(c);
   clear(g);
   g.M = B; g.ngrp = 2;
   g.seg[0] = seg_of(p->d_gates0, 4 * D, 4 * D);

@@ -173,3 +173,113 @@ def test_beam_search_rejects_non_l1_requests_before_any_fit():
         planner.beam_search(None, None, None, None, None, 2, [0, 1], ['brightness', 'contrast'], 1, 1e-3, dist_type='L2')
     with pytest.raises(NotImplementedError):
         planner.beam_search(None, None, None, None, object(), 2, [0, 1], ['brightness', 'contrast'], 1, 1e-3)
+
+
+class _StubExecutor(torch.nn.Module):
+    """Host stand-in for the Executor (the real one is GPU-only): per-operator heads 512 -> 24 like the real parameter
+    heads -- a head no local sample selected gets NO gradient on that rank -- and a differentiable per-pixel edit."""
+
+    def __init__(self):
+        super().__init__()
+        self.heads = torch.nn.ModuleList([torch.nn.Linear(512, 24) for _ in range(8)])
+
+    def execute_per_sample(self, img, exec_op, mask, features=None, specified_param=None):
+        B = img.shape[0]
+        par = torch.zeros(B, 24)
+        for op in range(8):
+            sel = (exec_op.view(-1) == op).nonzero().view(-1)
+            if len(sel):
+                par = par.index_add(0, sel, self.heads[op](features[sel]))
+        gain = 1.0 + 0.1 * torch.tanh(par[:, :1]).view(B, 1, 1, 1)
+        used = (exec_op.view(-1) >= 0).view(B, 1, 1, 1)
+        return torch.where(used, (img * gain).clamp(0, 1), img), par
+
+
+def _episode_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import t2onet_amd
+    import t2onet_amd.functional as T
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    from t2onet_amd.train_cli import sync_batchnorm_buffers
+    torch.set_num_threads(2)
+    # the product's L1 and attention core are GPU kernels: host stand-ins for exactly these two; everything else is the real code
+    T.l1_loss = lambda a, b: (a - b).abs().mean()
+
+    def attention_core(q, ctx):
+        a = torch.softmax(torch.bmm(ctx, q.unsqueeze(2)).squeeze(2), dim=1)
+        return torch.bmm(a.unsqueeze(1), ctx).squeeze(1), a
+    T.attention_core = attention_core
+    opt = t2onet_amd.default_options(input_dropout_p=0.0, dropout_p=0.0)
+    torch.manual_seed(0)
+    model = Actor(opt)
+    model.executor = _StubExecutor()
+    model.train()
+    for t in list(model.parameters()) + list(model.buffers()):     # identical replicas, as bench.py / train_cli do it
+        dist.broadcast(t.data, 0)
+    tr = Trainer(model, opt, lr=1e-3)
+    B, S = 4, 32
+    img = synth.images(B, S, S, 31 + rank)                          # every rank its own shard ...
+    tgt = synth.images(B, S, S, 41 + rank)
+    x = synth.requests(B, 17, 51 + rank)
+    torch.manual_seed(100 + rank)                                   # ... and its own sampling stream: the ranks draw different operators
+    drawn = []
+    orig = model._execute
+
+    def spy(img_, ops, ctx, mask=None, exec_op=None):
+        drawn.append(ops.view(-1).clone())
+        return orig(img_, ops, ctx, mask, exec_op)
+    model._execute = spy
+    head_grad_seen = []
+    for _ in range(2):
+        tr.episode_step(x, img, tgt, reinforce_sample=1)
+        head_grad_seen.append([bool(h.weight.grad.abs().sum() > 0) for h in model.executor.heads])
+    sync_batchnorm_buffers(model, world)
+    torch.save({'params': [p.detach().clone() for p in model.parameters()],
+                'buffers': {k: v.clone() for k, v in model.named_buffers() if 'running' in k},
+                'drawn': torch.stack(drawn), 'flat': tr.grads.flat.clone()}, out % rank)
+    dist.destroy_process_group()
+
+
+def test_episode_step_data_parallel_with_rank_local_operators(tmp_path):
+    """World size 2 (gloo), the real Trainer.episode_step: the ranks sample DIFFERENT operators, so parameter heads are
+    used on one rank only (zeros in the flat all-reduce from the other); afterwards the replicas are bit-identical, the
+    all-reduced gradient buffers are bit-identical, and the batch-norm running statistics are the ranks' mean."""
+    port = 31500 + os.getpid() % 2000
+    out = str(tmp_path / 'ep%d.pt')
+    mp.spawn(_episode_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    assert not torch.equal(a['drawn'], b['drawn'])                  # the premise: different operator sequences
+    assert all(torch.equal(u, v) for u, v in zip(a['params'], b['params']))
+    assert torch.equal(a['flat'], b['flat']) and float(a['flat'].abs().sum()) > 0
+    assert all(torch.equal(a['buffers'][k], b['buffers'][k]) for k in a['buffers'])
+    assert all(bool(torch.isfinite(p).all()) for p in a['params'])
+
+
+def _jit_worker(rank, world, port, cache, out):
+    """Two processes prepare the SAME new operator list at once: the hipRTC cache (compile, atomic file write, load) and --
+    when a GPU is present -- the autotuner's result file must be safe under that race."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ['T2O_JIT_CACHE'] = cache
+    import ctypes
+    from t2onet_amd import _lib
+    lib = _lib.load()
+    ops = (ctypes.c_int * 4)(6, 2, 1, 0)
+    rc = lib.t2o_fused_sequence_prepare(ops, 4)
+    with open(out % rank, 'w') as f:
+        f.write('%d %s' % (rc, lib.t2o_last_error().decode() if rc else ''))
+
+
+def test_chain_specialisation_cache_is_rank_safe(tmp_path):
+    """t2o_fused_sequence_prepare from two ranks at once, same cache directory: both return a status (0 with a GPU and
+    hipRTC, a clean error code without a device), neither crashes, and no partial file is left behind."""
+    cache = str(tmp_path / 'jit')
+    os.makedirs(cache)
+    out = str(tmp_path / 'jit%d.txt')
+    mp.spawn(_jit_worker, args=(2, 32500 + os.getpid() % 2000, cache, out), nprocs=2, join=True)
+    codes = [open(out % r).read().split(' ', 1) for r in range(2)]
+    assert codes[0][0] == codes[1][0], codes                        # the same outcome on both ranks
+    assert not [f for f in os.listdir(cache) if '.tmp' in f]        # atomic writes: nothing half-written remains

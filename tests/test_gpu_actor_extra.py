@@ -412,3 +412,22 @@ def test_variance_loop_matches_the_reference(golden_dir):
     assert got2 == got
     with pytest.raises(ValueError):
         evaluate.test_variance(model, batches, opt, ['darken it'], vocab2id, device=dev, verbose=False)
+
+
+def test_chain_specialisation_from_two_processes_at_once(tmp_path):
+    """The hipRTC cache under a real race (two ranks preparing the same NEW operator list, one cache directory): both succeed,
+    one code object file results, nothing half-written remains (tests/test_actor_cpu.py runs the same without a device)."""
+    import torch.multiprocessing as mp
+    from tests.test_actor_cpu import _jit_worker
+    cache = str(tmp_path / 'jit')
+    os.makedirs(cache)
+    out = str(tmp_path / 'jit%d.txt')
+    mp.spawn(_jit_worker, args=(2, 0, cache, out), nprocs=2, join=True)
+    codes = [open(out % r).read().split(' ', 1) for r in range(2)]
+    assert codes[0][0] == codes[1][0]
+    files = os.listdir(cache)
+    assert not [f for f in files if '.tmp' in f]
+    if codes[0][0] == '0':                                           # (status 2 = no libhiprtc on this box: the loop kernels serve the list)
+        assert len([f for f in files if f.endswith('.hsaco')]) == 1
+    else:
+        assert codes[0][0] == '2', codes

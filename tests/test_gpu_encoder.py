@@ -171,8 +171,11 @@ def test_trunk_matches_per_layer_path_and_fp64(monkeypatch, bias, size):
 
 
 def test_trunk_accumulates_into_persistent_gradients_and_is_deterministic():
-    """Every parameter has a dense .grad (the Trainer's flat buffer): the trunk adds into it inside its kernels, hands
-    autograd nothing, two backward passes give exactly twice one, and repeated runs are bit-identical."""
+    """Every parameter has a dense .grad REGISTERED for in-place accumulation (functional.enable_grad_accumulation -- what
+    the Trainer's flat buffer does): the trunk adds into it inside its kernels, hands autograd nothing, two backward passes
+    give exactly twice one, and repeated runs are bit-identical.  Unregistered .grad tensors get ordinary autograd
+    gradients (a forward, zero_grad(set_to_none), backward loop must work): second half."""
+    import t2onet_amd.functional as T
     N, H, W = 2, 32, 256
     img = synth.images(N, H, W, 41).to(DEV)
     gout = synth.uniform((N, 512), 42, -1.0, 1.0).to(DEV)
@@ -181,6 +184,7 @@ def test_trunk_accumulates_into_persistent_gradients_and_is_deterministic():
         net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
         for p in net.parameters():
             p.grad = torch.zeros_like(p)                    # (zeros_like keeps the channels-last strides)
+        T.enable_grad_accumulation(net.parameters())
         keep = [p.grad for p in net.parameters()]
         for _ in range(passes):
             x = img.clone().requires_grad_(True)
@@ -200,3 +204,30 @@ def test_trunk_accumulates_into_persistent_gradients_and_is_deterministic():
     trunk_names = [n for n in g1 if not n.startswith('fc.')]
     for n in trunk_names:                                    # batch statistics do not depend on the running buffers
         _close(g2[n], 2 * g1[n].double(), 1e-5)
+    # not registered: .grad present at the forward, set to None before the backward (optimizer.zero_grad()) -> autograd
+    # delivers fresh gradients, nothing is written into the orphaned tensors
+    net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    orphans = [p.grad for p in net.parameters()]
+    x = img.clone().requires_grad_(True)
+    y = net(x)
+    for p in net.parameters():
+        p.grad = None
+    y.backward(gout)
+    assert all(float(o.abs().sum()) == 0.0 for o in orphans)
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        _close(p.grad, gf[n], 1e-6)
+    # registered, then the gradient tensor replaced between forward and backward: same
+    net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    T.enable_grad_accumulation(net.parameters())
+    x = img.clone().requires_grad_(True)
+    y = net(x)
+    for p in net.parameters():
+        p.grad = None
+    y.backward(gout)
+    for n, p in net.named_parameters():
+        _close(p.grad, gf[n], 1e-6)

@@ -117,3 +117,40 @@ def test_ssim(golden_dir):
     a = synth.images(1, 48, 40, 51)
     b = (a + synth.uniform((1, 3, 48, 40), 52, -0.1, 0.1)).clamp(0, 1)
     assert abs(cpu_ref.ssim(a, b).item() - float(g['ssim'])) < 1e-6
+
+
+def test_hsv_epsilon_variant_fixture(golden_dir, monkeypatch):
+    """hsv_eps.npz: the reference's brightness / saturation with the HSV shim at eps = 1e-8 (current kornia) instead of the
+    1e-6 this build's spec fixes (oracle/hsv_spec.py; SURVEY 8(c): kornia is unpinned).  The oracle with the same epsilon
+    reproduces the fixture; the distance between the two epsilons -- what a maintainer on a current kornia should expect
+    against this implementation -- stays below the figures DESIGN.md section 2 quotes: 3e-6 on outputs in [0, 1],
+    1e-5 of the largest entry on image gradients of ordinary images, 5e-4 on a dark image (values <= 0.02)."""
+    from oracle import hsv_spec
+    g = np.load(os.path.join(golden_dir, 'hsv_eps.npz'))
+    B, H, W = 2, 24, 20
+    imgs = {'std': synth.images(B, H, W, 11), 'dark': synth.images(B, H, W, 11) * 0.02}
+    gout = synth.uniform((B, 3, H, W), 12, -1.0, 1.0)
+
+    def run(eps):
+        monkeypatch.setattr(hsv_spec, 'HSV_EPS', eps)
+        res = {}
+        for iname, img in imgs.items():
+            for op in (0, 2):
+                for si, setting in enumerate(['mid', 'strong', 'neg']):
+                    x = img.clone().requires_grad_(True)
+                    p = synth.op_params(op, B, 100 + 10 * op + si, setting).requires_grad_(True)
+                    out = cpu_ref.operator_apply(op, x, p, None, OPT)
+                    out.backward(gout)
+                    res['%s_op%d_%s' % (iname, op, setting)] = (out.detach().numpy(), x.grad.numpy(), p.grad.numpy())
+        return res
+    r8, r6 = run(1e-8), run(1e-6)
+    for k, (out, gimg, gpar) in r8.items():
+        np.testing.assert_array_equal(out, g[k + '_eps8_out'])
+        np.testing.assert_allclose(gimg, g[k + '_eps8_gimg'], rtol=1e-6, atol=1e-6 * np.abs(g[k + '_eps8_gimg']).max())
+        np.testing.assert_allclose(gpar, g[k + '_eps8_gparam'], rtol=1e-5, atol=1e-6 * max(np.abs(g[k + '_eps8_gparam']).max(), 1e-6))
+        assert np.abs(out - r6[k][0]).max() <= 3e-6
+        rel = np.abs(gimg - r6[k][1]).max() / np.abs(r6[k][1]).max()
+        assert rel <= (5e-4 if k.startswith('dark') else 1e-5), (k, rel)
+    for name in ('std_op0', 'std_op2', 'dark_op0', 'dark_op2'):
+        worst = max(np.abs(r8[k][0] - r6[k][0]).max() for k in r8 if k.startswith(name))
+        assert abs(worst - float(g['max_out_delta_' + name])) < 1e-9

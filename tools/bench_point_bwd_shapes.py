@@ -1,7 +1,7 @@
 """Why are the materialised point-operator backwards slower at 16 x 512^2 than at 64 x 256^2 (the same pixel count)?
-rocprofv3 --kernel-trace --stats -- python tools/scratch/point_bwd_shapes.py A|B   (A = 64x256x256, B = 16x512x512)"""
+rocprofv3 --kernel-trace --stats -- python tools/bench_point_bwd_shapes.py A|B   (A = 64x256x256, B = 16x512x512)"""
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import t2onet_amd.functional as T
 dev = torch.device('cuda:0')
 B, H = (64, 256) if sys.argv[1] == 'A' else (16, 512)

@@ -1,6 +1,6 @@
-"""Stand-alone timings of the 1x1 stride-2 shortcut kernels at the four encoder stages (bs=64, 256x256 image): python tools/scratch/sc_probe.py"""
+"""Stand-alone timings of the 1x1 stride-2 shortcut kernels at the four encoder stages (bs=64, 256x256 image): python tools/bench_shortcut.py"""
 import torch, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import t2onet_amd.functional as T
 from t2onet_amd import _lib
 dev = torch.device('cuda:0')

@@ -1,7 +1,7 @@
 """Stand-alone timings of the Winograd transform kernels at the two encoder stages that use them (bs=64):
-python tools/scratch/wino_probe.py"""
+python tools/bench_wino_transforms.py"""
 import torch, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import t2onet_amd.functional as T
 from t2onet_amd import _lib
 dev = torch.device('cuda:0')

@@ -592,6 +592,46 @@ def gen_extra2(opt):
     print('extra2.npz: %d arrays' % len(g), 'episode loss', float(g['ep128_loss']), 'eval', avg_init, avg)
 
 
+def gen_hsv_eps(opt):
+    """hsv_eps.npz: what a maintainer running a CURRENT kornia (rgb_to_hsv eps = 1e-8; the spec this build owns fixes
+    1e-6, the value of the 2020-era releases the reference was written against) would see differently -- the reference's
+    brightness and saturation operators on the operator fixture's inputs with the HSV shim at eps = 1e-8, forward and
+    gradients, plus a dark image (values in [0, 0.02]) where the epsilon matters most."""
+    from executors.executor import Executor
+    torch.manual_seed(0)
+    ex = Executor(opt)
+    ex.load_state_dict(synth.fill_state_dict(ex.state_dict(), seed=3))
+    B, H, W = 2, 24, 20
+    imgs = {'std': synth.images(B, H, W, 11), 'dark': synth.images(B, H, W, 11) * 0.02}
+    gout = synth.uniform((B, 3, H, W), 12, -1.0, 1.0)
+    g = {}
+    for eps, tag in ((1e-6, 'eps6'), (1e-8, 'eps8')):
+        hsv_spec.HSV_EPS = eps
+        for iname, img in imgs.items():
+            for op in (0, 2):
+                for si, setting in enumerate(['mid', 'strong', 'neg']):
+                    x = img.clone().requires_grad_(True)
+                    p = synth.op_params(op, B, 100 + 10 * op + si, setting).requires_grad_(True)
+                    out, _ = ex.execute(x, op, None, specified_param=p)
+                    out.backward(gout)
+                    key = '%s_op%d_%s_%s' % (iname, op, setting, tag)
+                    g[key + '_out'] = out.detach().numpy()
+                    g[key + '_gimg'] = x.grad.numpy()
+                    g[key + '_gparam'] = p.grad.numpy()
+    hsv_spec.HSV_EPS = 1e-6
+    worst = {}
+    for k in [k for k in g if k.endswith('eps8_out')]:
+        d = float(np.abs(g[k] - g[k.replace('eps8', 'eps6')]).max())
+        worst[k.split('_')[0] + '_' + k.split('_')[1]] = max(worst.get(k.split('_')[0] + '_' + k.split('_')[1], 0.0), d)
+    for k, v in worst.items():
+        g['max_out_delta_' + k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, 'hsv_eps.npz'), **{k: v for k, v in g.items() if 'eps6' not in k})
+    print('hsv_eps.npz: max |out(eps 1e-8) - out(eps 1e-6)|', worst)
+    for k in [k for k in g if k.endswith('eps8_gimg')]:
+        a, b = g[k], g[k.replace('eps8', 'eps6')]
+        print('  ', k, 'gimg delta / max', float(np.abs(a - b).max() / np.abs(b).max()))
+
+
 def gen_variance(opt):
     """variance.npz: the reference's test_variance() (experiments/t2onet/test_seq2seqL1.py:99-142) on three one-image
     batches (its loader is batch_size = 1: the (1, L) request row only broadcasts against one image) and four requests.
@@ -676,6 +716,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'extra2':
         gen_extra2(opt)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'hsv_eps':
+        gen_hsv_eps(opt)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'variance':
         gen_variance(opt)
         sys.exit(0)
@@ -691,3 +734,4 @@ if __name__ == '__main__':
     gen_planner(reference_opt())
     gen_extra2(reference_opt())
     gen_variance(reference_opt())
+    gen_hsv_eps(reference_opt())
