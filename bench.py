@@ -351,11 +351,17 @@ def executor_leg(ctx, ops, B, H, W, steps, warmup, with_api=False):
                              'hbm_min_GBps': round(hbm_min_bytes(name, P) / ms / 1e6, 1)}
         return el, kernels, float(run.loss.item())
 
+    fused_min_bytes = 36 * P                            # read image + target, write the image gradient, nothing else
+
     def summary(el, kernels, loss):
         ms = el / steps * 1e3
         return {'value': round(world * B * steps / el, 1), 'unit': 'images/sec', 'ms_per_step': round(ms, 4),
                 'achieved_GBps_whole_step': round(total_bytes / (ms * 1e-3) / 1e9, 1),
                 'frac_of_peak': round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # the whole sequence against the FUSED minimum (36 B/pixel for forward + L1 + backward, no intermediate
+                # ever written): the physical figure beside the credited one above -- it cannot exceed 1
+                'fused_min_MB': round(fused_min_bytes / 1e6, 2),
+                'fused_min_frac': round(fused_min_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 'sum_kernel_ms': round(sum(k['ms'] for k in kernels.values()), 4), 'loss': loss, 'kernels': kernels}
 
     mat = summary(*measure(SequenceRunner(ops, B, H, W, device)))
@@ -631,6 +637,40 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             evs.append((e0, e1))
         torch.cuda.synchronize()
         allreduce_ms = round(ctx['max_over_ranks'](sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]), 4)
+    # the other half of the reference's alternation (train_seq2seqL1.py:51-65, teacher forced: six encoder passes) and the
+    # alternating pair, AFTER the timed headline region: extra keys, same model and batch shapes
+    extra = {}
+    try:
+        ops_t = torch.stack([torch.randperm(6, generator=g)[:5] for _ in range(B)])
+        y = torch.cat([torch.full((B, 1), 1), torch.tensor([3, 4, 5, 6, 8, 9])[ops_t], torch.full((B, 1), 2)], 1).to(device)
+        img_y = torch.rand(B, 6, 3, H, W, generator=g).to(device)
+        gt = torch.rand(B, 5, 24, generator=g) * 2 - 1
+        npar = {3: 1, 4: 1, 5: 1, 6: 24, 8: 8, 9: 1}
+        for b_ in range(B):
+            for k_ in range(5):
+                gt[b_, k_, npar[int(y[b_, k_ + 1])]:] = 0
+        gt = gt.to(device)
+        n_sup = max(2, min(steps, 8))
+
+        def timed(fn, n, warm):
+            for _ in range(warm):
+                fn()
+            ctx['barrier']()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return ctx['max_over_ranks'](time.perf_counter() - t1) / n * 1e3
+        sup = timed(lambda: tr.supervised_step(x, y, img, img_y, gt, lengths=lengths), n_sup, 2)
+        pair = timed(lambda: (tr.supervised_step(x, y, img, img_y, gt, lengths=lengths),
+                              tr.episode_step(x, img, img_y[:, -1], lengths=lengths)), max(2, n_sup // 2), 1)
+        extra = {'supervised_step': {'ms_per_step': round(sup, 3), 'images_per_sec': round(world * B / sup * 1e3, 1), 'steps': n_sup,
+                                     'what': 'teacher-forced step (train_seq2seqL1.py:51-65): START + 5 operators + END, NLL + MSE, '
+                                             'six encoder passes'},
+                 'alternating_pair': {'ms_per_pair': round(pair, 3), 'images_per_sec': round(2 * world * B / pair * 1e3, 1),
+                                      'what': 'one supervised + one episode step, the reference\'s iteration parity'}}
+    except Exception as e:                 # noqa: BLE001
+        extra = {'supervised_step': {'error': '%s: %s' % (type(e).__name__, e)}}
     flop = TRAIN_FLOP_PER_IMAGE * (H * W) / (256.0 * 256.0) * B
     tf = flop / (dt / steps) / 1e12                        # per GPU
     # what the matrix cores really execute: the stride-1 3x3 layers that take the Winograd F(2x2,3x3) path (encoder.py: >= 256
@@ -666,7 +706,7 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
                                  'per GPU.  executed_*: the same minus what Winograd F(2x2,3x3) removes on the layers that '
                                  'take it (16 of 36 multiplies) -- the matrix pipe\'s real load'},
             'workload': 'episode/L1 train step (train_seq2seqL1.py:74-88), bs=%d/GPU %dx%d fp32, sampled ops, '
-                        'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world)}
+                        'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world), **extra}
 
 
 def conv_kernel_table(B, H, W, device, reps=40):

@@ -223,15 +223,19 @@ class Actor(nn.Module):
         op_mask = self._op_mask_row.repeat(B, 1)                # device-resident: no host-to-device copy (a sync)
         pred_op = torch.full((B, 1), self.start_id, dtype=torch.long, device=dev)
         pred_ops, pred_params, pred_imgs, pred_masks = [], [], [], []
+        fused_choice = img_x.is_cuda and img_x.dtype == torch.float32 and op_mask.shape[1] <= 32
+        # the Categorical draws' uniform numbers for ALL steps in one launch
+        draws = torch.rand(self.opt.decoder_max_len, B, device=dev, dtype=torch.float32) if (fused_choice and reinforce_sample) else None
         for call in range(self.opt.decoder_max_len):
             feat = feat0 if (call == 0 and feat0 is not None) else self.image_features(img_x, call)
             logp, hidden, _, context = self.decoder.forward_step(pred_op, hidden, enc_out, feat)
             if stack:
                 hiddens.append(tuple(torch.stack([t.detach() for t in h], 0) if isinstance(h, list) else h.detach() for h in hidden))
             exec_op = None
-            if logp.is_cuda and logp.dtype == torch.float32 and op_mask.shape[1] <= 32:
+            if fused_choice:
                 # exp, exploration floor, op-mask, renormalisation, draw / arg-max and the op-mask update: ONE launch
-                pred_op, exec_op = T.choose_op(logp, op_mask, self.opt.explore_prob, bool(reinforce_sample))
+                pred_op, exec_op = T.choose_op(logp, op_mask, self.opt.explore_prob, bool(reinforce_sample),
+                                               None if draws is None else draws[call])
             else:
                 probs = torch.exp(logp).squeeze(1)
                 probs = probs * (1 - self.opt.explore_prob) + self.opt.explore_prob

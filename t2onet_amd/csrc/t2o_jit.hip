@@ -64,10 +64,20 @@ const Rtc& rtc() {
 }
 
 struct Entry {
+  int device;                           // hipModuleLoadData binds a module to the device current at load time
   int K;
   int ops[kMaxChain];
   JitChain fn;
 };
+#ifndef T2O_ARCH
+#define T2O_ARCH "gfx950"               // (t2onet_amd/build.py passes the offload architecture of the ahead-of-time build)
+#endif
+
+int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) d = 0;
+  return d;
+}
 std::mutex g_mu;
 std::vector<Entry> g_entries;           // (entries are never removed: pointers into it are not handed out, copies are)
 std::string g_cache_dir;
@@ -114,8 +124,8 @@ void write_file_atomic(const std::string& path, const std::vector<char>& data) {
   const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f) return;
-  const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
-  fclose(f);
+  bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+  ok = (fclose(f) == 0) && ok;          // (a full disk shows up here)
   if (ok) rename(tmp.c_str(), path.c_str()); else remove(tmp.c_str());
 }
 
@@ -127,7 +137,7 @@ int compile(const std::string& src, std::vector<char>& code, std::string& err) {
     err = "hiprtcCreateProgram failed";
     return T2O_ELAUNCH;
   }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+  const char* opts[] = {"--offload-arch=" T2O_ARCH, "-O3", "-ffp-contract=off", "-std=c++17"};
   const hiprtcResult rc = r.compile(prog, 4, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t n = 0;
@@ -148,11 +158,28 @@ int compile(const std::string& src, std::vector<char>& code, std::string& err) {
 
 }  // namespace
 
-bool jit_lookup(const int* ops, int K, JitChain* out) {
-  std::lock_guard<std::mutex> lk(g_mu);
+static bool lookup_locked(int device, const int* ops, int K, JitChain* out) {
   for (const Entry& e : g_entries)
-    if (e.K == K && memcmp(e.ops, ops, sizeof(int) * K) == 0) { *out = e.fn; return true; }
+    if (e.device == device && e.K == K && memcmp(e.ops, ops, sizeof(int) * K) == 0) { *out = e.fn; return true; }
   return false;
+}
+
+bool jit_lookup(const int* ops, int K, JitChain* out) {
+  const int device = current_device();
+  std::lock_guard<std::mutex> lk(g_mu);
+  return lookup_locked(device, ops, K, out);
+}
+
+// code object -> module -> the six kernels; false (module unloaded again) when anything is missing
+static bool load_entry(const std::vector<char>& code, Entry& e, hipModule_t* mod_out) {
+  hipModule_t mod = nullptr;
+  if (code.empty() || hipModuleLoadData(&mod, code.data()) != hipSuccess) return false;
+  const char* names[6] = {"t2o_jit_fwd_v1", "t2o_jit_fwd_v1_l1", "t2o_jit_fwd_v2", "t2o_jit_fwd_v2_l1", "t2o_jit_bwd", "t2o_jit_bwd_l1"};
+  hipFunction_t* slots[6] = {&e.fn.fwd[0][0], &e.fn.fwd[0][1], &e.fn.fwd[1][0], &e.fn.fwd[1][1], &e.fn.bwd[0], &e.fn.bwd[1]};
+  for (int i = 0; i < 6; ++i)
+    if (hipModuleGetFunction(slots[i], mod, names[i]) != hipSuccess) { (void)hipModuleUnload(mod); return false; }
+  *mod_out = mod;
+  return true;
 }
 
 int jit_prepare(const int* ops, int K) {
@@ -161,27 +188,29 @@ int jit_prepare(const int* ops, int K) {
   if (jit_lookup(ops, K, &have)) return T2O_OK;
   const std::string src = chain_source(ops, K);
   char key[64];
-  snprintf(key, sizeof(key), "%016llx", fnv64(std::string(t2o_source_digest()) + "|gfx950|O3|nocontract|" + src));
+  snprintf(key, sizeof(key), "%016llx", fnv64(std::string(t2o_source_digest()) + "|" T2O_ARCH "|O3|nocontract|" + src));
   std::string cache_dir;
   { std::lock_guard<std::mutex> lk(g_mu); cache_dir = g_cache_dir; }
   const std::string path = cache_dir.empty() ? std::string() : cache_dir + "/chain_" + key + ".hsaco";
+  Entry e;
+  e.device = current_device();
+  e.K = K;
+  memcpy(e.ops, ops, sizeof(int) * K);
+  hipModule_t mod = nullptr;
   std::vector<char> code;
-  if (path.empty() || !read_file(path, code)) {
+  bool loaded = !path.empty() && read_file(path, code) && load_entry(code, e, &mod);
+  if (!loaded) {
+    // nothing cached, or a cached file this runtime cannot use (truncated, another compiler): evict it and compile
+    if (!path.empty()) remove(path.c_str());
     std::string err;
     const int rc = compile(src, code, err);
     if (rc != T2O_OK) return set_error(rc, err.c_str());
+    if (!load_entry(code, e, &mod)) return set_error(T2O_ELAUNCH, "jit_prepare: the compiled module does not load (hipModuleLoadData / hipModuleGetFunction)");
     if (!path.empty()) write_file_atomic(path, code);
   }
-  hipModule_t mod = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) return set_error(T2O_ELAUNCH, "jit_prepare: hipModuleLoadData failed");
-  Entry e;
-  e.K = K;
-  memcpy(e.ops, ops, sizeof(int) * K);
-  const char* names[6] = {"t2o_jit_fwd_v1", "t2o_jit_fwd_v1_l1", "t2o_jit_fwd_v2", "t2o_jit_fwd_v2_l1", "t2o_jit_bwd", "t2o_jit_bwd_l1"};
-  hipFunction_t* slots[6] = {&e.fn.fwd[0][0], &e.fn.fwd[0][1], &e.fn.fwd[1][0], &e.fn.fwd[1][1], &e.fn.bwd[0], &e.fn.bwd[1]};
-  for (int i = 0; i < 6; ++i)
-    if (hipModuleGetFunction(slots[i], mod, names[i]) != hipSuccess) return set_error(T2O_ELAUNCH, "jit_prepare: kernel missing in the compiled module");
   std::lock_guard<std::mutex> lk(g_mu);
+  JitChain other;
+  if (lookup_locked(e.device, ops, K, &other)) { (void)hipModuleUnload(mod); return T2O_OK; }   // another thread was faster
   g_entries.push_back(e);
   return T2O_OK;
 }

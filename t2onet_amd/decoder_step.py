@@ -252,8 +252,9 @@ def image_feature(pooled, fc, bn, tape=None):
     if slot is None:
         tape = DecoderTape(pooled.shape[0], fc.out_features, 4, 1, pooled.shape[1], 1, pooled.device)
         slot = tape.take_feat()
-        return _ImageFeatureFn.apply(pooled, tape, slot, fc, bn, fc.weight, fc.bias, bn.weight, bn.bias)
-    return _ImageFeatureFn.apply(pooled, tape, slot, fc, bn)
+    # (the parameters are inputs in both modes: the node must exist even when `pooled` carries no gradient -- a frozen
+    # encoder; with a persistent tape its backward hands autograd None for them and tape.flush() adds the real gradients)
+    return _ImageFeatureFn.apply(pooled, tape, slot, fc, bn, fc.weight, fc.bias, bn.weight, bn.bias)
 
 
 # ---------------------------------------------------------------------------------------------------------- decoder step
@@ -357,9 +358,6 @@ def decoder_step(dec, input_var, hidden, enc, feat, tape=None):
         D = dec.hidden_size
         tape = DecoderTape(B, D, dec.word_vec_dim, dec.output_size, 4, 1, feat.device)
         slot = tape.take_step()
-        params = tuple(p for p in _step_params(dec))
-        outs = _DecoderStepFn.apply(feat, h0, c0, h1, c1, enc, input_var, tape, slot, dec, *params)
-    else:
-        outs = _DecoderStepFn.apply(feat, h0, c0, h1, c1, enc, input_var, tape, slot, dec)
+    outs = _DecoderStepFn.apply(feat, h0, c0, h1, c1, enc, input_var, tape, slot, dec, *_step_params(dec))
     logp, h0n, c0n, h1n, c1n, ctx, attn = outs
     return logp.view(B, 1, -1), ([h0n, h1n], [c0n, c1n]), attn.view(B, 1, -1), ctx

@@ -79,6 +79,12 @@ class TrunkPlan:
         self._wt_valid = False
         self._uf_valid = False
 
+    def _versions(self):
+        """torch's in-place version counters of the convolution weights: an update made OUTSIDE the Trainer after a forward
+        (load_state_dict, a broadcast, an EMA, clipping) bumps them, and the cached transforms are then stale.  (The
+        Trainer's raw-pointer Adam kernel does not touch them: it calls weights_changed() instead -- both are checked.)"""
+        return tuple(p._version for p in self.params if p.dim() == 4)
+
     def wino(self, conv, H, W):
         """Winograd F(2x2,3x3) for this layer?  Stride 1, even maps, >= 256 channels: where 16 GEMMs of 8.6 GFLOP plus two
         transform passes over 4x the activation beat the direct kernel's 19.3 GFLOP (t2o_winograd.hip)."""
@@ -93,7 +99,7 @@ class TrunkPlan:
 
     def wino_forward(self, lib, st):
         """{id(conv): U (16,Co,Ci)} for the forward, refreshed once per weight update (persistent_wt) or per call."""
-        if self.persistent_wt and self._uf_valid:
+        if self.persistent_wt and self._uf_valid and self.__dict__.get('_uf_ver') == self._versions():
             return self._uf
         uf = self._uf if (self.persistent_wt and self._uf is not None) else {}
         ujobs = []
@@ -109,7 +115,7 @@ class TrunkPlan:
             _batched(lib.t2o_wino_weight_transform_batch, 't2o_wino_weight_transform_batch', st,
                      [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
         if self.persistent_wt:
-            self._uf, self._uf_valid = uf, True
+            self._uf, self._uf_valid, self._uf_ver = uf, True, self._versions()
         return uf
 
     def supported(self, img):
@@ -131,7 +137,7 @@ class TrunkPlan:
 
     def transformed(self, lib, st):
         """{id(conv): wt}: 3x3 stride-1 -> tap-mirrored transpose, 3x3 stride-2 -> plain transpose per tap, 1x1 -> transpose."""
-        if self.persistent_wt and self._wt_valid:
+        if self.persistent_wt and self._wt_valid and self.__dict__.get('_wt_ver') == self._versions():
             return self._wt
         wt = self._wt if (self.persistent_wt and self._wt is not None) else {}
         jobs = []                                              # every layer's transform in ONE launch
@@ -164,7 +170,7 @@ class TrunkPlan:
                      [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
         wt['wino'] = ub
         if self.persistent_wt:
-            self._wt, self._wt_valid, self._ub = wt, True, ub
+            self._wt, self._wt_valid, self._ub, self._wt_ver = wt, True, ub, self._versions()
         return wt
 
 

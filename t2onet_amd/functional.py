@@ -264,17 +264,21 @@ def attention_core(q, context):
     return _AttnFn.apply(q, context)
 
 
-def choose_op(logp, op_mask, explore_prob, sample=True):
+def choose_op(logp, op_mask, explore_prob, sample=True, u=None):
     """Next operator of the free-running decode (models/actor.py:222-236) in one launch (t2o_choose_op): probabilities
     from logp (B,n) with the exploration floor, masked by op_mask (B,n) and renormalised, one Categorical draw per
     sample (sample=True: uniform numbers from torch's generator) or the arg-max; op_mask's chosen entries are cleared in
-    place.  Returns (pred_op (B,1) int64 operator-vocabulary ids, exec_op (B) int32 executor indices = id - 3)."""
+    place.  u: this step's (B) uniform numbers when the caller drew all steps' at once (one launch per episode instead
+    of one per step).  Returns (pred_op (B,1) int64 operator-vocabulary ids, exec_op (B) int32 executor indices = id - 3)."""
     _need_gpu(logp, op_mask)
     B, n = op_mask.shape
     logp = logp.detach().reshape(B, n).contiguous()
     if not op_mask.is_contiguous():
         raise ValueError('choose_op: op_mask must be contiguous (it is updated in place)')
-    u = torch.rand(B, device=logp.device, dtype=torch.float32) if sample else None
+    if not sample:
+        u = None
+    elif u is None:
+        u = torch.rand(B, device=logp.device, dtype=torch.float32)
     pred = torch.empty(B, 1, dtype=torch.int64, device=logp.device)
     exe = torch.empty(B, dtype=torch.int32, device=logp.device)
     rc = _lib.load().t2o_choose_op(_ptr(logp), _ptr(op_mask), _ptr(u), float(explore_prob), _ptr(pred), _ptr(exe), B, n, _stream(logp.device))
@@ -831,11 +835,17 @@ def prepare_fused_sequence(ops):
         lib = _lib.load()
         c_ops = (ctypes.c_int * max(len(key), 1))(*key)
         rc = lib.t2o_fused_sequence_prepare(c_ops, len(key))
-        if rc == 2:                                            # T2O_EUNSUPPORTED: no libhiprtc here (or an unsupported operator: the call itself reports that)
-            got = False
-        else:
-            _lib.check(rc, 't2o_fused_sequence_prepare')
+        if rc == 0:
             got = True
+        else:
+            # no libhiprtc on this machine (status 2), a compile error, an unreadable cached code object ...: specialisation
+            # is an optimisation -- warn once for anything but the expected "no hipRTC", remember the outcome (no retry per
+            # call) and let the run-time-loop kernels serve this list
+            got = False
+            if rc != 2:
+                import warnings
+                warnings.warn('t2o_fused_sequence_prepare(%s) failed (status %d: %s); using the run-time-loop kernels'
+                              % (list(key), rc, lib.t2o_last_error().decode('utf-8', 'replace')))
         _prepared_chains[key] = got
     return got
 

@@ -118,14 +118,40 @@ class FlatAdam:
                                        self.betas[1], self.eps, self.step_count, T._stream(self.flat_param.device))
         _lib.check(rc, 't2o_adam_step')
 
+    LAYOUT = 2          # 2: every parameter's segment starts on a 64-float boundary (FlatGradients.ALIGN); 1: packed back to back
+
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr,
-                'betas': self.betas, 'eps': self.eps}
+                'betas': self.betas, 'eps': self.eps, 'layout': self.LAYOUT, 'offsets': list(self.grads.offsets),
+                'numels': [p.numel() for p in self.grads.params]}
 
     def load_state_dict(self, sd):
+        """Moments saved by this class under any segment layout: the state carries its offsets (layout >= 2); a state
+        without them is the packed layout of earlier versions and is converted segment by segment."""
+        numels = [p.numel() for p in self.grads.params]
+        if 'offsets' in sd:
+            src_off, src_n = list(sd['offsets']), list(sd['numels'])
+        else:                                              # layout 1: no padding between the segments
+            src_n, src_off, n = numels, [], 0
+            for k in numels:
+                src_off.append(n)
+                n += k
+        if src_n != numels:
+            raise ValueError('FlatAdam.load_state_dict: the saved state belongs to other parameters (%d tensors / %d elements, this '
+                             'model has %d / %d)' % (len(src_n), sum(src_n), len(numels), sum(numels)))
+        need = src_off[-1] + src_n[-1] if src_n else 0
+        for name in ('exp_avg', 'exp_avg_sq'):
+            if sd[name].numel() < need:
+                raise ValueError('FlatAdam.load_state_dict: %s holds %d elements, its layout needs %d' % (name, sd[name].numel(), need))
         self.step_count = int(sd['step'])
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        for name, dst in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+            src = sd[name].reshape(-1)
+            if src_off == list(self.grads.offsets) and src.numel() == dst.numel():
+                dst.copy_(src)
+            else:
+                dst.zero_()
+                for so, do, k in zip(src_off, self.grads.offsets, numels):
+                    dst[do:do + k].copy_(src[so:so + k])
         self.lr, self.betas, self.eps = float(sd['lr']), tuple(sd['betas']), float(sd['eps'])
 
 
@@ -244,7 +270,7 @@ class Trainer:
         if lengths is None:
             lengths = (x != self.opt.null_id).sum(1)
         L = self._request_length(x, lengths)
-        key = (tuple(img_x.shape), L, bool(reinforce_sample))
+        key = (tuple(img_x.shape), tuple(x.shape), L, bool(reinforce_sample))     # (x: the loader's padded request width is a captured shape too)
         sg = self._step_graphs.get(key)
         if sg is None:
             if len(self._step_graphs) >= self.max_step_graphs:

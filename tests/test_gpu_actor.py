@@ -447,6 +447,24 @@ def test_flat_adam_matches_torch_adam():
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
     x = torch.randn(2, 4, 5, 5, device=dev)
     assert torch.isfinite(net(x)).all()                                  # the module still runs on its re-homed parameters
+    # optimiser checkpoints: the state names its segment layout; a state of the earlier PACKED layout (no offsets) converts;
+    # a state of another model is refused with a message, not a bare size mismatch
+    sd = opt.state_dict()
+    assert sd['layout'] == 2 and sd['offsets'] == grads.offsets
+    packed = {'step': sd['step'], 'lr': sd['lr'], 'betas': sd['betas'], 'eps': sd['eps'],
+              'exp_avg': torch.cat([sd['exp_avg'][o:o + p.numel()] for o, p in zip(grads.offsets, params)]),
+              'exp_avg_sq': torch.cat([sd['exp_avg_sq'][o:o + p.numel()] for o, p in zip(grads.offsets, params)])}
+    keep = (sd['exp_avg'].clone(), sd['exp_avg_sq'].clone())
+    opt.exp_avg.fill_(7.0)
+    opt.exp_avg_sq.fill_(7.0)
+    opt.load_state_dict(packed)
+    for o, p in zip(grads.offsets, params):
+        assert torch.equal(opt.exp_avg[o:o + p.numel()], keep[0][o:o + p.numel()])
+        assert torch.equal(opt.exp_avg_sq[o:o + p.numel()], keep[1][o:o + p.numel()])
+    opt.load_state_dict({**sd, 'exp_avg': keep[0], 'exp_avg_sq': keep[1]})
+    assert torch.equal(opt.exp_avg, keep[0])
+    with pytest.raises(ValueError, match='other parameters'):
+        opt.load_state_dict({**sd, 'numels': sd['numels'][:-1], 'offsets': sd['offsets'][:-1]})
 
 
 @pytest.mark.gpu

@@ -409,7 +409,7 @@ def test_variance_loop_matches_the_reference(golden_dir):
     got = evaluate.test_variance(model, batches, opt, [str(t) for t in var['var_texts']], vocab2id, device=dev, verbose=False)
     assert abs(got - float(var['var_avg'])) < 1e-5
     got2 = evaluate.test_variance(model, batches, opt, list(torch.as_tensor(var['var_x'])), device=dev, verbose=False)
-    assert got2 == got
+    assert abs(got2 - got) < 1e-7
     with pytest.raises(ValueError):
         evaluate.test_variance(model, batches, opt, ['darken it'], vocab2id, device=dev, verbose=False)
 

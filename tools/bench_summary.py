@@ -24,12 +24,14 @@ for name, leg in d.get('executor', {}).items():
         continue
     for path in ('fused', 'materialised'):
         m = leg[path]
-        print('%-12s %-12s %9.0f img/s  %8.4f ms/step  frac %.3f' % (name, path, m['value'], m['ms_per_step'], m['frac_of_peak']))
+        print('%-12s %-12s %9.0f img/s  %8.4f ms/step  frac %.3f' % (name, path, m['value'], m['ms_per_step'], m['frac_of_peak']) + ('  fused-min frac %.3f' % m['fused_min_frac'] if 'fused_min_frac' in m else ''))
         for k, v in m['kernels'].items():
             print('      %-22s %8.2f us  %7.0f GB/s alg  %7.0f GB/s moved' % (k, v['ms'] * 1e3, v['GBps'], v.get('hbm_min_GBps', 0)))
     if 'api_path' in leg:
         print('   api path:', leg['api_path'])
 c = d.get('cpu_baseline')
 if c:
-    print('cpu cfg2: %s img/s on %s threads; cfg1 %s; cfg3 %s; host %s' % (c['value'], c['cores'], c.get('cfg1', {}).get('value'), c.get('cfg3', {}).get('value', c.get('cfg3')), c.get('host')))
+    print('cpu configs[2] (headline): %s img/s on %s threads of %s physical cores; configs[1] %s; configs[0] %s; host %s'
+          % (c.get('value'), c.get('threads', c.get('cores')), c.get('physical_cores'), c.get('configs_1', {}).get('value'),
+             c.get('configs_0', {}).get('value'), c.get('host')))
     print('   parity:', c.get('parity'))

@@ -4,7 +4,7 @@ python tools/clock_watch.py [steps]"""
 import glob, json, os, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-steps = sys.argv[1] if len(sys.argv) > 1 else '150'
+steps = sys.argv[1] if len(sys.argv) > 1 else '600'
 
 
 def sample():
@@ -35,11 +35,11 @@ def sample():
 
 for mode, label in (('0', 'eager'), ('1', 'whole-step hipGraph')):
     p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'step_only.py'), steps, mode, '0'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-    time.sleep(25.0)                               # start-up, warm-up steps, capture
     rows = []
-    while p.poll() is None and len(rows) < 40:
+    while p.poll() is None:                        # (the first ~10 s are start-up: the last two thirds of the samples are reported)
         rows.append(sample())
         time.sleep(0.25)
+    rows = rows[len(rows) // 3:]
     out = p.communicate()[0]
     print('==', label, out.strip().splitlines()[0] if out.strip() else '')
     keys = sorted({k for r in rows for k in r})
