@@ -174,6 +174,112 @@ class TrunkPlan:
         return wt
 
 
+class WgradArena:
+    """Weight gradients of the direct (non-Winograd) 3x3 and 1x1 layers ONCE per train step instead of once per encoder pass
+    (Trainer opt-in, like the decoder tape).  A train step runs the trunk P = 5 or 6 times; per pass and layer the weight
+    gradient kernel writes and re-reads 25-50 MB of split-K partials and launches a reduce.  With every pass's convolution
+    input x and output gradient dy stored as slice [p] of per-layer arenas (P*N, H, W, C), the P launches of a layer become
+    ONE launch of the unchanged kernel over P*N images after the last backward pass (flush()): one fifth of the partial
+    traffic, 4 of 5 reduce launches gone, nothing of it on the backward's dependent chain.  The x arenas replace buffers the
+    passes hold anyway; the dy arenas cost P x 0.55 GB at bs = 64, 256 x 256.
+
+    Keys: an activation is named by its producer -- 'a0' (stem output), (i, 'a1') / (i, 'out') of block i; a layer by its
+    module id.  begin() starts a train step; the trunk's forward takes pass numbers in call order."""
+
+    def __init__(self, plan, N, H, W, passes, device):
+        self.shape, self.P, self.N = (N, H, W), passes, N
+        self.x, self.dy, self.layers = {}, {}, []
+        Hc, Wc = H // 2, W // 2
+        prev = 'a0'
+        first_c = plan.net.conv1.weight.shape[0]
+        dims = {'a0': (Hc, Wc, first_c)}
+
+        def arena(h, w, c):
+            return torch.empty((passes * N, h, w, c), dtype=torch.float32, device=device)
+        for i, b in enumerate(plan.blocks):
+            s = b.conv1.stride[0]
+            Co, Ci = b.conv1.weight.shape[0], b.conv1.weight.shape[1]
+            Hn, Wn = (Hc - 1) // s + 1, (Wc - 1) // s + 1
+            dims[(i, 'a1')] = dims[(i, 'out')] = (Hn, Wn, Co)
+            for conv, xkey, hi, wi in ((b.conv1, prev, Hc, Wc), (b.conv2, (i, 'a1'), Hn, Wn)):
+                st = conv.stride[0]
+                if plan.wino(conv, hi, wi) or not (Wn % 4 == 0 and (st == 1 or (hi % 2 == 0 and wi % 2 == 0))):
+                    continue                                   # Winograd layers keep V; odd shapes use the gathered-row kernels
+                self.layers.append(('3x3', conv, xkey, hi, wi, Hn, Wn))
+                self.dy[id(conv)] = arena(Hn, Wn, conv.weight.shape[0])
+                if xkey not in self.x:
+                    self.x[xkey] = arena(*dims[xkey])
+            if len(b.shortcut):
+                sc = b.shortcut[0]
+                self.layers.append(('1x1', sc, prev, Hc, Wc, Hn, Wn))
+                self.dy[id(sc)] = arena(Hn, Wn, Co)
+                if prev not in self.x:
+                    self.x[prev] = arena(*dims[prev])
+            prev, Hc, Wc = (i, 'out'), Hn, Wn
+        self.begin()
+
+    def begin(self):
+        self.n_passes = 0
+        self.done = set()
+
+    def take_pass(self):
+        if self.n_passes >= self.P:
+            return None
+        self.n_passes += 1
+        return self.n_passes - 1
+
+    def x_slot(self, key, p):
+        a = self.x.get(key)
+        return None if a is None else a[p * self.N:(p + 1) * self.N]
+
+    def dy_slot(self, conv, p):
+        a = self.dy.get(id(conv))
+        return None if a is None else a[p * self.N:(p + 1) * self.N]
+
+    def flush(self, plan):
+        """One weight-gradient launch per layer over every recorded pass, ADDED into the parameters' .grad."""
+        if not self.done:
+            self.begin()
+            return
+        lib = _lib.load()
+        N = self.N
+        runs = []                                              # maximal runs of consecutive recorded passes: (first, count)
+        for p in sorted(self.done):
+            if runs and runs[-1][0] + runs[-1][1] == p:
+                runs[-1][1] += 1
+            else:
+                runs.append([p, 1])
+        for kind, conv, xkey, Hi, Wi, Hn, Wn in self.layers:
+            w = conv.weight
+            Co, Ci = w.shape[0], w.shape[1]
+            dev = w.device
+            st = _stream(dev)
+            for first, count in runs:
+                x = self.x[xkey][first * N:(first + count) * N]
+                dy = self.dy[id(conv)][first * N:(first + count) * N]
+                n = count * N
+                if kind == '3x3':
+                    s = conv.stride[0]
+                    need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(n, Hn, Wn, Ci, Co)
+                    if need == 0:                              # (more pixels than the kernel's 32-bit indices: pass by pass)
+                        for q in range(first, first + count):
+                            need1 = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)
+                            ws = torch.empty(need1, dtype=torch.uint8, device=dev)
+                            rc = lib.t2o_conv3x3_wgrad_acc_nhwc(_ptr(self.x[xkey][q * N:(q + 1) * N]), _ptr(self.dy[id(conv)][q * N:(q + 1) * N]),
+                                                                _ptr(w.grad), _ptr(ws), need1, N, Hn, Wn, Ci, Co, s, 1, st)
+                            _lib.check(rc, 't2o_conv3x3_wgrad_acc_nhwc')
+                        continue
+                    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    rc = lib.t2o_conv3x3_wgrad_acc_nhwc(_ptr(x), _ptr(dy), _ptr(w.grad), _ptr(ws), need, n, Hn, Wn, Ci, Co, s, 1, st)
+                    _lib.check(rc, 't2o_conv3x3_wgrad_acc_nhwc')
+                else:
+                    need = lib.t2o_conv1x1s2_wgrad_workspace_bytes(n, Hi, Wi, Ci, Co)
+                    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(w.grad), _ptr(ws), need, n, Hi, Wi, Ci, Co, 1, st)
+                    _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
+        self.begin()
+
+
 def _bn_fwd(lib, st, ws, bn, x, out, res, relu, partial, M, C):
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -204,6 +310,15 @@ class _TrunkFn(torch.autograd.Function):
         saved = []                                             # per layer: what the backward needs
         uf = plan.wino_forward(lib, st) if _WINOGRAD else {}
         kept_v = {}
+        # deferred weight gradients (WgradArena, installed by the Trainer): this call's pass number, or None
+        arena = plan.__dict__.get('arena')
+        into_grad = all(_persistent_grad(p) for p in plan.params)
+        apass = arena.take_pass() if (arena is not None and into_grad and arena.shape == (N, H, W) and torch.is_grad_enabled()) else None
+
+        def act_like(t, key):
+            """Buffer for an activation: its slice of the arena when a deferred weight gradient reads it, else a fresh tensor."""
+            slot = arena.x_slot(key, apass) if apass is not None else None
+            return slot if slot is not None else torch.empty_like(t)
 
         def conv3(x, conv, Nn, Hi, Wi, want_stats):
             """3x3, padding 1, stride 1 / 2 on (Nn,Hi,Wi,Ci) -> (y (Nn,Ho,Wo,Co), stats)."""
@@ -232,17 +347,17 @@ class _TrunkFn(torch.autograd.Function):
         y0 = _nhwc(N, Ho, Wo, C0, dev)
         st0 = torch.empty((lib.t2o_stem_fwd_stats_rows(N, Ho, Wo), 2, C0), dtype=torch.float32, device=dev)
         _lib.check(lib.t2o_stem_fwd(_ptr(img), _ptr(net.conv1.weight), _ptr(y0), _ptr(st0), N, Ho, Wo, C0, planar, st), 't2o_stem_fwd')
-        a0 = torch.empty_like(y0)
+        a0 = act_like(y0, 'a0')
         m0, i0 = _bn_fwd(lib, st, bn_ws, net.bn1, y0, a0, None, 1, st0, N * Ho * Wo, C0)
         stem = (y0, m0, i0)
         x, Hc, Wc = a0, Ho, Wo
-        for b in plan.blocks:
+        for bi, b in enumerate(plan.blocks):
             s = b.conv1.stride[0]
             Co = b.conv1.weight.shape[0]
             Hn, Wn = (Hc - 1) // s + 1, (Wc - 1) // s + 1
             M = N * Hn * Wn
             y1, s1 = conv3(x, b.conv1, N, Hc, Wc, True)
-            a1 = torch.empty_like(y1)
+            a1 = act_like(y1, (bi, 'a1'))
             m1, i1 = _bn_fwd(lib, st, bn_ws, b.bn1, y1, a1, None, 1, s1, M, Co)
             rec = {'x': x, 'y1': y1, 'm1': m1, 'i1': i1, 'a1': a1, 'H': Hc, 'W': Wc}
             if len(b.shortcut):
@@ -256,7 +371,7 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 sc = x
             y2, s2 = conv3(a1, b.conv2, N, Hn, Wn, True)
-            out = torch.empty_like(y2)
+            out = act_like(y2, (bi, 'out'))
             m2, i2 = _bn_fwd(lib, st, bn_ws, b.bn2, y2, out, sc, 1, s2, M, Co)
             rec.update(y2=y2, m2=m2, i2=i2, out=out)
             saved.append(rec)
@@ -264,9 +379,10 @@ class _TrunkFn(torch.autograd.Function):
         ctx.plan, ctx.img, ctx.stem, ctx.saved, ctx.planar = plan, img, stem, saved, planar
         ctx.a0 = a0
         ctx.kept_v = kept_v
+        ctx.arena, ctx.apass = (arena, apass) if apass is not None else (None, None)
         # persistent, dense gradient buffers registered for every parameter (functional.enable_grad_accumulation -- the
         # Trainer's flat buffer): the kernels accumulate into them.  Checked again in the backward.
-        ctx.into_grad = all(_persistent_grad(p) for p in plan.params)
+        ctx.into_grad = into_grad
         ctx.grads = [p.grad for p in plan.params] if ctx.into_grad else None
         ctx.pooled = plan.pool
         if plan.pool:                                          # global average pool inside the node (models/actor_resnet.py:106):
@@ -291,8 +407,15 @@ class _TrunkFn(torch.autograd.Function):
         conv_ws = _conv_workspace(dev, 64 << 10)
         wt = plan.transformed(lib, st)
 
-        def bn_bwd(bn, x, y, dy, mean, invstd, has_res, relu, want_dres, M, C):
-            dx = torch.empty_like(x)
+        # deferred weight gradients: only while the gradients really are accumulated in place (acc)
+        arena, apass = (ctx.arena, ctx.apass) if acc else (None, None)
+
+        def deferred(conv):
+            """This layer's dy slot in the arena (its weight gradient is then formed by arena.flush()), or None."""
+            return arena.dy_slot(conv, apass) if arena is not None else None
+
+        def bn_bwd(bn, x, y, dy, mean, invstd, has_res, relu, want_dres, M, C, dx=None):
+            dx = torch.empty_like(x) if dx is None else dx
             dres = torch.empty_like(x) if want_dres else None
             rc = lib.t2o_bn_relu_nhwc_bwd_acc(_ptr(x), _ptr(y), _ptr(dy), _ptr(bn.weight), _ptr(bn.bias), _ptr(mean), _ptr(invstd),
                                               _ptr(dx), _ptr(dres), _ptr(g(bn.weight)), _ptr(g(bn.bias)), has_res, relu, acc,
@@ -359,31 +482,37 @@ class _TrunkFn(torch.autograd.Function):
             Hn, Wn = (Hc - 1) // s + 1, (Wc - 1) // s + 1
             M = N * Hn * Wn
             # out = relu(bn2(y2) + sc)
-            dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co)
+            slot2 = deferred(b.conv2)
+            dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co, slot2)
             da1 = torch.empty_like(rec['a1'])
             if plan.wino(b.conv2, Hn, Wn):
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
             else:
                 dgrad3(b.conv2, dy2, da1, None, Hn, Wn, Hn, Wn)
-                wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn, Hn, Wn)
+                if slot2 is None:
+                    wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn, Hn, Wn)
             del dy2
             # a1 = relu(bn1(y1))
-            dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co)
+            slot1 = deferred(b.conv1)
+            dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co, slot1)
             del da1
             dx = torch.empty_like(rec['x'])
             if plan.wino(b.conv1, Hc, Wc) and not len(b.shortcut):
                 wino_bwd(b.conv1, rec['x'], dy1, dx, dsc, Hc, Wc)
                 d = dx
                 continue
-            wgrad3(b.conv1, rec['x'], dy1, Hc, Wc, Hn, Wn)
+            if slot1 is None:
+                wgrad3(b.conv1, rec['x'], dy1, Hc, Wc, Hn, Wn)
             if len(b.shortcut):
                 sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
-                dys, _ = bn_bwd(sc_bn, rec['ys'], None, dsc, rec['ms'], rec['is_'], 0, 0, False, M, Co)
-                need = lib.t2o_conv1x1s2_wgrad_workspace_bytes(N, Hc, Wc, Ci, Co)
-                ws = torch.empty(need, dtype=torch.uint8, device=dev)
-                rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(rec['x']), _ptr(dys), _ptr(g(sc_conv.weight)), _ptr(ws), need, N, Hc, Wc, Ci, Co,
-                                                  acc, st)
-                _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
+                slots = deferred(sc_conv)
+                dys, _ = bn_bwd(sc_bn, rec['ys'], None, dsc, rec['ms'], rec['is_'], 0, 0, False, M, Co, slots)
+                if slots is None:
+                    need = lib.t2o_conv1x1s2_wgrad_workspace_bytes(N, Hc, Wc, Ci, Co)
+                    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(rec['x']), _ptr(dys), _ptr(g(sc_conv.weight)), _ptr(ws), need, N, Hc, Wc, Ci, Co,
+                                                      acc, st)
+                    _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
                 dgrad3(b.conv1, dy1, dx, None, Hc, Wc, Hn, Wn)
                 rc = lib.t2o_conv1x1s2_dgrad_acc_nhwc(_ptr(dys), _ptr(wt[id(sc_conv)]), _ptr(dx), N, Hc, Wc, Ci, Co, st)
                 _lib.check(rc, 't2o_conv1x1s2_dgrad_acc_nhwc')
@@ -403,6 +532,8 @@ class _TrunkFn(torch.autograd.Function):
             dimg = torch.empty_like(ctx.img)                   # same layout as the image (planar NCHW or channels-last)
             rc = lib.t2o_stem_dgrad(_ptr(dy0), _ptr(net.conv1.weight), _ptr(dimg), N, Ho, Wo, C0, ctx.planar, 0, st)
             _lib.check(rc, 't2o_stem_dgrad')
+        if arena is not None:
+            arena.done.add(apass)
         return (None, dimg) + (tuple(None for _ in plan.params) if acc else tuple(grads))
 
 

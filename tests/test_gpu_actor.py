@@ -414,7 +414,9 @@ def test_trainer_with_graphed_encoder_matches_eager():
         np.testing.assert_allclose(gs1.cpu().numpy(), gs0.cpu().numpy(), rtol=0, atol=5e-4 * float(gs0.abs().max()))
         # the episode samples operators: same seed, same draws (encoder graphs consume no random numbers)
         assert abs(e0 - e1) < 1e-5
-        np.testing.assert_allclose(ge1.cpu().numpy(), ge0.cpu().numpy(), rtol=0, atol=1e-3 * float(ge0.abs().max()))
+        # (3e-3: with encoder graphs the feature head runs as fc + BatchNorm1d modules, eagerly as the fused kernel -- two fp32
+        # roundings of the same values, amplified through five chained encoder passes: measured 1.5e-3 on 5 of 22 M entries)
+        np.testing.assert_allclose(ge1.cpu().numpy(), ge0.cpu().numpy(), rtol=0, atol=3e-3 * float(ge0.abs().max()))
 
 
 @pytest.mark.gpu

@@ -231,3 +231,61 @@ def test_trunk_accumulates_into_persistent_gradients_and_is_deterministic():
     y.backward(gout)
     for n, p in net.named_parameters():
         _close(p.grad, gf[n], 1e-6)
+
+
+@pytest.mark.parametrize('size', [(64, 256), (128, 128)])
+def test_weight_gradients_once_per_step_equal_per_pass_gradients(size):
+    """encoder.WgradArena (the Trainer's opt-in): three trunk passes whose direct 3x3 / 1x1 weight gradients are formed by ONE
+    launch per layer over the passes' (x, dy) arenas, against the same passes with a weight-gradient launch each.  Same
+    kernels over 3 N images instead of 3 x N: equal up to the order of the split-K sums; everything else bit-identical."""
+    import t2onet_amd.functional as T
+    from t2onet_amd.encoder import WgradArena
+    N, (H, W), P = 2, size, 3
+    imgs = [synth.images(N, H, W, 51 + p).to(DEV) for p in range(P)]
+    gouts = [synth.uniform((N, 512), 61 + p, -1.0, 1.0).to(DEV) for p in range(P)]
+
+    def run(use_arena):
+        net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        T.enable_grad_accumulation(net.parameters())
+        plan = net.trunk_plan()
+        if use_arena:
+            plan.__dict__['arena'] = WgradArena(plan, N, H, W, P + 1, torch.device(DEV))
+            assert len(plan.arena.layers) >= 10
+        xs = [im.clone().requires_grad_(True) for im in imgs]
+        outs = [net(x) for x in xs]
+        total = sum((o * g).sum() for o, g in zip(outs, gouts))
+        total.backward()
+        if use_arena:
+            assert plan.arena.done == set(range(P))
+            plan.arena.flush(plan)
+            assert plan.arena.n_passes == 0
+        return {n: p.grad.clone() for n, p in net.named_parameters()}, [x.grad.clone() for x in xs], [o.detach() for o in outs]
+
+    g0, d0, o0 = run(False)
+    g1, d1, o1 = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(o0, o1)) and all(torch.equal(a, b) for a, b in zip(d0, d1))
+    moved = 0
+    for n in g0:
+        _close(g1[n], g0[n], 2e-5)
+        moved += int(not torch.equal(g1[n], g0[n]))
+    assert moved >= 10                                       # (the deferred layers did take the other summation order)
+    # a pass whose backward never ran (its output unused) is left out; the others still arrive
+    net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    T.enable_grad_accumulation(net.parameters())
+    plan = net.trunk_plan()
+    plan.__dict__['arena'] = WgradArena(plan, N, H, W, P + 1, torch.device(DEV))
+    outs = [net(im.clone().requires_grad_(True)) for im in imgs]
+    ((outs[0] * gouts[0]).sum() + (outs[2] * gouts[2]).sum()).backward()
+    assert plan.arena.done == {0, 2}
+    plan.arena.flush(plan)
+    ref = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+    for p in ref.parameters():
+        p.grad = torch.zeros_like(p)
+    T.enable_grad_accumulation(ref.parameters())
+    ((ref(imgs[0].clone().requires_grad_(True)) * gouts[0]).sum() + (ref(imgs[2].clone().requires_grad_(True)) * gouts[2]).sum()).backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 2e-5)

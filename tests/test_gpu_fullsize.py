@@ -97,7 +97,10 @@ def test_winograd_and_direct_kernels_give_the_same_full_size_step(monkeypatch):
     monkeypatch.setattr(E, '_WINOGRAD', True)
     tr._trunk.weights_changed()
     again = _one_step(tr, batch)
-    assert again[0] == wino[0] and torch.equal(again[2], wino[2])   # deterministic: bit-identical repeat
+    # a repeat: the loss bit for bit; the gradients to 1e-6 (this library's kernels add in fixed orders, but the step also
+    # contains framework scatter-adds -- the two embedding gradients -- whose atomic order is not fixed)
+    assert again[0] == wino[0]
+    _compare(tr, again, wino, 'repeat', 0.0, 1e-6)
 
 
 def test_tuned_library_gemms_give_the_same_full_size_step():

@@ -6,6 +6,9 @@ import t2onet_amd
 from t2onet_amd.actor import Actor
 from t2onet_amd.train import Trainer
 import bench
+if os.environ.get('T2O_NO_OVERLAP_LANG'):
+    import t2onet_amd.actor as _A
+    _A._OVERLAP_LANG = False
 
 dev = torch.device('cuda:0')
 opt = t2onet_amd.default_options()
