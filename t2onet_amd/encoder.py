@@ -313,7 +313,7 @@ class _TrunkFn(torch.autograd.Function):
         # deferred weight gradients (WgradArena, installed by the Trainer): this call's pass number, or None
         arena = plan.__dict__.get('arena')
         into_grad = all(_persistent_grad(p) for p in plan.params)
-        apass = arena.take_pass() if (arena is not None and into_grad and arena.shape == (N, H, W) and torch.is_grad_enabled()) else None
+        apass = arena.take_pass() if (arena is not None and into_grad and arena.shape == (N, H, W) and any(ctx.needs_input_grad)) else None   # (a call under no_grad records nothing)
 
         def act_like(t, key):
             """Buffer for an activation: its slice of the arena when a deferred weight gradient reads it, else a fresh tensor."""
