@@ -439,11 +439,15 @@ int t2o_wino_padded_tiles(int N, int H, int W);
 int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* stream);
 int t2o_wino_weight_transform_batch(const float* const* w, float* const* U, const int* Cn, const int* Ck, int n, void* stream);   /* n <= 32 banks, one launch */
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
+/* the same into rows [0, Tpad) of every plane of a LARGER (16, plane_rows, C) tensor whose first plane starts at V (a train
+ * step's passes side by side: the weight gradient then runs once over all of them); plane_rows = 0: Tpad */
+int t2o_wino_input_transform_ld(const float* x, float* V, int N, int H, int W, int C, int plane_rows, void* stream);
 int t2o_wino_stats_rows(int N, int H, int W, int C);
 int t2o_wino_output_transform(const float* M, const float* addend, float* y, float* stats, int N, int H, int W, int C, void* stream);
 int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream);
 /* t2o_wino_input_transform(dy) and t2o_wino_dy_transform(dy) in one pass over dy (a layer's backward needs both) */
 int t2o_wino_dy_transforms(const float* dy, float* V, float* Ad, int N, int H, int W, int C, void* stream);
+int t2o_wino_dy_transforms_ld(const float* dy, float* V, float* Ad, int N, int H, int W, int C, int ad_plane_rows, void* stream);   /* Ad as a row range of a (16, ad_plane_rows, C) tensor */
 int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int splits, int accumulate, void* stream);
 /* the batched fp32 matrix-core GEMMs behind them (t2o_conv.hip k_gemm_nt / k_gemm_tn: the forward convolution's LDS-DMA
  * machinery without taps), dense row-major operands:

@@ -37,7 +37,8 @@ __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(
 
 // x (N,H,W,C) -> V (16, Tpad, C), T = N * H/2 * W/2 tiles, rows T .. Tpad - 1 zero (the weight gradient's GEMM runs over
 // whole 64-row stages of the tile index)
-__global__ __launch_bounds__(kThreads) void k_wino_input(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C, int Tpad) {
+// (PR = rows per plane of V: Tpad for a tensor of its own, more when V is a row range of a larger (16, PR, C) arena)
+__global__ __launch_bounds__(kThreads) void k_wino_input(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W, int C, int Tpad, int PR) {
   const int q = C >> 2, TH = H >> 1, TW = W >> 1;
   const size_t T = (size_t)N * TH * TW;
   const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(kThreads) void k_wino_input(const float* __restrict
   if (t >= T) {
     float* o = V + t * C + 4 * cq;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) st4(o + (size_t)k * Tpad * C, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (int k = 0; k < 16; ++k) st4(o + (size_t)k * PR * C, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     return;
   }
   const int n = (int)(t / (TH * TW)), rem = (int)(t - (size_t)n * TH * TW), th = rem / TW, tw = rem - th * TW;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void k_wino_input(const float* __restrict
     r[2][j] = sub4(d[2][j], d[1][j]);
     r[3][j] = sub4(d[1][j], d[3][j]);
   }
-  const size_t plane = (size_t)Tpad * C;
+  const size_t plane = (size_t)PR * C;
   float* o = V + t * C + 4 * cq;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_wino_weight(const float* __restric
 //   Ad (16, T, Co) = A dY A^T of the 2 x 2 output-gradient tiles (A = [[1,0],[1,1],[1,-1],[0,-1]])
 //   dU[xi] (Co, Ci) = Ad[xi]^T * V[xi]       16 GEMMs with K = T, V = the forward's transformed input (kept, or redone)
 //   dw (Co,3,3,Ci) (+)= G^T dU G
-__global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ Ad, int N, int H, int W, int C, int Tpad) {
+__global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ Ad, int N, int H, int W, int C, int Tpad, int PR) {
   const int q = C >> 2, TH = H >> 1, TW = W >> 1;
   const size_t T = (size_t)N * TH * TW;
   const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ 
   if (t >= T) {                                            // zero rows up to Tpad (as k_wino_input)
     float* o = Ad + t * C + 4 * cq;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) st4(o + (size_t)k * Tpad * C, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (int k = 0; k < 16; ++k) st4(o + (size_t)k * PR * C, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     return;
   }
   const int n = (int)(t / (TH * TW)), rem = (int)(t - (size_t)n * TH * TW), th = rem / TW, tw = rem - th * TW;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ 
   // A d: rows (d0, d0 + d1, d0 - d1, -d1)
   const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   const float4 r[4][2] = {{d00, d01}, {add4(d00, d10), add4(d01, d11)}, {sub4(d00, d10), sub4(d01, d11)}, {sub4(zero, d10), sub4(zero, d11)}};
-  const size_t plane = (size_t)Tpad * C;
+  const size_t plane = (size_t)PR * C;
   float* o = Ad + t * C + 4 * cq;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -198,20 +199,20 @@ __global__ __launch_bounds__(kThreads) void k_wino_dy(const float* __restrict__ 
 // Both transforms of an output gradient in one pass over dy: V = B^T d B of the 4 x 4 patches (the data gradient's GEMM
 // operand) and Ad = A dY A^T of their inner 2 x 2 blocks (the weight gradient's); rows T .. Tpad - 1 of both are zero.
 __global__ __launch_bounds__(kThreads) void k_wino_dy_both(const float* __restrict__ dy, float* __restrict__ V, float* __restrict__ Ad,
-                                                           int N, int H, int W, int C, int Tpad) {
+                                                           int N, int H, int W, int C, int Tpad, int PRa) {
   const int q = C >> 2, TH = H >> 1, TW = W >> 1;
   const size_t T = (size_t)N * TH * TW;
   const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
   if (idx >= (size_t)Tpad * q) return;
   const size_t t = idx / q;
   const int cq = (int)(idx - t * q);
-  const size_t plane = (size_t)Tpad * C;
+  const size_t plane = (size_t)Tpad * C, plane_a = (size_t)PRa * C;
   float* ov = V + t * C + 4 * cq;
   float* oa = Ad + t * C + 4 * cq;
   const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (t >= T) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { st4(ov + (size_t)k * plane, zero); st4(oa + (size_t)k * plane, zero); }
+    for (int k = 0; k < 16; ++k) { st4(ov + (size_t)k * plane, zero); st4(oa + (size_t)k * plane_a, zero); }
     return;
   }
   const int n = (int)(t / (TH * TW)), rem = (int)(t - (size_t)n * TH * TW), th = rem / TW, tw = rem - th * TW;
@@ -229,10 +230,10 @@ __global__ __launch_bounds__(kThreads) void k_wino_dy_both(const float* __restri
                             {sub4(d[1][1], d[2][1]), sub4(d[1][2], d[2][2])}, {sub4(zero, d[2][1]), sub4(zero, d[2][2])}};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      st4(oa + (size_t)(4 * i + 0) * plane, r[i][0]);
-      st4(oa + (size_t)(4 * i + 1) * plane, add4(r[i][0], r[i][1]));
-      st4(oa + (size_t)(4 * i + 2) * plane, sub4(r[i][0], r[i][1]));
-      st4(oa + (size_t)(4 * i + 3) * plane, sub4(zero, r[i][1]));
+      st4(oa + (size_t)(4 * i + 0) * plane_a, r[i][0]);
+      st4(oa + (size_t)(4 * i + 1) * plane_a, add4(r[i][0], r[i][1]));
+      st4(oa + (size_t)(4 * i + 2) * plane_a, sub4(r[i][0], r[i][1]));
+      st4(oa + (size_t)(4 * i + 3) * plane_a, sub4(zero, r[i][1]));
     }
   }
   float4 r[4][4];
@@ -374,12 +375,17 @@ int t2o_wino_padded_tiles(int N, int H, int W) {
 }
 
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream) {
+  return t2o_wino_input_transform_ld(x, V, N, H, W, C, 0, stream);
+}
+
+int t2o_wino_input_transform_ld(const float* x, float* V, int N, int H, int W, int C, int plane_rows, void* stream) {
   if (!x || !V || !wino_shape_ok(N, H, W, C)) return set_error(T2O_EINVAL, "wino_input_transform: null pointer or bad shape (H, W even; C a power of two in [4, 1024])");
   if ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(V)) & 15) return set_error(T2O_EINVAL, "wino_input_transform: tensors must be 16-byte aligned");
   const int Tpad = t2o_wino_padded_tiles(N, H, W);
   if (Tpad <= 0) return set_error(T2O_EUNSUPPORTED, "wino_input_transform: too many tiles");
+  if (plane_rows != 0 && plane_rows < Tpad) return set_error(T2O_EINVAL, "wino_input_transform: plane_rows smaller than the padded tile count");
   const size_t work = (size_t)Tpad * (C / 4);
-  k_wino_input<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(x, V, N, H, W, C, Tpad);
+  k_wino_input<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(x, V, N, H, W, C, Tpad, plane_rows ? plane_rows : Tpad);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_input_transform: launch failed");
 }
 
@@ -389,17 +395,22 @@ int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C
   const int Tpad = t2o_wino_padded_tiles(N, H, W);
   if (Tpad <= 0) return set_error(T2O_EUNSUPPORTED, "wino_dy_transform: too many tiles");
   const size_t work = (size_t)Tpad * (C / 4);
-  k_wino_dy<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, Ad, N, H, W, C, Tpad);
+  k_wino_dy<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, Ad, N, H, W, C, Tpad, Tpad);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transform: launch failed");
 }
 
 int t2o_wino_dy_transforms(const float* dy, float* V, float* Ad, int N, int H, int W, int C, void* stream) {
+  return t2o_wino_dy_transforms_ld(dy, V, Ad, N, H, W, C, 0, stream);
+}
+
+int t2o_wino_dy_transforms_ld(const float* dy, float* V, float* Ad, int N, int H, int W, int C, int ad_plane_rows, void* stream) {
   if (!dy || !V || !Ad || !wino_shape_ok(N, H, W, C)) return set_error(T2O_EINVAL, "wino_dy_transforms: null pointer or bad shape (H, W even; C a power of two in [4, 1024])");
   if ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(V) | reinterpret_cast<size_t>(Ad)) & 15) return set_error(T2O_EINVAL, "wino_dy_transforms: tensors must be 16-byte aligned");
   const int Tpad = t2o_wino_padded_tiles(N, H, W);
   if (Tpad <= 0) return set_error(T2O_EUNSUPPORTED, "wino_dy_transforms: too many tiles");
+  if (ad_plane_rows != 0 && ad_plane_rows < Tpad) return set_error(T2O_EINVAL, "wino_dy_transforms: ad_plane_rows smaller than the padded tile count");
   const size_t work = (size_t)Tpad * (C / 4);
-  k_wino_dy_both<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, V, Ad, N, H, W, C, Tpad);
+  k_wino_dy_both<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, V, Ad, N, H, W, C, Tpad, ad_plane_rows ? ad_plane_rows : Tpad);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transforms: launch failed");
 }
 

@@ -24,7 +24,8 @@ import os
 import torch
 
 from . import _lib
-from .functional import _need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input, wino_backward_nhwc
+from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input,
+                         wino_backward_nhwc, wino_dw_from)
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
@@ -189,6 +190,7 @@ class WgradArena:
     def __init__(self, plan, N, H, W, passes, device):
         self.shape, self.P, self.N = (N, H, W), passes, N
         self.x, self.dy, self.layers = {}, {}, []
+        self.V, self.Ad, self.wino = {}, {}, []
         Hc, Wc = H // 2, W // 2
         prev = 'a0'
         first_c = plan.net.conv1.weight.shape[0]
@@ -203,8 +205,16 @@ class WgradArena:
             dims[(i, 'a1')] = dims[(i, 'out')] = (Hn, Wn, Co)
             for conv, xkey, hi, wi in ((b.conv1, prev, Hc, Wc), (b.conv2, (i, 'a1'), Hn, Wn)):
                 st = conv.stride[0]
-                if plan.wino(conv, hi, wi) or not (Wn % 4 == 0 and (st == 1 or (hi % 2 == 0 and wi % 2 == 0))):
-                    continue                                   # Winograd layers keep V; odd shapes use the gathered-row kernels
+                if plan.wino(conv, hi, wi):
+                    # Winograd layer: the passes' transformed inputs V and output gradients A dY A^T side by side, one
+                    # batch of 16 GEMMs over all their tiles + one back-transform per train step
+                    Tpad = _lib.load().t2o_wino_padded_tiles(N, hi, wi)
+                    self.wino.append((conv, hi, wi, Tpad))
+                    self.V[id(conv)] = torch.empty((16, passes * Tpad, conv.weight.shape[1]), dtype=torch.float32, device=device)
+                    self.Ad[id(conv)] = torch.empty((16, passes * Tpad, conv.weight.shape[0]), dtype=torch.float32, device=device)
+                    continue
+                if not (Wn % 4 == 0 and (st == 1 or (hi % 2 == 0 and wi % 2 == 0))):
+                    continue                                   # odd shapes use the gathered-row kernels, pass by pass
                 self.layers.append(('3x3', conv, xkey, hi, wi, Hn, Wn))
                 self.dy[id(conv)] = arena(Hn, Wn, conv.weight.shape[0])
                 if xkey not in self.x:
@@ -220,7 +230,8 @@ class WgradArena:
 
     def begin(self):
         self.n_passes = 0
-        self.done = set()
+        self.done = set()                                      # passes whose backward ran
+        self.rec = {}                                          # id(layer) -> passes whose backward left this layer's dy / A dY A^T here
 
     def take_pass(self):
         if self.n_passes >= self.P:
@@ -233,8 +244,23 @@ class WgradArena:
         return None if a is None else a[p * self.N:(p + 1) * self.N]
 
     def dy_slot(self, conv, p):
+        """Pass p's slice of the layer's dy arena for the backward to fill (the layer's weight gradient is then flush()'s), or
+        None when the layer is not deferred."""
         a = self.dy.get(id(conv))
-        return None if a is None else a[p * self.N:(p + 1) * self.N]
+        if a is None:
+            return None
+        self.rec.setdefault(id(conv), set()).add(p)
+        return a[p * self.N:(p + 1) * self.N]
+
+    def wino_slot(self, which, conv, p):
+        """Pass p's (16, Tpad, C) row range of the layer's V ('V', forward) or A dY A^T ('Ad', backward) arena, or None."""
+        a = (self.V if which == 'V' else self.Ad).get(id(conv))
+        if a is None:
+            return None
+        if which == 'Ad':
+            self.rec.setdefault(id(conv), set()).add(p)
+        Tpad = a.shape[1] // self.P
+        return a[:, p * Tpad:(p + 1) * Tpad]
 
     def flush(self, plan):
         """One weight-gradient launch per layer over every recorded pass, ADDED into the parameters' .grad."""
@@ -243,18 +269,22 @@ class WgradArena:
             return
         lib = _lib.load()
         N = self.N
-        runs = []                                              # maximal runs of consecutive recorded passes: (first, count)
-        for p in sorted(self.done):
-            if runs and runs[-1][0] + runs[-1][1] == p:
-                runs[-1][1] += 1
-            else:
-                runs.append([p, 1])
+        def runs_of(passes):
+            """Maximal runs of consecutive passes: [first, count]."""
+            runs = []
+            for p in sorted(passes):
+                if runs and runs[-1][0] + runs[-1][1] == p:
+                    runs[-1][1] += 1
+                else:
+                    runs.append([p, 1])
+            return runs
         for kind, conv, xkey, Hi, Wi, Hn, Wn in self.layers:
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             dev = w.device
             st = _stream(dev)
-            for first, count in runs:
+            for first, count in runs_of(self.rec.get(id(conv), ())):      # (a layer the backward did not leave here -- e.g. the plan's
+                                                                          # Winograd choice changed since the arena was built -- has none)
                 x = self.x[xkey][first * N:(first + count) * N]
                 dy = self.dy[id(conv)][first * N:(first + count) * N]
                 n = count * N
@@ -277,6 +307,14 @@ class WgradArena:
                     ws = torch.empty(need, dtype=torch.uint8, device=dev)
                     rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(w.grad), _ptr(ws), need, n, Hi, Wi, Ci, Co, 1, st)
                     _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
+        for conv, Hi, Wi, Tpad in self.wino:
+            V, Ad, dw = self.V[id(conv)], self.Ad[id(conv)], conv.weight.grad
+            got = self.rec.get(id(conv), set())
+            if len(got) == self.P and wino_dw_from(Ad, V, dw, True):
+                continue                                       # every pass recorded: ONE batch of GEMMs over all tiles
+            for q in sorted(got):                              # (an unused pass, or a row count without a valid split)
+                if not wino_dw_from(Ad[:, q * Tpad:(q + 1) * Tpad].contiguous(), V[:, q * Tpad:(q + 1) * Tpad].contiguous(), dw, True):
+                    raise RuntimeError('WgradArena: no split for the Winograd weight gradient of %d tiles' % Tpad)
         self.begin()
 
 
@@ -328,7 +366,8 @@ class _TrunkFn(torch.autograd.Function):
             Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
             if plan.wino(conv, Hi, Wi):
                 keep = []
-                y, stats = wino_conv_nhwc(x, uf[id(conv)], Nn, Hi, Wi, None, True, keep_v=keep)
+                y, stats = wino_conv_nhwc(x, uf[id(conv)], Nn, Hi, Wi, None, True, keep_v=keep,
+                                          v_out=arena.wino_slot('V', conv, apass) if apass is not None else None)
                 kept_v[id(conv)] = keep[0]                     # (4x the layer's input: its weight gradient starts from it)
                 return y, stats
             y = _nhwc(Nn, Ho, Wo, Co, dev)
@@ -448,7 +487,8 @@ class _TrunkFn(torch.autograd.Function):
             V = ctx.kept_v.pop(id(conv), None)
             if V is None:
                 V = wino_input(x, N, Hi, Wi)
-            wino_backward_nhwc(dy, V, wt['wino'][id(conv)], g(conv.weight), dx, N, Hi, Wi, addend, acc)
+            ad_out = arena.wino_slot('Ad', conv, apass) if arena is not None else None
+            wino_backward_nhwc(dy, V, wt['wino'][id(conv)], g(conv.weight), dx, N, Hi, Wi, addend, acc, ad_out)
 
         def dgrad3(conv, dy, dx, addend, Hi, Wi, Hn, Wn):
             """dx (N,Hi,Wi,Ci) = data gradient of conv for dy (N,Hn,Wn,Co) (+ addend, stride 1 only)."""

@@ -1355,6 +1355,9 @@ def gemm_nt_batched(A, B, M=None):
     M = rows if M is None else M
     if not _OWN_WINO_GEMM:
         return torch.bmm(A[:, :M], B.transpose(1, 2))
+    if A.stride(2) != 1 or A.stride(1) != K or A.stride(0) % K:
+        raise ValueError('gemm_nt_batched: A must have dense rows (a row range of a larger (batches, R, K) tensor is fine)')
+    rows = A.stride(0) // K                                # rows per plane of the tensor A lives in
     N = B.shape[1]
     C = torch.empty((batches, M, N), dtype=torch.float32, device=A.device)
     _lib.check(_lib.load().t2o_gemm_nt_batched(_ptr(A), _ptr(B), _ptr(C), batches, M, N, K, rows, _stream(A.device)), 't2o_gemm_nt_batched')
@@ -1377,14 +1380,18 @@ def gemm_tn_batched(A, B):
     return C
 
 
-def wino_input(x, N, H, W):
+def wino_input(x, N, H, W, out=None):
     """x (N,H,W,C) -> V (16, Tpad, C): the transformed 4x4 input patches of the T = N*H/2*W/2 output tiles, zero rows up to
-    Tpad = t2o_wino_padded_tiles (a multiple of 256)."""
+    Tpad = t2o_wino_padded_tiles (a multiple of 256).  out: a (16, Tpad, C) row range of a larger (16, R, C) tensor to write
+    into (encoder.WgradArena: the passes of a train step side by side)."""
     lib = _lib.load()
     C = x.shape[-1]
-    V = torch.empty((16, lib.t2o_wino_padded_tiles(N, H, W), C), dtype=torch.float32, device=x.device)
-    _lib.check(lib.t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, C, _stream(x.device)), 't2o_wino_input_transform')
-    return V
+    if out is None:
+        V = torch.empty((16, lib.t2o_wino_padded_tiles(N, H, W), C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.t2o_wino_input_transform(_ptr(x), _ptr(V), N, H, W, C, _stream(x.device)), 't2o_wino_input_transform')
+        return V
+    _lib.check(lib.t2o_wino_input_transform_ld(_ptr(x), _ptr(out), N, H, W, C, out.stride(0) // C, _stream(x.device)), 't2o_wino_input_transform_ld')
+    return out
 
 
 def wino_wgrad_nhwc(V, dy, dw, N, H, W, accumulate):
@@ -1394,36 +1401,54 @@ def wino_wgrad_nhwc(V, dy, dw, N, H, W, accumulate):
     Co, Ci = dy.shape[-1], V.shape[2]
     Ad = torch.empty((16, V.shape[1], Co), dtype=torch.float32, device=dy.device)
     _lib.check(lib.t2o_wino_dy_transform(_ptr(dy), _ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transform')
-    dU = gemm_tn_batched(Ad, V)                           # 16 GEMMs over the tiles (Co x T) x (T x Ci), in `splits` pieces
+    dU = gemm_tn_batched(Ad, V.contiguous())              # 16 GEMMs over the tiles (Co x T) x (T x Ci), in `splits` pieces
     _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, dU.shape[0], 1 if accumulate else 0, st), 't2o_wino_dw_transform')
 
 
-def wino_backward_nhwc(dy, Vx, Ud, dw, dx, N, H, W, addend, accumulate):
+def wino_backward_nhwc(dy, Vx, Ud, dw, dx, N, H, W, addend, accumulate, ad_out=None):
     """Both gradients of a Winograd layer from one pass over dy (N,H,W,Co): dx (N,H,W,Ci) = data gradient (+ addend) with
     Ud (16,Ci,Co) the transformed mirrored filter, dw (Co,3,3,Ci) (+)= weight gradient with Vx (16,Tpad,Ci) the forward's
-    transformed input."""
+    transformed input.  ad_out: a (16, Tpad, Co) row range of a larger tensor that receives A dY A^T instead -- the weight
+    gradient is then NOT formed here (encoder.WgradArena forms it once over all passes of the train step)."""
     lib = _lib.load()
     dev = dy.device
     st = _stream(dev)
     Co, Ci = dy.shape[-1], Vx.shape[2]
     Tpad = Vx.shape[1]
     Vd = torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
-    Ad = torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
-    _lib.check(lib.t2o_wino_dy_transforms(_ptr(dy), _ptr(Vd), _ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transforms')
+    if ad_out is None:
+        Ad = torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
+        _lib.check(lib.t2o_wino_dy_transforms(_ptr(dy), _ptr(Vd), _ptr(Ad), N, H, W, Co, st), 't2o_wino_dy_transforms')
+    else:
+        _lib.check(lib.t2o_wino_dy_transforms_ld(_ptr(dy), _ptr(Vd), _ptr(ad_out), N, H, W, Co, ad_out.stride(0) // Co, st), 't2o_wino_dy_transforms_ld')
     M = gemm_nt_batched(Vd, Ud, N * (H // 2) * (W // 2))
     _lib.check(lib.t2o_wino_output_transform(_ptr(M), _ptr(addend), _ptr(dx), None, N, H, W, Ci, st), 't2o_wino_output_transform')
-    dU = gemm_tn_batched(Ad, Vx)
-    _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, dU.shape[0], 1 if accumulate else 0, st), 't2o_wino_dw_transform')
+    if ad_out is None:
+        if not wino_dw_from(Ad, Vx.contiguous(), dw, accumulate):       # (.contiguous(): Vx may be a row range of an arena)
+            raise RuntimeError('wino_backward_nhwc: no split for %d tile rows' % Tpad)
 
 
-def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_v=None):
+def wino_dw_from(Ad, V, dw, accumulate):
+    """dw (Co,3,3,Ci) (+)= G^T [sum over the tile rows of Ad (16,R,Co)^T V (16,R,Ci)] G; False when the row count has no valid
+    split (the caller then goes piece by piece)."""
+    lib = _lib.load()
+    Co, Ci = Ad.shape[2], V.shape[2]
+    if lib.t2o_gemm_tn_splits(16, Ad.shape[1], Co, Ci) <= 0:
+        return False
+    dU = gemm_tn_batched(Ad, V)
+    _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, dU.shape[0], 1 if accumulate else 0, _stream(dw.device)), 't2o_wino_dw_transform')
+    return True
+
+
+def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_v=None, v_out=None):
     """x (N,H,W,Ci) NHWC buffer, U (16,Co,Ci) -> y (N,H,W,Co) (+ addend) [, stats rows for the batch norm that follows].
-    keep_v: a list that receives V (the weight gradient reuses it: wino_wgrad_nhwc)."""
+    keep_v: a list that receives V (the weight gradient reuses it: wino_wgrad_nhwc); v_out: where V is to be written
+    (wino_input's `out`)."""
     lib = _lib.load()
     dev = x.device
     st = _stream(dev)
     Co = U.shape[1]
-    V = wino_input(x, N, H, W)
+    V = wino_input(x, N, H, W, v_out)
     if keep_v is not None:
         keep_v.append(V)
     M = gemm_nt_batched(V, U, N * (H // 2) * (W // 2))    # 16 GEMMs (T x Ci) x (Ci x Co)

@@ -209,7 +209,7 @@ class GraphedEpisodeStep:
             tr._trunk.weights_changed()                        # the weights were updated since the last step: transform them again
         tr.grads.zero()
         tr._tape(self.s_img.shape[0])
-        tr._arena(self.s_img)
+        tr._arena(self.s_img, tr.opt.decoder_max_len)
         lengths = (self.s_x != tr.opt.null_id).sum(1)         # on the device, inside the graph: no host-side lengths to copy
         _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, lengths, self.longest, stack=False)
         loss = end_l1_loss(imgs, ops, tr.opt.end_id, self.s_target)

@@ -230,20 +230,22 @@ class Trainer:
         if arena is not None:
             arena.flush(self._trunk)
 
-    def _arena(self, img):
-        """The encoder's per-layer (x, dy) arenas for this batch shape (encoder.WgradArena): the direct convolutions' weight
-        gradients are then ONE launch per layer and train step (formed by _flush_tape) instead of one per encoder pass.  Not
-        with per-pass encoder graphs (their backward graphs accumulate inside the graph)."""
+    def _arena(self, img, passes):
+        """The encoder's per-layer (x, dy) / (V, A dY A^T) arenas for this batch shape and number of encoder passes
+        (encoder.WgradArena): the convolutions' weight gradients are then ONE launch per layer and train step (formed by
+        _flush_tape) instead of one per encoder pass.  Not with per-pass encoder graphs (their backward graphs accumulate
+        inside the graph).  One arena per (shape, passes) met: the episode step runs decoder_max_len passes, the
+        teacher-forced step one more."""
         if self._trunk is None or self.graph_encoder or not img.is_cuda:
             return
-        arena = self._trunk.__dict__.get('arena')
-        shape = (img.shape[0], img.shape[2], img.shape[3])
-        if arena is None or arena.shape != shape:
+        key = (img.shape[0], img.shape[2], img.shape[3], int(passes))
+        arenas = self.__dict__.setdefault('_arenas', {})
+        arena = arenas.get(key)
+        if arena is None and key not in arenas:
             from .encoder import WgradArena
-            self._trunk.__dict__['arena'] = None
-            if self._trunk.supported(img):
-                arena = self._trunk.__dict__['arena'] = WgradArena(self._trunk, shape[0], shape[1], shape[2], self.opt.decoder_max_len + 1,
-                                                                   img.device)
+            arena = arenas[key] = (WgradArena(self._trunk, key[0], key[1], key[2], key[3], img.device)
+                                   if (passes > 0 and self._trunk.supported(img)) else None)
+        self._trunk.__dict__['arena'] = arena
         if arena is not None:
             arena.begin()
 
@@ -315,7 +317,7 @@ class Trainer:
         step = int((y != self.opt.null_id).sum(1).max())
         self._maybe_graph(img_x)
         self._tape(img_x.shape[0])
-        self._arena(img_x)
+        self._arena(img_x, step - 1)
         _, pred_params, logp = self.model.supervised_forward(x, y, img_x, img_y, gt_params, None, lengths)
         target = y[:, 1:step].contiguous().view(-1)
         op_loss = F.nll_loss(logp.reshape(-1, logp.shape[-1]), target)
@@ -332,7 +334,7 @@ class Trainer:
                 return loss
         self._maybe_graph(img_x)
         self._tape(img_x.shape[0])
-        self._arena(img_x)
+        self._arena(img_x, self.opt.decoder_max_len)
         _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths, stack=False)
         loss = end_l1_loss(pred_imgs, pred_ops, self.opt.end_id, target)
         self._finish(loss)

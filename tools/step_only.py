@@ -17,7 +17,7 @@ model = Actor(opt).to(dev).train()
 model.use_channels_last()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 if os.environ.get('T2O_NO_ARENA'):
-    Trainer._arena = lambda self, img: None
+    Trainer._arena = lambda self, img, passes: None
 tr = Trainer(model, opt, graph_encoder=(sys.argv[3] != '0') if len(sys.argv) > 3 else True, graph_step=(sys.argv[2] != '0') if len(sys.argv) > 2 else True)
 g = torch.Generator().manual_seed(10)
 B, H, W = 64, 256, 256
