@@ -19,7 +19,7 @@ opt = t2onet_amd.default_options()
 torch.manual_seed(10)
 model = Actor(opt).to(dev).train()
 model.use_channels_last()
-tr = Trainer(model, opt, graph_encoder=True)
+tr = Trainer(model, opt)                      # eager, as bench.py runs it
 g = torch.Generator().manual_seed(10)
 img = torch.rand(B, 3, H, W, generator=g).to(dev)
 img_y = torch.rand(B, 6, 3, H, W, generator=g).to(dev)
