@@ -142,6 +142,10 @@ class ResNet(nn.Module):
 
     def pooled_features(self, x):
         """Everything before `fc` (models/actor_resnet.py:98-106): the convolutional trunk and the global mean, (N, 512)."""
+        if x.is_cuda and x.dim() == 4 and not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+            # a batch-strided view (the teacher-forced step feeds img_y[:, i]: actor.py:172): one 50 MB copy instead of the
+            # per-layer path the strided image would otherwise take (no Winograd, no once-per-step weight gradients)
+            x = x.contiguous()
         if _TRUNK and _FUSED and _OWN_WGRAD and self.training and x.is_cuda and torch.is_grad_enabled():
             plan = self.trunk_plan()
             if plan.supported(x):

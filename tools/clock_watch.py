@@ -8,21 +8,26 @@ steps = sys.argv[1] if len(sys.argv) > 1 else '600'
 
 
 def sample():
-    out = {}
-    for hw in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'):
-        for name in ('power1_average', 'power1_input', 'freq1_input', 'power1_cap'):
-            try:
-                with open(os.path.join(hw, name)) as f:
-                    out[name] = int(f.read().strip())
-            except (OSError, ValueError):
-                pass
-    for f in glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'):
+    """Counters of the BUSIEST card (the box shows every GPU of the node; the leased one is the one drawing power)."""
+    best = {}
+    for card in sorted(glob.glob('/sys/class/drm/card*/device')):
+        out = {}
+        for hw in glob.glob(os.path.join(card, 'hwmon/hwmon*')):
+            for name in ('power1_average', 'power1_input', 'freq1_input', 'power1_cap'):
+                try:
+                    with open(os.path.join(hw, name)) as f:
+                        out[name] = int(f.read().strip())
+                except (OSError, ValueError):
+                    pass
         try:
-            cur = [ln for ln in open(f).read().splitlines() if ln.rstrip().endswith('*')]
+            cur = [ln for ln in open(os.path.join(card, 'pp_dpm_sclk')).read().splitlines() if ln.rstrip().endswith('*')]
             if cur:
                 out['sclk'] = cur[0]
         except OSError:
             pass
+        if out.get('power1_input', out.get('power1_average', 0)) > best.get('power1_input', best.get('power1_average', -1)):
+            best = out
+    out = best
     if not out:
         try:
             r = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--json'], capture_output=True, text=True, timeout=10)
