@@ -283,3 +283,69 @@ def test_chain_specialisation_cache_is_rank_safe(tmp_path):
     codes = [open(out % r).read().split(' ', 1) for r in range(2)]
     assert codes[0][0] == codes[1][0], codes                        # the same outcome on both ranks
     assert not [f for f in os.listdir(cache) if '.tmp' in f]        # atomic writes: nothing half-written remains
+
+
+def test_decoder_tape_forms_each_weight_gradient_once_over_all_steps():
+    """decoder_step.DecoderTape host logic (no kernels involved): with the (X, dY) pairs of n recorded steps in the tape's arrays,
+    flush() must ADD exactly sum_s dY_s^T X_s (and the bias / embedding / batch-norm sums) to every parameter's .grad, skip the
+    output projection when no step had a gradient through its scores, zero the slots of a step whose backward never ran, and
+    rewind.  Checked against the same sums written out step by step."""
+    from t2onet_amd.action_decoder import Decoder
+    from t2onet_amd.decoder_step import DecoderTape
+    torch.manual_seed(1)
+    B, D, E, V, K, S, n = 3, 64, 8, 11, 32, 4, 3
+    dec = Decoder(V, 5, E, D // 2, 2, bidirectional=True, use_attention=True)
+    fc, bn = torch.nn.Linear(K, D), torch.nn.BatchNorm1d(D)
+
+    class Holder:
+        pass
+    model = Holder()
+    model.decoder, model.bn1, model.vis_encoder = dec, bn, Holder()
+    model.vis_encoder.fc = fc
+    tape = DecoderTape(B, D, E, V, K, S, torch.device('cpu'), persistent=True)
+    for name, arr in tape.a.items():
+        arr.copy_(torch.randn(arr.shape))
+    tape.prev_ops.copy_(torch.randint(0, V, tape.prev_ops.shape))
+    params = list(dec.parameters()) + list(fc.parameters()) + list(bn.parameters())
+
+    def run(step_done, step_logp, feat_done):
+        for p in params:
+            p.grad = torch.full_like(p, 0.5)                       # (flush ADDS: a recognisable start value)
+        tape.begin()
+        tape.n_steps = tape.n_feats = n
+        tape.step_done, tape.step_logp, tape.feat_done = set(step_done), set(step_logp), set(feat_done)
+        snap = {k: v.clone() for k, v in tape.a.items()}
+        tape.flush(model)
+        assert tape.n_steps == 0 and tape.n_feats == 0 and not tape.step_done
+        return snap
+
+    snap = run({0, 1, 2}, {0, 2}, {0, 1, 2})
+    A = snap
+
+    def acc(dy, x, steps):
+        return sum(A[dy][s].t() @ A[x][s] for s in steps)
+    rnn, lo = dec.rnn, dec.attention.linear_out
+    all_s = range(n)
+    want = {
+        dec.vis_linear.weight: acc('d_vis', 'featc', all_s), dec.vis_linear.bias: sum(A['d_vis'][s].sum(0) for s in all_s),
+        rnn.weight_ih_l0: acc('d_gates0', 'step_in', all_s), rnn.weight_hh_l0: acc('d_gates0', 'hp0', all_s),
+        rnn.weight_ih_l1: acc('d_gates1', 'h0n', all_s), rnn.weight_hh_l1: acc('d_gates1', 'hp1', all_s),
+        rnn.bias_ih_l0: sum(A['d_gates0'][s].sum(0) for s in all_s), rnn.bias_hh_l1: sum(A['d_gates1'][s].sum(0) for s in all_s),
+        lo.weight: torch.cat([acc('d_lin', 'mix', all_s), acc('d_lin', 'h1n', all_s)], 1), lo.bias: sum(A['d_lin'][s].sum(0) for s in all_s),
+        dec.out_linear.weight: acc('d_logits', 'ctx', (0, 2)), dec.out_linear.bias: sum(A['d_logits'][s].sum(0) for s in (0, 2)),
+        fc.weight: acc('d_fc', 'pooledc', all_s), fc.bias: sum(A['d_fc'][s].sum(0) for s in all_s),
+        bn.weight: A['d_bn'][:n, 0].sum(0), bn.bias: A['d_bn'][:n, 1].sum(0),
+    }
+    emb = torch.zeros_like(dec.embedding.weight)
+    for s in all_s:
+        emb.index_add_(0, tape.prev_ops[s], A['d_step_in'][s][:, :E])
+    want[dec.embedding.weight] = emb
+    for p, w in want.items():
+        np.testing.assert_allclose((p.grad - 0.5).numpy(), w.numpy(), rtol=1e-4, atol=1e-4)
+    # step 1's backward never ran, no step had a gradient through its scores, feature head 2 unused
+    snap = run({0, 2}, set(), {0, 1})
+    A = snap
+    np.testing.assert_allclose((rnn.weight_ih_l0.grad - 0.5).numpy(), acc('d_gates0', 'step_in', (0, 2)).numpy(), rtol=1e-4, atol=1e-4)
+    assert float((dec.out_linear.weight.grad - 0.5).abs().max()) == 0.0
+    np.testing.assert_allclose((fc.weight.grad - 0.5).numpy(), acc('d_fc', 'pooledc', (0, 1)).numpy(), rtol=1e-4, atol=1e-4)
+    assert float(tape.a['d_gates0'][1].abs().max()) == 0.0         # the unused slot was cleared, not summed
