@@ -546,6 +546,26 @@ typedef struct t2o_decoder_step {
 int t2o_decoder_step_fwd(const t2o_decoder_step_t* args, void* stream);
 int t2o_decoder_step_bwd(const t2o_decoder_step_t* args, void* stream);
 
+/* ---- the two batch norms of a shortcut block in one pass each way: models/actor_resnet.py:33-36, 42-44
+ *   out = relu(bn2(x) + bn_s(xs))        x = conv2's output, xs = the 1x1 stride-2 shortcut convolution's output, both (M, C)
+ * Forward (3 launches instead of 5: the normalised shortcut is never stored): `partial` = the main branch's statistics rows
+ * left by its producing convolution (t2o_conv3x3_fwd_stats_nhwc / t2o_wino_output_transform; NULL: a statistics pass is
+ * made here), the shortcut branch's statistics are always made here.  Both batch norms get their batch statistics
+ * (save_*), running statistics and — backward, 3 launches instead of 6: the gated gradient shared by both branches is
+ * never stored — their input gradients dx / dxs and parameter gradients (accumulate != 0: added).  Same arithmetic in the
+ * same order as t2o_bn_relu_nhwc_fwd(relu = 0) followed by t2o_bn_relu_nhwc_fwd_partials(res): bit-identical results. */
+size_t t2o_bn_dual_nhwc_workspace_bytes(int M, int C);
+int t2o_bn_dual_relu_nhwc_fwd(const float* x, const float* partial, int partial_rows, const float* xs,
+                              const float* weight, const float* bias, float* running_mean, float* running_var, float* save_mean,
+                              float* save_invstd, const float* weight_s, const float* bias_s, float* running_mean_s,
+                              float* running_var_s, float* save_mean_s, float* save_invstd_s, float* out, float momentum, float eps,
+                              float momentum_s, float eps_s, void* workspace, size_t workspace_bytes, int M, int C, void* stream);
+int t2o_bn_dual_relu_nhwc_bwd_acc(const float* x, const float* xs, const float* y, const float* dy, const float* weight,
+                                  const float* bias, const float* save_mean, const float* save_invstd, const float* weight_s,
+                                  const float* bias_s, const float* save_mean_s, const float* save_invstd_s, float* dx, float* dxs,
+                                  float* dweight, float* dbias, float* dweight_s, float* dbias_s, int accumulate, void* workspace,
+                                  size_t workspace_bytes, int M, int C, void* stream);
+
 /* Rewrites a captured, not yet instantiated hipGraph (hipGraph_t) in place: every memset node becomes a kernel node
  * doing the same fill, with the same dependencies and dependents; *replaced = how many.  Memset nodes were seen to
  * run out of order with neighbouring kernel nodes on replay (ROCm 7.2 / gfx950): t2onet_amd/graphs.py calls this on

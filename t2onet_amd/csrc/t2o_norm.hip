@@ -351,11 +351,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_stats(BnArgs a, int M, int
 // partial (nblk, 2, C) fp32 -> per-channel fp64 totals in a fixed order, then the channel epilogue.  A workgroup
 // takes 4 channels: thread = (slice s of 64, channel quad), each slice adds the workgroups b = s, s + 64, ...
 // (one 16-byte load per partial row), slices are combined through LDS by the first 4 threads.
+// (stride = floats per partial row, the second quantity at column offset off1: (2C, C) for the plain forms, (3C, C | 2C) for the
+// two batch norms of a shortcut block, which share the first quantity; block = which 4 channels)
 template <bool BWD>
-__global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize(BnArgs a, const float* partial, int nblk) {
+__device__ __forceinline__ void bn_nhwc_finalize_body(const BnArgs& a, const float* partial, int nblk, int stride, int off1, int block) {
   __shared__ double sm[2][kThreads / 64][4];
   const int sl = threadIdx.x >> 2, j = threadIdx.x & 3;
-  const int c = blockIdx.x * 4 + j;
+  const int c = block * 4 + j;
   // the channel epilogue's own operands travel while the partial rows are being added (the kernel is one dependent chain:
   // every microsecond of latency taken out of it is a microsecond of an otherwise idle GPU)
   float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
@@ -373,8 +375,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize(BnArgs a, const f
   // (measured: issuing a slice's 16 row loads 8 at a time made this kernel SLOWER, 8.4 -> 12.5 us -- it is a 16-workgroup
   // launch whose time is the launch itself plus one dependent chain load -> reduce -> coefficient loads -> stores)
   for (int b = sl; b < nblk; b += 64) {
-    s0 += (double)partial[(size_t)b * 2 * a.C + c];
-    s1 += (double)partial[(size_t)b * 2 * a.C + a.C + c];
+    s0 += (double)partial[(size_t)b * stride + c];
+    s1 += (double)partial[(size_t)b * stride + off1 + c];
   }
 #pragma unroll
   for (int o = 4; o < 64; o <<= 1) {                 // the 16 slices of this wave (lane = slice * 4 + channel)
@@ -411,6 +413,21 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize(BnArgs a, const f
       }
     }
   }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize(BnArgs a, const float* partial, int nblk) {
+  bn_nhwc_finalize_body<BWD>(a, partial, nblk, 2 * a.C, a.C, blockIdx.x);
+}
+
+// both batch norms of a shortcut block in ONE launch (2 x C/4 workgroups): the main branch's from (partial0, n0, stride0,
+// off0), the shortcut's from (partial1, n1, stride1, off1)
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize_pair(BnArgs a0, const float* partial0, int n0, int stride0, int off0,
+                                                                    BnArgs a1, const float* partial1, int n1, int stride1, int off1) {
+  const int per = a0.C >> 2;
+  if ((int)blockIdx.x < per) bn_nhwc_finalize_body<BWD>(a0, partial0, n0, stride0, off0, blockIdx.x);
+  else bn_nhwc_finalize_body<BWD>(a1, partial1, n1, stride1, off1, blockIdx.x - per);
 }
 
 template <bool HAS_RES>
@@ -504,6 +521,143 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply(BnArgs a, size_t
       o.w = ac.w * ((g.w - mg.w) - ((xq[k].w - mean.w) * invstd.w) * mgx.w);
       *reinterpret_cast<float4*>(a.out + 4 * i) = o;
       if (HAS_RES && a.dres) *reinterpret_cast<float4*>(a.dres + 4 * i) = g;
+    }
+  }
+}
+
+// ---- the two batch norms of a shortcut block as one pass each way (models/actor_resnet.py:33-36, 42-44) ---------------
+//   out = relu(bn2(y2) + bn_s(ys))           ys = the 1x1 stride-2 shortcut convolution's output
+// Separately that is: apply(bn_s) writes sc, apply(bn2, res = sc) re-reads it; backward: sums / finalize / apply for bn2
+// (writing the gated gradient g for the shortcut), then sums / finalize / apply again for bn_s over the same g.  Both
+// branches see the SAME gated gradient g = dout * [out > 0], so one sums pass yields sum g, sum g xhat2, sum g xhat_s and one
+// apply pass writes both input gradients: 3 launches instead of 5 forward, 3 instead of 6 backward, sc and g never stored.
+// Same arithmetic in the same order as the separate kernels (bit-identical results).
+struct BnDual {
+  const float* xs;         // shortcut branch input (M, C)
+  const float* coef_s;     // forward: (2, C) scale, shift of bn_s;  backward: (3, C) a, mean_g, mean_gxhat of bn_s
+  const float* mean_s;     // backward: batch statistics / parameters of bn_s
+  const float* invstd_s;
+  float* out_s;            // backward: gradient w.r.t. xs
+};
+
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply_dual(BnArgs a, BnDual d, size_t total4) {
+  const int q = a.C >> 2, cq = threadIdx.x % q;
+  const float4 sc = ld4(a.coef + 4 * cq), sh = ld4(a.coef + a.C + 4 * cq);
+  const float4 scs = ld4(d.coef_s + 4 * cq), shs = ld4(d.coef_s + a.C + 4 * cq);
+  const size_t span = (size_t)kThreads * kUnroll, stride = (size_t)gridDim.x * span;
+  for (size_t i0 = (size_t)blockIdx.x * span + threadIdx.x; i0 < total4; i0 += stride) {
+    float4 v[kUnroll], rs[kUnroll];
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      const bool in = i < total4;
+      v[k] = in ? ld4(a.x + 4 * i) : f4(0.0f);
+      rs[k] = in ? ld4(d.xs + 4 * i) : f4(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < kUnroll; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      if (i >= total4) break;
+      const float4 r = make_float4(rs[k].x * scs.x + shs.x, rs[k].y * scs.y + shs.y, rs[k].z * scs.z + shs.z, rs[k].w * scs.w + shs.w);
+      float4 o = make_float4(v[k].x * sc.x + sh.x, v[k].y * sc.y + sh.y, v[k].z * sc.z + sh.z, v[k].w * sc.w + sh.w);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      o.x = fmaxf(o.x, 0.0f); o.y = fmaxf(o.y, 0.0f); o.z = fmaxf(o.z, 0.0f); o.w = fmaxf(o.w, 0.0f);
+      *reinterpret_cast<float4*>(a.out + 4 * i) = o;
+    }
+  }
+}
+
+// three running sums of the workgroup's threads -> one partial row (3, C)
+__device__ __forceinline__ void nhwc_block_store3(float4 s1, float4 s2, float4 s3, int q, float* dst, int C) {
+  __shared__ float4 sm[3][kThreads];
+  sm[0][threadIdx.x] = s1;
+  sm[1][threadIdx.x] = s2;
+  sm[2][threadIdx.x] = s3;
+  __syncthreads();
+  if ((int)threadIdx.x < q) {
+    float4 a = sm[0][threadIdx.x], b = sm[1][threadIdx.x], c = sm[2][threadIdx.x];
+    for (int t = threadIdx.x + q; t < kThreads; t += q) {          // fixed order
+      const float4 u = sm[0][t], v = sm[1][t], w = sm[2][t];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      c.x += w.x; c.y += w.y; c.z += w.z; c.w += w.w;
+    }
+    *reinterpret_cast<float4*>(dst + 4 * threadIdx.x) = a;
+    *reinterpret_cast<float4*>(dst + C + 4 * threadIdx.x) = b;
+    *reinterpret_cast<float4*>(dst + 2 * C + 4 * threadIdx.x) = c;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_sums_dual(BnArgs a, BnDual d, int M, int rows_per_block, float* partial) {
+  constexpr int U = 2;
+  const int q = a.C >> 2, cq = threadIdx.x % q, r = threadIdx.x / q, R = kThreads / q;
+  const int row0 = blockIdx.x * rows_per_block, row1 = min(row0 + rows_per_block, M);
+  const float4 mean = ld4(a.save_mean + 4 * cq), invstd = ld4(a.save_invstd + 4 * cq);
+  const float4 means = ld4(d.mean_s + 4 * cq), invstds = ld4(d.invstd_s + 4 * cq);
+  float4 sg = f4(0.0f), sgx = f4(0.0f), sgs = f4(0.0f);
+  for (int row = row0 + r; row < row1; row += R * U) {
+    float4 xq[U], xsq[U], dq[U], yq[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int rr = row + k * R;
+      const bool in = rr < row1;
+      const size_t off = (size_t)rr * a.C + 4 * cq;
+      xq[k] = in ? ld4(a.x + off) : f4(0.0f);
+      xsq[k] = in ? ld4(d.xs + off) : f4(0.0f);
+      dq[k] = in ? ld4(a.dy + off) : f4(0.0f);
+      yq[k] = in ? ld4(a.y + off) : f4(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const float g0 = yq[k].x > 0.0f ? dq[k].x : 0.0f, g1 = yq[k].y > 0.0f ? dq[k].y : 0.0f;
+      const float g2 = yq[k].z > 0.0f ? dq[k].z : 0.0f, g3 = yq[k].w > 0.0f ? dq[k].w : 0.0f;
+      sg.x += g0; sg.y += g1; sg.z += g2; sg.w += g3;
+      sgx.x += g0 * ((xq[k].x - mean.x) * invstd.x); sgx.y += g1 * ((xq[k].y - mean.y) * invstd.y);
+      sgx.z += g2 * ((xq[k].z - mean.z) * invstd.z); sgx.w += g3 * ((xq[k].w - mean.w) * invstd.w);
+      sgs.x += g0 * ((xsq[k].x - means.x) * invstds.x); sgs.y += g1 * ((xsq[k].y - means.y) * invstds.y);
+      sgs.z += g2 * ((xsq[k].z - means.z) * invstds.z); sgs.w += g3 * ((xsq[k].w - means.w) * invstds.w);
+    }
+  }
+  nhwc_block_store3(sg, sgx, sgs, q, partial + (size_t)blockIdx.x * 3 * a.C, a.C);
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply_dual(BnArgs a, BnDual d, size_t total4) {
+  constexpr int U = 2;
+  const int q = a.C >> 2, cq = threadIdx.x % q;
+  const float4 mean = ld4(a.save_mean + 4 * cq), invstd = ld4(a.save_invstd + 4 * cq);
+  const float4 ac = ld4(a.coef + 4 * cq), mg = ld4(a.coef + a.C + 4 * cq), mgx = ld4(a.coef + 2 * a.C + 4 * cq);
+  const float4 means = ld4(d.mean_s + 4 * cq), invstds = ld4(d.invstd_s + 4 * cq);
+  const float4 acs = ld4(d.coef_s + 4 * cq), mgs = ld4(d.coef_s + a.C + 4 * cq), mgxs = ld4(d.coef_s + 2 * a.C + 4 * cq);
+  const size_t span = (size_t)kThreads * U, stride = (size_t)gridDim.x * span;
+  for (size_t i0 = (size_t)blockIdx.x * span + threadIdx.x; i0 < total4; i0 += stride) {
+    float4 xq[U], xsq[U], dq[U], yq[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      const bool in = i < total4;
+      xq[k] = in ? ld4(a.x + 4 * i) : f4(0.0f);
+      xsq[k] = in ? ld4(d.xs + 4 * i) : f4(0.0f);
+      dq[k] = in ? ld4(a.dy + 4 * i) : f4(0.0f);
+      yq[k] = in ? ld4(a.y + 4 * i) : f4(0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const size_t i = i0 + (size_t)k * kThreads;
+      if (i >= total4) break;
+      float4 g;
+      g.x = yq[k].x > 0.0f ? dq[k].x : 0.0f; g.y = yq[k].y > 0.0f ? dq[k].y : 0.0f;
+      g.z = yq[k].z > 0.0f ? dq[k].z : 0.0f; g.w = yq[k].w > 0.0f ? dq[k].w : 0.0f;
+      float4 o, os;
+      o.x = ac.x * ((g.x - mg.x) - ((xq[k].x - mean.x) * invstd.x) * mgx.x);
+      o.y = ac.y * ((g.y - mg.y) - ((xq[k].y - mean.y) * invstd.y) * mgx.y);
+      o.z = ac.z * ((g.z - mg.z) - ((xq[k].z - mean.z) * invstd.z) * mgx.z);
+      o.w = ac.w * ((g.w - mg.w) - ((xq[k].w - mean.w) * invstd.w) * mgx.w);
+      os.x = acs.x * ((g.x - mgs.x) - ((xsq[k].x - means.x) * invstds.x) * mgxs.x);
+      os.y = acs.y * ((g.y - mgs.y) - ((xsq[k].y - means.y) * invstds.y) * mgxs.y);
+      os.z = acs.z * ((g.z - mgs.z) - ((xsq[k].z - means.z) * invstds.z) * mgxs.z);
+      os.w = acs.w * ((g.w - mgs.w) - ((xsq[k].w - means.w) * invstds.w) * mgxs.w);
+      *reinterpret_cast<float4*>(a.out + 4 * i) = o;
+      *reinterpret_cast<float4*>(d.out_s + 4 * i) = os;
     }
   }
 }
@@ -691,6 +845,83 @@ int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const 
                          void* stream) {
   return t2o_bn_relu_nhwc_bwd_acc(x, y, dy, weight, bias, save_mean, save_invstd, dx, dres, dweight, dbias, has_res, relu, 0,
                                   workspace, workspace_bytes, M, C, stream);
+}
+
+size_t t2o_bn_dual_nhwc_workspace_bytes(int M, int C) {
+  (void)M;
+  // [coef main (4, C)][coef shortcut (4, C)][partials: shortcut statistics (2, C) rows | backward (3, C) rows]
+  return sizeof(float) * 8 * (size_t)C + sizeof(float) * 3 * (size_t)C * kNhwcMaxBlocks + sizeof(float) * 2 * (size_t)C * kNhwcMaxBlocks;
+}
+
+int t2o_bn_dual_relu_nhwc_fwd(const float* x, const float* partial, int partial_rows, const float* xs,
+                              const float* weight, const float* bias, float* running_mean, float* running_var, float* save_mean,
+                              float* save_invstd, const float* weight_s, const float* bias_s, float* running_mean_s,
+                              float* running_var_s, float* save_mean_s, float* save_invstd_s, float* out, float momentum, float eps,
+                              float momentum_s, float eps_s, void* workspace, size_t workspace_bytes, int M, int C, void* stream) {
+  if (!x || !xs || M <= 0 || !nhwc_channels_ok(C) || !weight || !bias || !weight_s || !bias_s || !save_mean || !save_invstd || !save_mean_s ||
+      !save_invstd_s || !out)
+    return set_error(T2O_EINVAL, "bn_dual_relu_nhwc_fwd: null pointer or bad shape (C must be a power of two in [4, 1024])");
+  if ((running_mean == nullptr) != (running_var == nullptr) || (running_mean_s == nullptr) != (running_var_s == nullptr))
+    return set_error(T2O_EINVAL, "bn_dual_relu_nhwc_fwd: running_mean and running_var must both be given or both be null");
+  if (partial && partial_rows <= 0) return set_error(T2O_EINVAL, "bn_dual_relu_nhwc_fwd: partial_rows");
+  if (!workspace || workspace_bytes < t2o_bn_dual_nhwc_workspace_bytes(M, C)) return set_error(T2O_EWORKSPACE, "bn_dual_relu_nhwc_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* coef0 = (float*)workspace;
+  float* coef1 = coef0 + 4 * (size_t)C;
+  float* part_s = coef1 + 4 * (size_t)C;                        // (rows, 2, C) statistics of the shortcut branch
+  float* part_m = part_s + 2 * (size_t)C * kNhwcMaxBlocks;      // (rows, 2, C) of the main branch when its producer left none
+  BnArgs a = {}, b = {};
+  a.x = x; a.out = out; a.weight = weight; a.bias = bias; a.running_mean = running_mean; a.running_var = running_var;
+  a.save_mean = save_mean; a.save_invstd = save_invstd; a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.eps = eps; a.momentum = momentum;
+  a.relu = 1; a.coef = coef0;
+  b.x = xs; b.weight = weight_s; b.bias = bias_s; b.running_mean = running_mean_s; b.running_var = running_var_s;
+  b.save_mean = save_mean_s; b.save_invstd = save_invstd_s; b.N = M; b.C = C; b.HW = 1; b.splits = 1; b.eps = eps_s; b.momentum = momentum_s;
+  b.relu = 0; b.coef = coef1;
+  int rpb, nblk;
+  nhwc_partition(M, C, kUnroll, &rpb, &nblk);
+  k_bn_nhwc_stats<<<nblk, kThreads, 0, st>>>(b, M, rpb, part_s);
+  if (!partial) {
+    k_bn_nhwc_stats<<<nblk, kThreads, 0, st>>>(a, M, rpb, part_m);
+    partial = part_m;
+    partial_rows = nblk;
+  }
+  k_bn_nhwc_finalize_pair<false><<<2 * (C / 4), kThreads, 0, st>>>(a, partial, partial_rows, 2 * C, C, b, part_s, nblk, 2 * C, C);
+  BnDual d = {};
+  d.xs = xs; d.coef_s = coef1;
+  const size_t total4 = (size_t)M * (C >> 2);
+  k_bn_nhwc_apply_dual<<<flat_grid(total4, 1, kUnroll), kThreads, 0, st>>>(a, d, total4);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
+}
+
+int t2o_bn_dual_relu_nhwc_bwd_acc(const float* x, const float* xs, const float* y, const float* dy, const float* weight,
+                                  const float* bias, const float* save_mean, const float* save_invstd, const float* weight_s,
+                                  const float* bias_s, const float* save_mean_s, const float* save_invstd_s, float* dx, float* dxs,
+                                  float* dweight, float* dbias, float* dweight_s, float* dbias_s, int accumulate, void* workspace,
+                                  size_t workspace_bytes, int M, int C, void* stream) {
+  if (!x || !xs || !y || !dy || M <= 0 || !nhwc_channels_ok(C) || !weight || !bias || !weight_s || !bias_s || !save_mean || !save_invstd ||
+      !save_mean_s || !save_invstd_s || !dx || !dxs)
+    return set_error(T2O_EINVAL, "bn_dual_relu_nhwc_bwd: null pointer or bad shape (C must be a power of two in [4, 1024])");
+  if (!workspace || workspace_bytes < t2o_bn_dual_nhwc_workspace_bytes(M, C)) return set_error(T2O_EWORKSPACE, "bn_dual_relu_nhwc_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* coef0 = (float*)workspace;
+  float* coef1 = coef0 + 4 * (size_t)C;
+  float* partial = coef1 + 4 * (size_t)C;                       // (rows, 3, C)
+  BnArgs a = {}, b = {};
+  a.x = x; a.y = y; a.dy = dy; a.out = dx; a.weight = weight; a.bias = bias;
+  a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
+  a.dweight = dweight; a.dbias = dbias; a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.relu = 1; a.acc = accumulate ? 1 : 0; a.coef = coef0;
+  b.x = xs; b.weight = weight_s; b.bias = bias_s;
+  b.save_mean = const_cast<float*>(save_mean_s); b.save_invstd = const_cast<float*>(save_invstd_s);
+  b.dweight = dweight_s; b.dbias = dbias_s; b.N = M; b.C = C; b.HW = 1; b.splits = 1; b.relu = 0; b.acc = accumulate ? 1 : 0; b.coef = coef1;
+  BnDual d = {};
+  d.xs = xs; d.coef_s = coef1; d.mean_s = save_mean_s; d.invstd_s = save_invstd_s; d.out_s = dxs;
+  int rpb, nblk;
+  nhwc_partition(M, C, 2, &rpb, &nblk);
+  k_bn_nhwc_bwd_sums_dual<<<nblk, kThreads, 0, st>>>(a, d, M, rpb, partial);
+  k_bn_nhwc_finalize_pair<true><<<2 * (C / 4), kThreads, 0, st>>>(a, partial, nblk, 3 * C, C, b, partial, nblk, 3 * C, 2 * C);
+  const size_t total4 = (size_t)M * (C >> 2);
+  k_bn_nhwc_bwd_apply_dual<<<flat_grid(total4, 1, 2), kThreads, 0, st>>>(a, d, total4);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
 }  // extern "C"

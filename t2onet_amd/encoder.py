@@ -30,6 +30,7 @@ from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_works
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
 _WINO_MIN_C = int(os.environ.get('T2O_WINOGRAD_MIN_C', '256'))
+_DUAL_BN = True      # a shortcut block's two batch norms in one pass each way (t2o_bn_dual_*); module switch for the tests
 
 
 def _fast_direct(stride, Hi, Wi, Wo):
@@ -399,19 +400,34 @@ class _TrunkFn(torch.autograd.Function):
             a1 = act_like(y1, (bi, 'a1'))
             m1, i1 = _bn_fwd(lib, st, bn_ws, b.bn1, y1, a1, None, 1, s1, M, Co)
             rec = {'x': x, 'y1': y1, 'm1': m1, 'i1': i1, 'a1': a1, 'H': Hc, 'W': Wc}
+            dual = bool(len(b.shortcut)) and _DUAL_BN
             if len(b.shortcut):
                 sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
                 ys = _nhwc(N, Hn, Wn, Co, dev)
                 rc = lib.t2o_conv1x1s2_fwd_nhwc(_ptr(x), _ptr(sc_conv.weight), _ptr(ys), N, Hc, Wc, sc_conv.weight.shape[1], Co, st)
                 _lib.check(rc, 't2o_conv1x1s2_fwd_nhwc')
-                sc = torch.empty_like(ys)
-                ms, is_ = _bn_fwd(lib, st, bn_ws, sc_bn, ys, sc, None, 0, None, M, Co)
-                rec.update(ys=ys, ms=ms, is_=is_)
+                if not dual:
+                    sc = torch.empty_like(ys)
+                    ms, is_ = _bn_fwd(lib, st, bn_ws, sc_bn, ys, sc, None, 0, None, M, Co)
+                    rec.update(ys=ys, ms=ms, is_=is_)
             else:
                 sc = x
             y2, s2 = conv3(a1, b.conv2, N, Hn, Wn, True)
             out = act_like(y2, (bi, 'out'))
-            m2, i2 = _bn_fwd(lib, st, bn_ws, b.bn2, y2, out, sc, 1, s2, M, Co)
+            if dual:
+                # out = relu(bn2(y2) + bn_s(ys)) in one pass: the normalised shortcut is never stored
+                m2, i2, ms, is_ = (torch.empty(Co, dtype=torch.float32, device=dev) for _ in range(4))
+                need = lib.t2o_bn_dual_nhwc_workspace_bytes(M, Co)
+                dws = torch.empty(need, dtype=torch.uint8, device=dev)
+                rc = lib.t2o_bn_dual_relu_nhwc_fwd(_ptr(y2), _ptr(s2), 0 if s2 is None else s2.shape[0], _ptr(ys),
+                                                   _ptr(b.bn2.weight), _ptr(b.bn2.bias), _ptr(b.bn2.running_mean), _ptr(b.bn2.running_var),
+                                                   _ptr(m2), _ptr(i2), _ptr(sc_bn.weight), _ptr(sc_bn.bias), _ptr(sc_bn.running_mean),
+                                                   _ptr(sc_bn.running_var), _ptr(ms), _ptr(is_), _ptr(out), float(b.bn2.momentum),
+                                                   float(b.bn2.eps), float(sc_bn.momentum), float(sc_bn.eps), _ptr(dws), need, M, Co, st)
+                _lib.check(rc, 't2o_bn_dual_relu_nhwc_fwd')
+                rec.update(ys=ys, ms=ms, is_=is_, dual=True)
+            else:
+                m2, i2 = _bn_fwd(lib, st, bn_ws, b.bn2, y2, out, sc, 1, s2, M, Co)
             rec.update(y2=y2, m2=m2, i2=i2, out=out)
             saved.append(rec)
             x, Hc, Wc = out, Hn, Wn
@@ -523,7 +539,24 @@ class _TrunkFn(torch.autograd.Function):
             M = N * Hn * Wn
             # out = relu(bn2(y2) + sc)
             slot2 = deferred(b.conv2)
-            dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co, slot2)
+            dys = None
+            if rec.get('dual'):
+                # both batch norms of the shortcut block from one pass over the gated gradient (never stored)
+                sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
+                slots = deferred(sc_conv)
+                dy2 = slot2 if slot2 is not None else torch.empty_like(rec['y2'])
+                dys = slots if slots is not None else torch.empty_like(rec['ys'])
+                need = lib.t2o_bn_dual_nhwc_workspace_bytes(M, Co)
+                dws = torch.empty(need, dtype=torch.uint8, device=dev)
+                rc = lib.t2o_bn_dual_relu_nhwc_bwd_acc(_ptr(rec['y2']), _ptr(rec['ys']), _ptr(rec['out']), _ptr(d), _ptr(b.bn2.weight),
+                                                       _ptr(b.bn2.bias), _ptr(rec['m2']), _ptr(rec['i2']), _ptr(sc_bn.weight), _ptr(sc_bn.bias),
+                                                       _ptr(rec['ms']), _ptr(rec['is_']), _ptr(dy2), _ptr(dys), _ptr(g(b.bn2.weight)),
+                                                       _ptr(g(b.bn2.bias)), _ptr(g(sc_bn.weight)), _ptr(g(sc_bn.bias)), acc, _ptr(dws), need,
+                                                       M, Co, st)
+                _lib.check(rc, 't2o_bn_dual_relu_nhwc_bwd_acc')
+                dsc = None
+            else:
+                dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co, slot2)
             da1 = torch.empty_like(rec['a1'])
             if plan.wino(b.conv2, Hn, Wn):
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
@@ -545,8 +578,9 @@ class _TrunkFn(torch.autograd.Function):
                 wgrad3(b.conv1, rec['x'], dy1, Hc, Wc, Hn, Wn)
             if len(b.shortcut):
                 sc_conv, sc_bn = b.shortcut[0], b.shortcut[1]
-                slots = deferred(sc_conv)
-                dys, _ = bn_bwd(sc_bn, rec['ys'], None, dsc, rec['ms'], rec['is_'], 0, 0, False, M, Co, slots)
+                if dys is None:
+                    slots = deferred(sc_conv)
+                    dys, _ = bn_bwd(sc_bn, rec['ys'], None, dsc, rec['ms'], rec['is_'], 0, 0, False, M, Co, slots)
                 if slots is None:
                     need = lib.t2o_conv1x1s2_wgrad_workspace_bytes(N, Hc, Wc, Ci, Co)
                     ws = torch.empty(need, dtype=torch.uint8, device=dev)

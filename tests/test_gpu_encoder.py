@@ -291,3 +291,25 @@ def test_weight_gradients_once_per_step_equal_per_pass_gradients(size, spare):
     ((ref(imgs[0].clone().requires_grad_(True)) * gouts[0]).sum() + (ref(imgs[2].clone().requires_grad_(True)) * gouts[2]).sum()).backward()
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         _close(p.grad, q.grad, 2e-5)
+
+
+@pytest.mark.parametrize('size', [(64, 256), (96, 160)])
+def test_dual_batch_norm_of_shortcut_blocks_is_bit_identical_to_the_separate_passes(monkeypatch, size):
+    """t2o_bn_dual_relu_nhwc_fwd / _bwd_acc (out = relu(bn2(y2) + bn_s(ys)) and both backward passes from one sweep over the
+    gated gradient) against the separate kernels they replace: same arithmetic in the same order, so outputs, running
+    statistics, image gradient and every parameter gradient must be bit-identical."""
+    import t2onet_amd.encoder as E
+    N, (H, W) = 3, size
+    img = synth.images(N, H, W, 71).to(DEV)
+    gout = synth.uniform((N, 512), 72, -1.0, 1.0).to(DEV)
+    res = {}
+    for dual in (True, False):
+        monkeypatch.setattr(E, '_DUAL_BN', dual)
+        net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+        out, dimg, g = _run(net, img, gout)
+        res[dual] = (out, dimg, g, {n: b.clone() for n, b in net.named_buffers()})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for n in res[True][2]:
+        assert torch.equal(res[True][2][n], res[False][2][n]), n
+    for n in res[True][3]:
+        assert torch.equal(res[True][3][n], res[False][3][n]), n
