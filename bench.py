@@ -262,6 +262,36 @@ class FusedRunner(SequenceRunner):
             self._p(self.gimg), self._p(self.gparams), None, None, self._p(self.ws), wsn, B, H, W, st))
 
 
+class ValueGradRunner(FusedRunner):
+    """Same workload, same outputs (loss, image gradient, parameter gradients) through ONE call,
+    t2o_fused_sequence_l1_value_grad: the last segment's forward is not launched -- the sharpness backward forms the
+    final pixel anyway and also emits the loss.  3 launches per step instead of 4 (tests/test_gpu_operators.py:
+    gradients bit-identical to the two-call path)."""
+
+    def step(self):
+        st, B, H, W = self._stream(), self.B, self.H, self.W
+        rc = self.lib.t2o_fused_sequence_l1_value_grad(
+            self.c_ops, self.K, self._p(self.img), self._p(self.params), self._p(self.tgt), self._p(self.gloss), None,
+            self._p(self.loss), self._p(self.gimg), self._p(self.gparams), self._p(self.seg), self._p(self.gbuf),
+            self._p(self.ws), self.ws.numel(), B, H, W, st)
+        self.check(rc, 't2o_fused_sequence_l1_value_grad')
+
+    def profiled_step(self, rec):
+        st, B, H, W, nc = self._stream(), self.B, self.H, self.W, self.nc
+        wsn = self.ws.numel()
+        mid, p6, gp6 = self.seg[0], self.params[nc], self.gparams[nc]
+        c6 = (ctypes.c_int * 1)(6)
+        self._timed(rec, 'fwd_chain%d' % nc, lambda: self.lib.t2o_fused_sequence_fwd(
+            self.c_chain, nc, self._p(self.img), self._p(self.params), None, self._p(mid), None, None,
+            self._p(self.ws), wsn, B, H, W, st))
+        self._timed(rec, 'bwd_sharpness+l1+loss', lambda: self.lib.t2o_fused_sequence_l1_value_grad(
+            c6, 1, self._p(mid), self._p(p6), self._p(self.tgt), self._p(self.gloss), None, self._p(self.loss),
+            self._p(self.gbuf[0]), self._p(gp6), None, None, self._p(self.ws), wsn, B, H, W, st))
+        self._timed(rec, 'bwd_chain%d' % nc, lambda: self.lib.t2o_fused_sequence_bwd(
+            self.c_chain, nc, self._p(self.img), self._p(self.params), None, None, self._p(self.gbuf[0]),
+            self._p(self.gimg), self._p(self.gparams), None, None, self._p(self.ws), wsn, B, H, W, st))
+
+
 def _chain_len(name):
     i = name.find('chain')
     return int(name[i + 5:]) if i >= 0 else 1
@@ -371,10 +401,16 @@ def executor_leg(ctx, ops, B, H, W, steps, warmup, with_api=False):
     fus['compile_time_specialised'] = bool(fused_runner.specialised)
     del fused_runner
     torch.cuda.empty_cache()
+    vg_runner = ValueGradRunner(ops, B, H, W, device)
+    vg = summary(*measure(vg_runner))
+    del vg_runner
+    torch.cuda.empty_cache()
     res = {'workload': 'bs=%d/GPU %dx%d fp32, executor ops %s forward + L1 + backward to all parameters and the image'
                        % (B, H, W, list(ops)),
            'steps': steps, 'warmup': warmup, 'algorithmic_GB_per_step': round(total_bytes / 1e9, 4),
-           'fused': fus, 'materialised': mat}
+           'fused': fus, 'value_grad': vg, 'materialised': mat}
+    res['value_grad']['what'] = ('t2o_fused_sequence_l1_value_grad: loss + all gradients in one call, no forward launch for the '
+                                 'last segment (its backward also emits the loss): 3 launches instead of 4, same gradients bit for bit')
     res['fused']['what'] = ('t2o_fused_sequence_fwd/bwd: per-pixel operators fused in registers, sharpness+L1 stencil '
                             'kernels; frac_of_peak uses the materialised algorithmic bytes (SURVEY 8(d)), i.e. it '
                             'includes fusion credit')

@@ -135,6 +135,21 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
                            float* gimg, float* gparams, const float* seg_bufs, float* gbuf,
                            void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 
+/* value AND gradient of loss = mean|sequence(img) - target| in one call (what one train iteration of the planner's and
+ * the L1 trainer's inner loop needs: Executor.execute K times, executors/executor.py:33-55, then L1Loss + backward,
+ * experiments/t2onet/train_seq2seqL1.py:82-86, utils/beam_search.py:65-91).  The forward of the LAST segment is not
+ * launched: its backward kernels recompute the final pixel anyway (for sign(out - target)) and also emit |out - target|
+ * partials and, when out != NULL, the final image.  BASELINE configs[1] (5 per-pixel operators + sharpness): 3 launches
+ * instead of 4; a list without sharpness: ONE launch.  gimg, gparams and out are bit-identical to
+ * t2o_fused_sequence_fwd(target) + t2o_fused_sequence_bwd(target, gloss) (the same kernels in the same geometry); loss
+ * is the same sum in another order (partials per backward workgroup), equal to ~1e-7 relative.  out may be NULL;
+ * seg_bufs / gbuf as for the two-call form.  Image sizes whose sharpness runs on the LDS-tile kernels (W % 4 != 0 ...)
+ * fall back to the two calls internally (then out is required when the list is a single sharpness segment). */
+int t2o_fused_sequence_l1_value_grad(const int* ops, int K, const float* img, const float* params,
+                                     const float* target, const float* gloss, float* out, float* loss,
+                                     float* gimg, float* gparams, float* seg_bufs, float* gbuf,
+                                     void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+
 /* ---- run-time specialisation of the fused chain kernels for an arbitrary operator list (t2o_jit.hip).
  * The fastest kernels behind t2o_fused_sequence_fwd/bwd take the operator list as a compile-time constant; ahead of time
  * only BASELINE.json's two lists are instantiated.  t2o_fused_sequence_prepare(ops, K) compiles (hipRTC, from the headers

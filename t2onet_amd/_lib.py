@@ -39,6 +39,7 @@ SIGNATURES = {
     't2o_fused_sequence_buffers': (_I, [_P, _I]),
     't2o_fused_sequence_fwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     't2o_fused_sequence_bwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
+    't2o_fused_sequence_l1_value_grad': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     't2o_candidates_workspace_bytes': (_Z, [_I, _I, _I]),
     't2o_op_candidates_l1': (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P]),
     't2o_candidates_multi_workspace_bytes': (_Z, [_I, _I, _I, _I]),

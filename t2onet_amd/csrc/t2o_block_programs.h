@@ -742,14 +742,18 @@ T2O_HD float chain_fwd_thread(const ChainArgs& a, int b, int blk, int tid, const
 template <int V>
 T2O_HD int chain_save_floats(int K) { return K * 3 * V * kThreads; }
 
+// Returns (L1 forms) the thread's sum of |chain(img) - target| over its live pixels: the "value" of a value-and-gradient
+// call -- the backward recomputes the forward anyway, so the loss (and, when a.out is set, the final image) costs no
+// separate forward launch (t2o_fused_sequence_l1_value_grad).
 template <int V, bool L1, class ACC>
-T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* sv, ACC& acc) {
+T2O_HD float chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* sv, ACC& acc) {
   const unsigned hw = (unsigned)a.H * (unsigned)a.W;
   const unsigned groups = hw / V;
   const size_t sb = (size_t)b * 3 * hw;
   const float* xin = a.img + sb;
   const float* gin = (L1 ? a.target : a.gout) + sb;
   const float gs = L1 ? a.gloss[0] * a.inv_n : 0.0f;
+  float l1 = 0.0f;
   for (int it = 0; it < a.iters; ++it) {
     const unsigned g = ((unsigned)blk * a.iters + it) * kThreads + tid;
     const bool live = g < groups;                 // dead threads still take part in the quad reductions
@@ -782,11 +786,19 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
         }
       }
     }
+    if (a.out && live) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) store_vec<V>(a.out + sb + c * hw + px, x[c]);
+    }
     if (L1) {
       T2O_UNROLL
       for (int c = 0; c < 3; ++c) {
         T2O_UNROLL
-        for (int i = 0; i < V; ++i) gg[c][i] = sign_of(x[c][i] - gg[c][i]) * gs;
+        for (int i = 0; i < V; ++i) {
+          const float d = x[c][i] - gg[c][i];
+          if (live) l1 += fabsf(d);
+          gg[c][i] = sign_of(d) * gs;
+        }
       }
     }
     if (!live) {
@@ -839,6 +851,7 @@ T2O_HD void chain_bwd_thread(const ChainArgs& a, int b, int blk, int tid, const 
       for (int c = 0; c < 3; ++c) store_vec<V>(a.gimg + sb + c * hw + px, gg[c]);
     }
   }
+  return l1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -899,8 +912,9 @@ T2O_HD float chain_fwd_thread_static(const ChainArgs& a, int b, int blk, int tid
 }
 
 template <bool L1, class SEQ, bool SV_LDS, class ACC>
-T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* svl, ACC& acc) {
+T2O_HD float chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* svl, ACC& acc) {
   constexpr int K = SEQ::K;
+  float l1 = 0.0f;                                   // (L1 forms: sum |chain(img) - target| of the live pixels, see chain_bwd_thread)
   const unsigned hw = (unsigned)a.H * (unsigned)a.W;
   const size_t sb = (size_t)b * 3 * hw;
   const float* xin = a.img + sb;
@@ -947,9 +961,17 @@ T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid,
         pass[k][c] = x[c] == r.c[c];                   // == (0 <= r && r <= 1), NaN included: one compare on the clamped value
       }
     }
+    if (a.out && live) {
+      T2O_UNROLL
+      for (int c = 0; c < 3; ++c) a.out[sb + c * hw + px] = x[c];
+    }
     T2O_UNROLL
     for (int c = 0; c < 3; ++c) {
-      if (L1) gg[c] = sign_of(x[c] - gg[c]) * gs;
+      if (L1) {
+        const float d = x[c] - gg[c];
+        if (live) l1 += fabsf(d);
+        gg[c] = sign_of(d) * gs;
+      }
       if (!live) gg[c] = 0.0f;
     }
     T2O_UNROLL
@@ -985,6 +1007,7 @@ T2O_HD void chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid,
     else if (op == OP_TONE) { float (&r)[8] = reinterpret_cast<float (&)[8]>(red[k]); acc.template add_n<8>(a.bin_off[k], r); }
     else if (op != OP_WHITE) { float (&r)[1] = reinterpret_cast<float (&)[1]>(red[k]); acc.template add_n<1>(a.bin_off[k], r); }
   }
+  return l1;
 }
 
 // ===================================================================== SSIM (evaluation metric)

@@ -127,7 +127,8 @@ __device__ __forceinline__ void chain_bwd_static_body(const ChainArgs& a) {
   if ((int)threadIdx.x < SEQ::K) chain_build_table(a, b, threadIdx.x, tab);
   __syncthreads();
   LdsAcc acc{lds};
-  chain_bwd_thread_static<L1, SEQ, SV_LDS>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
+  const float l1 = chain_bwd_thread_static<L1, SEQ, SV_LDS>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
+  if (L1 && a.loss_partials) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk);   // value-and-gradient calls
   __syncthreads();
   for (int s = threadIdx.x; s < NB; s += kThreads) {
     float sum = 0.0f;

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
   const float p = a.param[(size_t)b * a.param_stride];
   const float gs = a.target ? a.gloss[0] * a.inv_n : 0.0f;
   float red0 = 0.0f;
+  float l1 = 0.0f;                  // L1 form: sum |out - target| over this thread's output pixels (value-and-gradient calls)
 #pragma unroll 1
   for (int c = 0; c < 3; ++c) {
     const float* xp = a.img + ((size_t)b * 3 + c) * hw;
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
       const bool in = col_live && y >= 0 && y < a.H;
       const float* ce = xr[k + 1];
       const float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
+      const bool mine = k >= 1 && k <= kStripRows && own && in;        // an output pixel of this thread
+      float oz[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
@@ -244,12 +247,15 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
         const float m = MASKED ? mk[k][i] : 1.0f;
         float z = ce[i] + p * d;
         if (MASKED) z = blend(z, ce[i], m);
-        const float gz = a.target ? sign_of(clamp01(z) - g[k][i]) * gs : g[k][i];
+        oz[i] = clamp01(z);
+        if (a.target && mine) l1 += fabsf(oz[i] - g[k][i]);
+        const float gz = a.target ? sign_of(oz[i] - g[k][i]) * gs : g[k][i];
         const float dz = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
         g[k][i] = MASKED ? dz * m : dz;                                   // do
         if (MASKED && k >= 1 && k <= kStripRows) pass[k - 1][i] = dz * (1.0f - m);
         if (k >= 1 && k <= kStripRows && own) red0 += dz * m * d;
       }
+      if (a.out && mine) store_vec<4>(a.out + ((size_t)b * 3 + c) * hw + (unsigned)y * (unsigned)a.W + (unsigned)gx0, oz);
     }
     // gimg rows y0 .. y0+kStripRows-1
 #pragma unroll
@@ -269,6 +275,10 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
     }
   }
   block_reduce_store1(red0, a.partials + ((size_t)b * a.nblk_max + blk) * kRedSlots);
+  if (a.target && a.loss_partials) {
+    __syncthreads();                                           // (block_reduce_store1's staging cells are reused)
+    block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk_max + blk);
+  }
 }
 
 template <bool DYN, int V>
@@ -312,7 +322,8 @@ __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
   if ((int)threadIdx.x < a.K) chain_build_table(a, b, threadIdx.x, tab);
   __syncthreads();
   LdsAcc acc{lds};
-  chain_bwd_thread<V, L1>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
+  const float l1 = chain_bwd_thread<V, L1>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
+  if (L1 && a.loss_partials) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk);   // value-and-gradient calls
   __syncthreads();
   for (int s = threadIdx.x; s < NB; s += kThreads) {            // cell rows -> per-workgroup sums, fixed order
     float sum = 0.0f;
@@ -1078,7 +1089,9 @@ int run_fwd(int op, const int* op_id, const float* img, const float* param, int 
 int run_bwd(int op, const int* op_id, const float* img, const float* param, int param_stride, const float* mask,
             int mask_ch, const float* gout, const float* target, const float* gloss, float* gimg, float* gparam,
             int gparam_stride, void* ws, size_t ws_bytes, int B, int H, int W, void* stream,
-            float* partials_region = nullptr, int* nblk_out = nullptr) {
+            float* partials_region = nullptr, int* nblk_out = nullptr, float* value_out = nullptr, float* value_loss = nullptr) {
+  // value_loss (sharpness + L1 target on the strip kernels only): the backward also leaves the loss -- and the operator's
+  // output image in value_out when that is given -- so a value-and-gradient call needs no forward launch for this operator
   if (int rc = check_common(op, op_id, img, param, param_stride, mask, mask_ch, B, H, W)) return rc;
   if (!target && !gout) return fail(T2O_EINVAL, "gout is null");
   if (target && !gloss) return fail(T2O_EINVAL, "gloss is null");
@@ -1105,6 +1118,11 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   a.iters = g.iters; a.nblk_max = g.nblk_max;
   a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
   hipStream_t st = (hipStream_t)stream;
+  if (value_loss) {
+    if (op != OP_SHARPNESS || !target || !sharp_bwd_uses_strips(a, g)) return fail(T2O_EUNSUPPORTED, "value-and-gradient: sharpness on the strip kernels only");
+    a.out = value_out;
+    a.loss_partials = (float*)ws + ws_partials_floats(g, B, H, W);
+  }
   if (partials_region) {                        // the caller finalises every operator of the sequence at once
     if (op != OP_SHARPNESS) launch_point_bwd(a, g, st);
     else launch_sharp_bwd(a, g, st);
@@ -1115,6 +1133,7 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   if (op == OP_SHARPNESS || op == OP_DYNAMIC) launch_sharp_bwd(a, g, st);
   if (gparam && op != OP_IDENTITY)
     k_finalize_params<<<B, kThreads, 0, st>>>(a, gparam, gparam_stride, g.nblk_point, sharp_bwd_blocks(a, g));
+  if (value_loss) k_finalize_loss<<<1, kThreads, 0, st>>>(a, value_loss, g.nblk_point, sharp_bwd_blocks(a, g));
   return check_launch("operator backward");
 }
 
@@ -1460,9 +1479,12 @@ int t2o_fused_sequence_fwd(const int* ops, int K, const float* img, const float*
   return check_launch("fused sequence forward");
 }
 
-int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float* params, const float* target,
-                           const float* gloss, const float* gout, float* gimg, float* gparams, const float* seg_bufs,
-                           float* gbuf, void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+// value_loss != null: the LAST segment's backward also leaves the loss (and the final image in value_out when given): the
+// caller ran the forward of every segment but the last (t2o_fused_sequence_l1_value_grad)
+static int fused_sequence_bwd_impl(const int* ops, int K, const float* img, const float* params, const float* target,
+                                   const float* gloss, const float* gout, float* gimg, float* gparams, const float* seg_bufs,
+                                   float* gbuf, void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream,
+                                   float* value_out, float* value_loss) {
   if (!ops || K < 0 || !img || (K > 0 && (!params || !gparams)))
     return fail(T2O_EINVAL, "fused_sequence_bwd: null pointer");
   if (target ? !gloss : !gout) return fail(T2O_EINVAL, "fused_sequence_bwd: give (target, gloss) or gout");
@@ -1491,11 +1513,13 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
     float* gnext = s == 0 ? gimg : gbuf + (size_t)(s & 1) * img_floats;
     const bool last = (s == ns - 1) && target;     // fused L1: the last segment reads the target instead of a gradient
     if (s == ns - 1 && !target) gcur = gout;
+    const bool value = last && value_loss != nullptr;
     if (seg[s].sharp) {
       const int k = seg[s].first;
       const int rc = run_bwd(OP_SHARPNESS, nullptr, in, params + (size_t)k * B * kMaxParam, kMaxParam, nullptr, 0,
                              last ? nullptr : gcur, last ? target : nullptr, last ? gloss : nullptr, gnext,
-                             gparams + (size_t)k * B * kMaxParam, kMaxParam, workspace, workspace_bytes, B, H, W, stream);
+                             gparams + (size_t)k * B * kMaxParam, kMaxParam, workspace, workspace_bytes, B, H, W, stream,
+                             nullptr, nullptr, value ? value_out : nullptr, value ? value_loss : nullptr);
       if (rc) return rc;
     } else {
       ChainArgs a;
@@ -1510,12 +1534,62 @@ int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float*
       }
       a.img = in; a.params = params; a.gimg = gnext; a.partials = (float*)workspace;
       if (last) { a.target = target; a.gloss = gloss; } else { a.gout = gcur; }
+      if (value) {
+        const Geometry gg = launch_geometry(B, H, W);
+        a.out = value_out;
+        a.loss_partials = (float*)workspace + ws_partials_floats(gg, B, H, W);
+      }
       fused_chain_launch_bwd(a, vec, last, st);
       if (a.K > 0) k_chain_finalize<<<B, kThreads, 0, st>>>(a, gparams);
+      if (value) k_l1_finalize<<<1, kThreads, 0, st>>>(a.loss_partials, B * a.nblk, a.inv_n, value_loss);
     }
     gcur = gnext;
   }
   return check_launch("fused sequence backward");
+}
+
+int t2o_fused_sequence_bwd(const int* ops, int K, const float* img, const float* params, const float* target,
+                           const float* gloss, const float* gout, float* gimg, float* gparams, const float* seg_bufs,
+                           float* gbuf, void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  return fused_sequence_bwd_impl(ops, K, img, params, target, gloss, gout, gimg, gparams, seg_bufs, gbuf, workspace, workspace_bytes,
+                                 B, H, W, stream, nullptr, nullptr);
+}
+
+int t2o_fused_sequence_l1_value_grad(const int* ops, int K, const float* img, const float* params, const float* target,
+                                     const float* gloss, float* out, float* loss, float* gimg, float* gparams, float* seg_bufs,
+                                     float* gbuf, void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (!ops || K <= 0 || !img || !params || !gparams || !target || !gloss || !loss)
+    return fail(T2O_EINVAL, "fused_sequence_l1_value_grad: null pointer or empty sequence");
+  if (B <= 0 || H <= 0 || W <= 0) return fail(T2O_EINVAL, "B, H, W must be positive");
+  Segment seg[64];
+  const int ns = plan_segments(ops, K, seg, 64);
+  if (ns <= 0) return fail(T2O_EUNSUPPORTED, "operator index not supported, more than 64 segments, or nothing to apply");
+  if (ns > 1 && (!seg_bufs || !gbuf)) return fail(T2O_EINVAL, "seg_bufs / gbuf is null (see t2o_fused_sequence_buffers)");
+  if (!workspace || workspace_bytes < t2o_workspace_bytes(B, H, W)) return fail(T2O_EWORKSPACE, "workspace too small");
+  // the last segment's backward computes its forward anyway: a per-pixel chain recomputes it per pixel, the stencil's
+  // strip kernel forms clamp(z + p Lap z) for the sign of (out - target).  Sharpness on the LDS-tile kernels (W % 4 != 0
+  // ...) has no such form: forward + backward as two calls
+  const Geometry g = launch_geometry(B, H, W);
+  bool single = true;
+  if (seg[ns - 1].sharp) {
+    OpArgs probe;
+    memset(&probe, 0, sizeof(probe));
+    probe.op = OP_SHARPNESS; probe.B = B; probe.H = H; probe.W = W;
+    single = sharp_bwd_uses_strips(probe, g);
+  }
+  if (!single) {
+    if (!out && ns == 1) return fail(T2O_EINVAL, "fused_sequence_l1_value_grad: this image size needs `out` (sharpness on the tile kernels)");
+    float* final_img = out ? out : gbuf + (size_t)(ns & 1) * (size_t)B * 3 * H * W;      // (a gradient buffer not yet in use)
+    if (int rc = t2o_fused_sequence_fwd(ops, K, img, params, target, final_img, loss, seg_bufs, workspace, workspace_bytes, B, H, W, stream)) return rc;
+    return t2o_fused_sequence_bwd(ops, K, img, params, target, gloss, nullptr, gimg, gparams, seg_bufs, gbuf, workspace, workspace_bytes, B, H, W, stream);
+  }
+  if (ns > 1) {                                  // forward of every segment but the last, materialising the segment boundaries
+    int kcut = seg[ns - 1].first;                // operators in front of the last segment
+    if (int rc = t2o_fused_sequence_fwd(ops, kcut, img, params, nullptr, seg_bufs + (size_t)(ns - 2) * (size_t)B * 3 * H * W, nullptr, seg_bufs,
+                                        workspace, workspace_bytes, B, H, W, stream)) return rc;
+  }
+  return fused_sequence_bwd_impl(ops, K, img, params, target, gloss, nullptr, gimg, gparams, seg_bufs, gbuf, workspace, workspace_bytes,
+                                 B, H, W, stream, out, loss);
 }
 
 size_t t2o_candidates_workspace_bytes(int C, int H, int W) {

@@ -107,3 +107,12 @@ class Executor(nn.Module):
         registers (one read of the image, one write): returns (loss, out (B,3,H,W)) -- for callers
         that only need the end result, like the planner's candidate evaluation."""
         return T.fused_sequence_l1(img, ops, self._pad_params(img, params), target)
+
+    def value_and_grad(self, img, ops, params, target, gloss=None, want_image=False, want_image_grad=True):
+        """loss = mean |sequence(img) - target| and its gradients in ONE call, outside autograd -- one iteration of a
+        parameter fit (utils/beam_search.py:65-91) or of an L1 train step's executor part without a separate forward:
+        the last segment's backward kernels also produce the loss (T.fused_sequence_l1_value_grad).  Returns
+        (loss, gimg or None, gparams (K,B,24), out or None): gradients and image bit-identical to run_sequence_fused +
+        backward, the loss equal up to summation order."""
+        return T.fused_sequence_l1_value_grad(img, ops, self._pad_params(img, params), target, gloss=gloss,
+                                              want_image=want_image, want_image_grad=want_image_grad)

@@ -904,6 +904,48 @@ def fused_sequence_l1(img, ops, params, target):
     return _FusedSequenceFn.apply(img, params, target, [int(o) for o in ops])
 
 
+def fused_sequence_l1_value_grad(img, ops, params, target, gloss=None, want_image=False, want_image_grad=True):
+    """loss = mean |sequence(img) - target| AND its gradients in one call, outside autograd (the inner loop of a
+    parameter fit or a planner step: execute K times + L1Loss + backward, executors/executor.py:33-55,
+    utils/beam_search.py:65-91).  t2o_fused_sequence_l1_value_grad: the last segment's forward is not launched -- its
+    backward kernels produce the loss (and the image) too -- so BASELINE configs[1]'s list takes 3 launches instead of 4
+    and a list without sharpness ONE.  Gradients and image bit-identical to fused_sequence_l1(...) + backward, the loss
+    equal up to summation order.
+
+    params (K,B,24); gloss: () tensor scaling the gradients (default 1).  Returns (loss (), gimg (B,3,H,W) or None,
+    gparams (K,B,24), out (B,3,H,W) or None)."""
+    _need_gpu(img, params, target)
+    img, params, target = _img(img.detach()), params.detach().contiguous(), _img(target.detach())
+    ops = [int(o) for o in ops]
+    B, _, H, W = img.shape
+    K = len(ops)
+    if params.shape != (K, B, PARAM_PAD):
+        raise ValueError('params must be (K,B,24)')
+    lib = _lib.load()
+    c_ops = (ctypes.c_int * max(K, 1))(*ops)
+    nbuf = lib.t2o_fused_sequence_buffers(c_ops, K)
+    if nbuf < 0:
+        raise RuntimeError('unsupported operator in sequence %s' % (ops,))
+    if _CHAIN_JIT and tuple(ops) not in _prepared_chains and not torch.cuda.is_current_stream_capturing():
+        prepare_fused_sequence(ops)
+    dev = img.device
+    gloss = torch.ones((), dtype=torch.float32, device=dev) if gloss is None else gloss.detach().contiguous().to(torch.float32)
+    # one allocation for the scratch images: segment boundaries, the two gradient buffers, and (sharpness on the tile
+    # kernels, W % 4 != 0: the call falls back to forward + backward) the final image
+    scratch = torch.empty((max(nbuf, 1) + 2,) + tuple(img.shape), dtype=torch.float32, device=dev)
+    seg, gbuf = scratch[:max(nbuf, 1)], scratch[max(nbuf, 1):]
+    out = torch.empty_like(img) if want_image or W % 4 else None
+    gimg = torch.empty_like(img) if want_image_grad else None
+    gparams = torch.empty_like(params)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    ws = workspace(B, H, W, dev)
+    rc = lib.t2o_fused_sequence_l1_value_grad(c_ops, K, _ptr(img), _ptr(params), _ptr(target), _ptr(gloss), _ptr(out),
+                                              _ptr(loss), _ptr(gimg), _ptr(gparams), _ptr(seg), _ptr(gbuf), _ptr(ws),
+                                              ws.numel(), B, H, W, _stream(dev))
+    _lib.check(rc, 't2o_fused_sequence_l1_value_grad')
+    return loss, gimg, gparams, (out if want_image else None)
+
+
 def candidates_multi_l1(ops, img_index, imgs, target, params):
     """loss[j, c] = mean |execute(imgs[img_index[j]], ops[j], params[j, c]) - target| for J jobs x C candidates in
     ONE launch (t2o_op_candidates_multi_l1).  ops / img_index: python ints; imgs (n,3,H,W); params (J,C,n)."""

@@ -84,20 +84,25 @@ def fit_sweep_batch(images, jobs, target, executor, rounds=3):
 
 
 def _fit_adam(I0, I1, operation, executor, param0, steps=300, lr=2e-2, check_every=50, tol=1e-6):
-    param = param0.clone().to(I0.device).requires_grad_(True)
+    """Adam on the operator's parameters against mean |execute(I0) - I1| (beam_search.py:65-91 with a first-order
+    optimiser).  One library call per iteration: executor.value_and_grad (loss + parameter gradient, no separate forward,
+    no image gradient, no autograd graph)."""
+    n = param0.shape[-1]
+    padded = torch.zeros(1, I0.shape[0], T.PARAM_PAD, device=I0.device)
+    padded[0, :, :n] = param0.to(I0.device)
+    param = padded[0, :, :n].requires_grad_(True)                        # a view: Adam's in-place update lands in `padded`
     opt = torch.optim.Adam([param], lr=lr)
     prev = None
     for it in range(steps):
-        opt.zero_grad()
-        loss, _ = executor.run_sequence_fused(I0, [operation], [param], I1)
-        loss.backward()
+        loss, _, gparams, _ = executor.value_and_grad(I0, [operation], padded, I1, want_image_grad=False)
+        param.grad = gparams[0, :, :n]
         opt.step()
         if (it + 1) % check_every == 0:                                  # one sync per check_every iterations
             cur = loss.item()
             if prev is not None and prev - cur < tol:
                 break
             prev = cur
-    return param.detach(), True
+    return param.detach().clone(), True
 
 
 def _fit_scipy(I0, I1, operation, executor, param0, method):

@@ -58,7 +58,7 @@ def bwd(op, img, param, gout=None, mask=None, op_id=None, target=None, gloss=1.0
     return gimg, gparam
 
 
-def fused(ops, img, params, target, gloss=1.0, iters=0, use_static=0):
+def fused(ops, img, params, target, gloss=1.0, iters=0, use_static=0, with_value=False):
     """Fused sequence forward + backward.  params (K,B,24).  Returns out, loss, gimg, gparams."""
     img, params, target = _f(img), _f(params), _f(target)
     B, _, H, W = img.shape
@@ -74,8 +74,11 @@ def fused(ops, img, params, target, gloss=1.0, iters=0, use_static=0):
     gimg = np.empty_like(img)
     gparams = np.zeros_like(params)
     gl = np.array([gloss], np.float32)
+    vout, vloss = np.full_like(img, np.nan), np.full(1, np.nan, np.float32)
     assert lib().emul_fused_bwd(c_ops, K, _p(img), _p(params), _p(target), _p(gl), _p(gimg), _p(gparams), _p(seg),
-                                _p(gbuf), B, H, W, iters, use_static) == 0
+                                _p(gbuf), B, H, W, iters, use_static, _p(vout), _p(vloss)) == 0
+    if with_value:                       # what the last segment's backward ALSO produced (value-and-gradient entry point);
+        return out, float(loss[0]), gimg, gparams, vout, float(vloss[0])     # NaN when the last segment is a sharpness
     return out, float(loss[0]), gimg, gparams
 
 

@@ -184,7 +184,7 @@ int emul_fused_fwd(const int* ops, int K, const float* img, const float* params,
 // pixel per thread-iteration, parameter sums kept across the thread's pixels), as the device dispatch does
 int emul_fused_bwd(const int* ops, int K, const float* img, const float* params, const float* target,
                    const float* gloss, float* gimg, float* gparams, const float* seg_bufs, float* gbuf, int B, int H,
-                   int W, int forced_iters, int use_static) {
+                   int W, int forced_iters, int use_static, float* value_out, float* value_loss) {
   Segment seg[64];
   const int ns = plan_segments(ops, K, seg, 64);
   if (ns < 0) return 2;
@@ -207,7 +207,8 @@ int emul_fused_bwd(const int* ops, int K, const float* img, const float* params,
       memset(&a, 0, sizeof(a));
       chain_fill(a, seg[s], B, H, W, iters, nblk);
       a.img = in; a.params = params; a.gimg = gnext;
-      if (last) { a.target = target; a.gloss = gloss; } else { a.gout = gcur; }
+      if (last) { a.target = target; a.gloss = gloss; a.out = value_out; } else { a.gout = gcur; }
+      double l1_total = 0.0;                      // value outputs of the last segment's backward (t2o_fused_sequence_l1_value_grad)
       for (int b = 0; b < B; ++b) {
         std::vector<float> tab(kMaxChain * kTabStride, 0.0f);
         for (int k = 0; k < a.K; ++k) chain_build_table(a, b, k, tab.data());
@@ -219,10 +220,10 @@ int emul_fused_bwd(const int* ops, int K, const float* img, const float* params,
         const bool st2 = use_static && vec == 1 && emu_chain_is<EmuSeq2>(a), st5 = use_static && vec == 1 && emu_chain_is<EmuSeq5>(a);
         for (int blk = 0; blk < nblk; ++blk)
           for (int tid = 0; tid < kThreads; ++tid) {
-            if (st2) { if (last) chain_bwd_thread_static<true, EmuSeq2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread_static<false, EmuSeq2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
-            else if (st5) { if (last) chain_bwd_thread_static<true, EmuSeq5, false>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread_static<false, EmuSeq5, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
-            else if (vec == 2) { if (last) chain_bwd_thread<2, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
-            else { if (last) chain_bwd_thread<1, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<1, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            if (st2) { if (last) l1_total += chain_bwd_thread_static<true, EmuSeq2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread_static<false, EmuSeq2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            else if (st5) { if (last) l1_total += chain_bwd_thread_static<true, EmuSeq5, false>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread_static<false, EmuSeq5, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            else if (vec == 2) { if (last) l1_total += chain_bwd_thread<2, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<2, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
+            else { if (last) l1_total += chain_bwd_thread<1, true>(a, b, blk, tid, tab.data(), sv.data(), acc); else chain_bwd_thread<1, false>(a, b, blk, tid, tab.data(), sv.data(), acc); }
           }
         for (int sl = 0; sl < a.slot_off[kMaxChain]; ++sl) sums[sl] = chain_slot_value(a, sl, bins);
         for (int k = 0; k < a.K; ++k) {
@@ -230,6 +231,7 @@ int emul_fused_bwd(const int* ops, int K, const float* img, const float* params,
           finalize_param_grad(a.ops[k], params + ((size_t)a.src[k] * B + b) * kMaxParam, sums + a.slot_off[k], grow);
         }
       }
+      if (last && value_loss) value_loss[0] = (float)(l1_total * a.inv_n);
     }
     gcur = gnext;
   }

@@ -178,6 +178,25 @@ def test_static_chain_backward_equals_runtime_loop_program(ops, iters):
     np.testing.assert_allclose(p1, p0, rtol=2e-5, atol=1e-6 * max(np.abs(p0).max(), 1e-6))
 
 
+@pytest.mark.parametrize('ops', [[0, 1, 2, 3, 5], [5, 3, 5, 3, 0, 1, 2], [6, 0, 7, 5]])
+@pytest.mark.parametrize('iters,use_static', [(0, 0), (3, 0), (0, 1), (3, 1)])
+def test_last_chain_backward_also_yields_the_image_and_the_loss(ops, iters, use_static):
+    """t2o_fused_sequence_l1_value_grad: the last per-pixel segment's L1 backward recomputes the final pixel, so it also
+    stores it (ChainArgs.out) and returns |out - target| for the loss -- the device-side forward launch of that segment is
+    dropped.  The image must be the forward program's bit for bit, the loss equal to the forward's up to summation order."""
+    B, H, W = 2, 23, 19
+    img, tgt = synth.images(B, H, W, 71), synth.images(B, H, W, 72)
+    params = torch.zeros(len(ops), B, 24)
+    for k, op in enumerate(ops):
+        n = cpu_ref.OP_NPARAM[op]
+        if n:
+            params[k, :, :n] = synth.op_params(op, B, 500 + k, 'mid')
+    out, loss, _, _, vout, vloss = emul.fused(ops, img.numpy(), params.numpy(), tgt.numpy(), gloss=1.5, iters=iters,
+                                              use_static=use_static, with_value=True)
+    np.testing.assert_array_equal(vout, out)
+    assert abs(vloss - loss) <= 2e-7 * max(loss, 1e-3)
+
+
 def edge_image():
     """Exact ties the random suite never hits: black, white, greys, two equal maxima/minima,
     values on curve knots, flat saturated regions (sharpness output exactly 0 / 1)."""

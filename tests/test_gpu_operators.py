@@ -439,6 +439,59 @@ def test_fused_sequence_equals_materialised_sequence(executor, dev, ops, shape):
     assert torch.allclose(gp0, gp1, rtol=2e-4, atol=2e-5 * max(1.0, gp0.abs().max().item()))
 
 
+@pytest.mark.parametrize('ops', [[0, 1, 2, 3, 5, 6], [5, 3, 5, 3, 0, 1, 2, 6], [6, 0, -1, 6, 3], [1], [6], [0, 1, 2, 3, 5],
+                                 [0, 1, 2, 3, 5, 0, 1, 2, 3, 5, 7, 1], [6, 6]])
+@pytest.mark.parametrize('shape', [(3, 32, 40), (2, 23, 19), (2, 128, 128), (1, 256, 256)])
+@pytest.mark.parametrize('jit', [True, False])
+def test_value_and_grad_equals_forward_plus_backward(executor, dev, ops, shape, jit, monkeypatch):
+    """Executor.value_and_grad (t2o_fused_sequence_l1_value_grad: no forward launch for the last segment -- its backward
+    kernels also emit the loss and the image) against run_sequence_fused + backward: image, image gradient and parameter
+    gradients BIT-identical (same kernels, same geometry), the loss equal up to summation order.  (2,23,19): sharpness on
+    the LDS-tile kernels, where the call falls back to the two launches internally."""
+    import t2onet_amd.functional as T
+    monkeypatch.setattr(T, '_CHAIN_JIT', jit)
+    B, H, W = shape
+    img = synth.images(B, H, W, 41).to(dev)
+    tgt = synth.images(B, H, W, 42).to(dev)
+    params = torch.zeros(len(ops), B, 24)
+    for k, op in enumerate(ops):
+        if op >= 0 and cpu_ref.OP_NPARAM[op]:
+            params[k, :, :cpu_ref.OP_NPARAM[op]] = synth.op_params(op, B, 330 + k, 'mid')
+    x = img.clone().requires_grad_(True)
+    p = params.to(dev).requires_grad_(True)
+    loss, out = executor.run_sequence_fused(x, ops, p, tgt)
+    (loss * 1.75).backward()
+    gl = torch.tensor(1.75, device=dev)
+    for want_image in (True, False):
+        l2, gx, gp, o2 = executor.value_and_grad(img, ops, params.to(dev), tgt, gloss=gl, want_image=want_image)
+        assert abs(l2.item() - loss.item()) <= 2e-7 * max(loss.item(), 1e-3)
+        assert torch.equal(gx, x.grad)
+        assert torch.equal(gp, p.grad)
+        assert (o2 is None) if not want_image else torch.equal(o2, out)
+    l3, gx3, gp3, _ = executor.value_and_grad(img, ops, params.to(dev), tgt, gloss=gl, want_image_grad=False)
+    assert gx3 is None and torch.equal(gp3, p.grad) and l3.item() == l2.item()
+
+
+def test_value_and_grad_at_256_against_fp64(executor, dev):
+    """BASELINE configs[1]'s list at 256 x 256 (bs = 16 of its 64: the fp64 oracle runs on the host) through the one-call
+    path: loss, image, image gradient and the gradient of every operator's parameters against fp64 autograd of the oracle."""
+    ops = [0, 1, 2, 3, 5, 6]
+    B, H, W = 16, 256, 256
+    img, tgt = synth.images(B, H, W, 51), synth.images(B, H, W, 52)
+    params = [synth.op_params(op, B, 340 + k, 'mid') for k, op in enumerate(ops)]
+    ref_out, ref_loss, ref_gx, ref_gp = _fp64_oracle_sequence(img, tgt, ops, params)
+    loss, gimg, gparams, out = executor.value_and_grad(img.to(dev), ops, [q.to(dev) for q in params], tgt.to(dev), want_image=True)
+    assert abs(loss.item() - ref_loss) < 1e-6
+    _close_except_branch_flips(out.cpu().numpy(), ref_out.numpy(), 0, 2e-5, what='out')
+    gx = ref_gx.numpy()
+    _close_except_branch_flips(gimg.cpu().numpy(), gx, 2e-4, 2e-5 * np.abs(gx).max(), what='gimg')
+    for k in range(len(ops)):
+        gk = ref_gp[k].numpy()
+        # (a parameter gradient is a sum over 196 608 pixels of terms of both signs, in fp32: 1e-3 relative on the small ones)
+        np.testing.assert_allclose(gparams[k, :, :gk.shape[1]].cpu().numpy(), gk, rtol=2e-3,
+                                   atol=2e-4 * max(np.abs(gk).max(), 1e-6), err_msg='gparam %d (op %d)' % (k, ops[k]))
+
+
 def test_fused_sequence_golden_chain6(executor, gold, dev):
     B, H, W = 3, 32, 40
     ops = [0, 1, 2, 3, 5, 6]
