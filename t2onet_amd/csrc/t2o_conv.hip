@@ -449,7 +449,11 @@ constexpr int kFwdWBuf = 3 * kFwdCo * 128;                      // [kw][co][32 c
 // kS = 2: the forward of a STRIDE-2 convolution.  a.H, a.W are then the OUTPUT grid (x is 2H x 2W) and the x tile is
 // two planes, as in the stride-2 weight gradient: the even input columns 2 beta (kw = 1) and the odd ones 2 beta + 1
 // (kw = 2, and kw = 0 one output pixel to the left).
-template <int kBM, int kS = 1>
+// kAdd: a.addend is added in the epilogue.  Its 16 kBM values per lane are FETCHED at the top of the last loop iteration (one or
+// two stages = 5-10 us before they are needed): with one workgroup per CU nothing else hides that round trip, and every
+// workgroup of a round reaches its epilogue at the same time -- loading after the loop cost 20 us (128 channels) to 58 us (64
+// channels: 67 MB) per launch over the same kernel without addend.
+template <int kBM, int kS = 1, bool kAdd = false>
 __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   constexpr int kFwdPix = 128 * kBM;                              // output pixels per workgroup
   constexpr int kFwdXPieces = (kFwdPix + 2 * kFwdHalo) / 8;       // pieces of 8 rows (34 / 18)
@@ -632,7 +636,19 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 #ifdef T2O_CONV_DIAG
   t_loop = __builtin_amdgcn_s_memtime();
 #endif
+  float pre[kAdd ? kBM : 1][16];
   for (int st = 0; st < stages; st += 2) {
+    if constexpr (kAdd) {
+      if (st + 2 >= stages) {                              // (uniform) the last iteration: fetch the addend under its MFMAs
+#pragma unroll
+        for (int i = 0; i < kBM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int p = p0 + wm * 32 * kBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            pre[i][r] = p < P ? a.addend[(size_t)p * a.Co + co0 + wn * 32 + ln] : 0.0f;
+          }
+      }
+    }
     stage(std::integral_constant<int, 0>{}, st);
     if (st + 1 < stages) stage(std::integral_constant<int, 1>{}, st + 1);
   }
@@ -648,7 +664,8 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
       const int p = p0 + wm * 32 * kBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (p < P) {
         const size_t o = (size_t)p * a.Co + co0 + wn * 32 + ln;
-        a.y[o] = a.addend ? acc[i][r] + a.addend[o] : acc[i][r];
+        if constexpr (kAdd) a.y[o] = acc[i][r] + pre[i][r];
+        else a.y[o] = acc[i][r];
       }
     }
   // Batch-norm statistics of the layer that follows, straight from the accumulators (a lane holds 16 * kBM pixels of
@@ -997,12 +1014,18 @@ struct Dgrad2Args {
   int tiles_p, tiles_n;
 };
 
-__global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a) {
+// kWN: waves along the input channels.  2: 8 waves, 128 dy pixels x 64 channels per workgroup (the normal tile).  1: 4 waves,
+// 128 x 32 -- for layers whose 64-channel tiles number fewer than half the CUs (stage 4 at bs = 64: 32 pixel tiles x 4 = 128
+// workgroups took 135 us where the same FLOP on the other stages take 77-83); a wave's instruction stream is the same, a
+// SIMD holds one wave instead of two.
+template <int kWN>
+__global__ __launch_bounds__(256 * kWN, 1) void k_conv3x3s2_dgrad(Dgrad2Args a) {
+  constexpr int NW = 4 * kWN;                                    // waves
   constexpr int kPix = 128;
   constexpr int kXPieces = (kPix + 2 * kFwdHalo) / 8;            // 18
   constexpr int kXBuf = (kXPieces + 1) * 1024;                   // + zero rows
   constexpr int kZeroRow = kXPieces * 8;
-  constexpr int kTapBytes = 64 * 128;                            // one tap of the w tile: 64 output channels x 32 reduction channels
+  constexpr int kTapBytes = 32 * kWN * 128;                      // one tap of the w tile: 32 kWN input channels (rows) x 32 reduction channels
   __shared__ __attribute__((aligned(16))) char Xs[2][kXBuf];     // [0]: rows alpha (stage A), [1]: rows alpha + 1 (stage B)
   __shared__ __attribute__((aligned(16))) char WsA[6 * kTapBytes];
   __shared__ __attribute__((aligned(16))) char WsB[3 * kTapBytes];
@@ -1012,10 +1035,10 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a
   const int pt = (k8 / a.tiles_n) * 8 + xcd, ct = k8 % a.tiles_n;
   if (pt >= a.tiles_p) return;
   const int P = a.N * a.Ho * a.Wo, HW = a.Ho * a.Wo;
-  const int p0 = pt * kPix, n0 = ct * 64;
+  const int p0 = pt * kPix, n0 = ct * 32 * kWN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / kWN, wn = wave % kWN;
   const int ln = lane & 31, lh = lane >> 5;
 
   f32x16 acc[2][2];                                       // [ph][pw]
@@ -1025,7 +1048,7 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a
     for (int r = 0; r < 16; ++r) acc[c >> 1][c & 1][r] = 0.0f;
 
   const unsigned lds_x = lds_addr(&Xs[0][0]), lds_wa = lds_addr(&WsA[0]), lds_wb = lds_addr(&WsB[0]);
-  constexpr int NXW = (kXPieces + 7) / 8;                 // 3 (the last one only for waves 0, 1)
+  constexpr int NXW = (kXPieces + NW - 1) / NW;           // 3 / 5 (the last one only for waves 0, 1)
   const int prow = lane >> 3, ppos = lane & 7;
   const int pswz = ((wave * 8 + prow) >> 1) & 7;
   const unsigned lane_x = (unsigned)(prow * a.Co * 4 + ((ppos ^ pswz) << 4));
@@ -1033,7 +1056,7 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a
   int mrow[NXW];
 #pragma unroll
   for (int i = 0; i < NXW; ++i)
-    mrow[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(p0 - kFwdHalo + (wave + 8 * i) * 8 + HW) % (unsigned)HW));
+    mrow[i] = __builtin_amdgcn_readfirstlane((int)((unsigned)(p0 - kFwdHalo + (wave + NW * i) * 8 + HW) % (unsigned)HW));
   const long long xrow = (long long)a.Co * 4;
   const char* const x0 = (const char*)a.dy + ((long long)p0 - kFwdHalo + wave * 8) * xrow;
   const char* const w0 = (const char*)a.wt + (long long)(n0 + wave * 8) * 9 * xrow;
@@ -1042,18 +1065,18 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3s2_dgrad(Dgrad2Args a
   auto dma_piece = [&](auto typec, auto jc, int cc) {
     constexpr int type = decltype(typec)::value, j = decltype(jc)::value;      // type 0 = A, 1 = B
     if constexpr (j < NXW) {
-      const int piece = wave + 8 * j;
+      const int piece = wave + NW * j;
       if (piece < kXPieces) {                              // wave-uniform
         const int q0 = p0 - kFwdHalo + piece * 8;
         const bool ok = (unsigned)q0 < (unsigned)P && (type == 0 || mrow[j] < HW - a.Wo);      // B: the row alpha + 1 exists
-        const char* src = x0 + ((long long)j * 64 + (long long)type * a.Wo) * xrow + cc * 128;
+        const char* src = x0 + ((long long)j * NW * 8 + (long long)type * a.Wo) * xrow + cc * 128;
         glds16(lane_x, ok ? src : (const char*)a.zero, lds_x + (unsigned)(type * kXBuf + piece * 1024));
       }
     } else {
       constexpr int t = j - NXW;                           // A: taps (kh = 1 + t / 3, kw = t % 3); B: (kh = 0, kw = t)
       constexpr int tap = type == 0 ? 3 + t : t;           // kh * 3 + kw
       const char* src = w0 + (long long)tap * xrow + cc * 128;
-      glds16(lane_w, src, (type == 0 ? lds_wa : lds_wb) + (unsigned)((t * 8 + wave) * 1024));
+      glds16(lane_w, src, (type == 0 ? lds_wa : lds_wb) + (unsigned)((t * NW + wave) * 1024));
     }
   };
   constexpr int NPA = NXW + 6, NPB = NXW + 3;             // pieces per wave of a stage A / B
@@ -1497,9 +1520,16 @@ int launch_fwd(const float* x, const float* w, float* y, const float* zero, int 
   a.addend = addend;
   a.stamps = nullptr;
   const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
-  if (stride == 2) k_conv3x3_fwd<1, 2><<<grid, kFwdThreads, 0, st>>>(a);
-  else if (bm == 1) k_conv3x3_fwd<1><<<grid, kFwdThreads, 0, st>>>(a);
-  else k_conv3x3_fwd<2><<<grid, kFwdThreads, 0, st>>>(a);
+  if (stride == 2) {
+    if (addend) return T2O_EINVAL;                       // (no caller: the stride-2 data gradient is its own kernel)
+    k_conv3x3_fwd<1, 2><<<grid, kFwdThreads, 0, st>>>(a);
+  } else if (bm == 1) {
+    if (addend) k_conv3x3_fwd<1, 1, true><<<grid, kFwdThreads, 0, st>>>(a);
+    else k_conv3x3_fwd<1><<<grid, kFwdThreads, 0, st>>>(a);
+  } else {
+    if (addend) k_conv3x3_fwd<2, 1, true><<<grid, kFwdThreads, 0, st>>>(a);
+    else k_conv3x3_fwd<2><<<grid, kFwdThreads, 0, st>>>(a);
+  }
   return hipGetLastError() == hipSuccess ? T2O_OK : T2O_ELAUNCH;
 }
 
@@ -1578,9 +1608,12 @@ int launch_dgrad2(const float* dy, const float* wt, float* dx, const float* zero
   a.dy = dy; a.wt = wt; a.dx = dx; a.zero = zeros;
   a.N = N; a.Ho = Ho; a.Wo = Wo; a.Ci = Ci; a.Co = Co;
   const int P = N * Ho * Wo;
-  a.tiles_p = (P + 127) / 128; a.tiles_n = Ci / 64;
+  a.tiles_p = (P + 127) / 128;
+  const bool narrow = (long long)a.tiles_p * (Ci / 64) <= 128;      // fewer 64-channel tiles than half the CUs: 32-channel tiles, 4 waves
+  a.tiles_n = Ci / (narrow ? 32 : 64);
   const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
-  k_conv3x3s2_dgrad<<<grid, kFwdThreads, 0, st>>>(a);
+  if (narrow) k_conv3x3s2_dgrad<1><<<grid, 256, 0, st>>>(a);
+  else k_conv3x3s2_dgrad<2><<<grid, kFwdThreads, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "conv3x3s2_dgrad launch failed");
 }
 

@@ -143,7 +143,10 @@ def test_encoder_layer_shapes_at_batch_64_vs_fp64_samples(layer):
 
 
 # (N, Ci, Co, Ho, Wo) of the stride-2 layers: dx is (N, Ci, 2Ho, 2Wo)
+# (the data gradient has two tilings: 8 waves x 64 input channels, and -- when those tiles number <= 128 -- 4 waves x 32
+# channels; (40, 64, 64, 16, 32) and (12, 128, 64, 16, 32) take the first, the rest the second)
 S2_SHAPES = [(2, 64, 64, 8, 8), (3, 64, 128, 5, 16), (1, 128, 64, 3, 24), (2, 64, 32, 1, 8), (2, 128, 256, 20, 8), (1, 64, 64, 2, 136),
+             (40, 64, 64, 16, 32), (12, 128, 64, 16, 32), (8, 256, 512, 8, 8),
              (2, 3, 64, 16, 16), (3, 3, 64, 9, 37), (1, 3, 32, 1, 1), (2, 3, 64, 8, 64)]      # (the last four: the 3-channel stem)
 
 
