@@ -911,7 +911,7 @@ T2O_HD float chain_fwd_thread_static(const ChainArgs& a, int b, int blk, int tid
   return l1;
 }
 
-template <bool L1, class SEQ, bool SV_LDS, class ACC>
+template <bool L1, class SEQ, bool SV_LDS, class ACC, bool VAL = L1>
 T2O_HD float chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid, const float* tab, float* svl, ACC& acc) {
   constexpr int K = SEQ::K;
   float l1 = 0.0f;                                   // (L1 forms: sum |chain(img) - target| of the live pixels, see chain_bwd_thread)
@@ -961,15 +961,17 @@ T2O_HD float chain_bwd_thread_static(const ChainArgs& a, int b, int blk, int tid
         pass[k][c] = x[c] == r.c[c];                   // == (0 <= r && r <= 1), NaN included: one compare on the clamped value
       }
     }
-    if (a.out && live) {
-      T2O_UNROLL
-      for (int c = 0; c < 3; ++c) a.out[sb + c * hw + px] = x[c];
+    if constexpr (L1 && VAL) {
+      if (a.out && live) {
+        T2O_UNROLL
+        for (int c = 0; c < 3; ++c) a.out[sb + c * hw + px] = x[c];
+      }
     }
     T2O_UNROLL
     for (int c = 0; c < 3; ++c) {
       if (L1) {
         const float d = x[c] - gg[c];
-        if (live) l1 += fabsf(d);
+        if constexpr (VAL) { if (live) l1 += fabsf(d); }
         gg[c] = sign_of(d) * gs;
       }
       if (!live) gg[c] = 0.0f;

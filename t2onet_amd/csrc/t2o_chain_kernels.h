@@ -115,7 +115,10 @@ __device__ __forceinline__ void chain_fwd_static_body(const ChainArgs& a) {
 }
 
 
-template <bool L1, class SEQ, bool SV_LDS>
+// VAL: the launch also emits the loss partials (and the image when a.out is set) of a value-and-gradient call.  Kernels
+// compiled at run time (t2o_jit.hip) take the default: their fused-L1 form is value-capable; the ahead-of-time kernels keep
+// a plain L1 instantiation beside it (3 waves per SIMD at 164-166 VGPRs; the value outputs cost 4-12 more).
+template <bool L1, class SEQ, bool SV_LDS, bool VAL = L1>
 __device__ __forceinline__ void chain_bwd_static_body(const ChainArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // accumulator cells: NB rows of kAccStride [+ save area]
   __shared__ float tab[kMaxChain * kTabStride];
@@ -127,8 +130,8 @@ __device__ __forceinline__ void chain_bwd_static_body(const ChainArgs& a) {
   if ((int)threadIdx.x < SEQ::K) chain_build_table(a, b, threadIdx.x, tab);
   __syncthreads();
   LdsAcc acc{lds};
-  const float l1 = chain_bwd_thread_static<L1, SEQ, SV_LDS>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
-  if (L1 && a.loss_partials) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk);   // value-and-gradient calls
+  const float l1 = chain_bwd_thread_static<L1, SEQ, SV_LDS, LdsAcc, VAL>(a, b, blk, threadIdx.x, tab, lds + NB * kAccStride, acc);
+  if constexpr (L1 && VAL) { if (a.loss_partials) block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk + blk); }   // value-and-gradient calls
   __syncthreads();
   for (int s = threadIdx.x; s < NB; s += kThreads) {
     float sum = 0.0f;

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(kThreads) void k_sharp_fwd_strip(OpArgs a, int nblk
 
 // MASKED: out = clamp(blend(x + p * Lap(x), x, m)): with do = dz * m the input gradient is
 // dz * (1 - m) + do + p * Lap(do) and d loss / d p sums do * Lap(x); the mask rows ride along in registers.
-template <bool DYN, bool WIDE, bool MASKED>
+// VAL (fused-L1 calls only): the launch also emits |out - target| partial sums (a.loss_partials) and, when a.out is set,
+// the output image -- a value-and-gradient call needs no forward launch.  A separate instantiation: the plain kernels keep
+// their register count (119 / 173 VGPRs; +29 with the value outputs).
+template <bool DYN, bool WIDE, bool MASKED, bool VAL = false>
 __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk, int nseg) {
   int b, blk;
   wg_coords(nblk, b, blk);
@@ -238,8 +241,8 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
       const bool in = col_live && y >= 0 && y < a.H;
       const float* ce = xr[k + 1];
       const float L = dpp_wave_shr1(ce[3]), R = dpp_wave_shl1(ce[0]);
-      const bool mine = k >= 1 && k <= kStripRows && own && in;        // an output pixel of this thread
-      float oz[4];
+      const bool mine = VAL && k >= 1 && k <= kStripRows && own && in;        // an output pixel of this thread
+      float oz[VAL ? 4 : 1];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float left = i == 0 ? L : ce[i > 0 ? i - 1 : 0], right = i == 3 ? R : ce[i < 3 ? i + 1 : 3];
@@ -247,15 +250,19 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
         const float m = MASKED ? mk[k][i] : 1.0f;
         float z = ce[i] + p * d;
         if (MASKED) z = blend(z, ce[i], m);
-        oz[i] = clamp01(z);
-        if (a.target && mine) l1 += fabsf(oz[i] - g[k][i]);
-        const float gz = a.target ? sign_of(oz[i] - g[k][i]) * gs : g[k][i];
+        if constexpr (VAL) {
+          oz[i] = clamp01(z);
+          if (mine) l1 += fabsf(oz[i] - g[k][i]);
+        }
+        const float gz = a.target ? sign_of(clamp01(z) - g[k][i]) * gs : g[k][i];
         const float dz = (in && z >= 0.0f && z <= 1.0f) ? gz : 0.0f;
         g[k][i] = MASKED ? dz * m : dz;                                   // do
         if (MASKED && k >= 1 && k <= kStripRows) pass[k - 1][i] = dz * (1.0f - m);
         if (k >= 1 && k <= kStripRows && own) red0 += dz * m * d;
       }
-      if (a.out && mine) store_vec<4>(a.out + ((size_t)b * 3 + c) * hw + (unsigned)y * (unsigned)a.W + (unsigned)gx0, oz);
+      if constexpr (VAL) {
+        if (a.out && mine) store_vec<4>(a.out + ((size_t)b * 3 + c) * hw + (unsigned)y * (unsigned)a.W + (unsigned)gx0, oz);
+      }
     }
     // gimg rows y0 .. y0+kStripRows-1
 #pragma unroll
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void k_sharp_bwd_strip(OpArgs a, int nblk
     }
   }
   block_reduce_store1(red0, a.partials + ((size_t)b * a.nblk_max + blk) * kRedSlots);
-  if (a.target && a.loss_partials) {
+  if constexpr (VAL) {
     __syncthreads();                                           // (block_reduce_store1's staging cells are reused)
     block_reduce_store1(l1, a.loss_partials + (size_t)b * a.nblk_max + blk);
   }
@@ -337,8 +344,8 @@ __global__ __launch_bounds__(kThreads) void k_chain_bwd(ChainArgs a) {
 
 // the backward for an operator list fixed at compile time: body in t2o_chain_kernels.h (shared with the hipRTC path,
 // t2o_fused_sequence_prepare).  One instantiation per entry of the dispatch in fused_chain_launch_bwd.
-template <bool L1, class SEQ, bool SV_LDS, int MINW>
-__global__ __launch_bounds__(kThreads, MINW) void k_chain_bwd_static(ChainArgs a) { chain_bwd_static_body<L1, SEQ, SV_LDS>(a); }
+template <bool L1, class SEQ, bool SV_LDS, int MINW, bool VAL = false>
+__global__ __launch_bounds__(kThreads, MINW) void k_chain_bwd_static(ChainArgs a) { chain_bwd_static_body<L1, SEQ, SV_LDS, VAL>(a); }
 
 // one workgroup per sample: per-block sums -> raw sums -> parameter gradients of every chain operator.
 // 8 threads per slot walk the block rows (stride 8), then a fixed-order LDS combine.
@@ -1022,6 +1029,11 @@ void launch_sharp_bwd(const OpArgs& a, const Geometry& g, hipStream_t st) {
     const int nseg = strip_bwd_segments(a.W), nblk = g.nblk_strip_bwd;
     const unsigned grid = (unsigned)a.B * nblk;
     const bool dyn = a.op == OP_DYNAMIC;
+    if (a.loss_partials) {                      // value-and-gradient (run_bwd checked: fused L1, one operator, no mask)
+      if (nseg > 1) k_sharp_bwd_strip<false, true, false, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg);
+      else k_sharp_bwd_strip<false, false, false, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg);
+      return;
+    }
 #define T2O_BWD_STRIP(D, Wd) \
     { if (a.mask_ch) k_sharp_bwd_strip<D, Wd, true><<<grid, kThreads, 0, st>>>(a, nblk, nseg); \
       else k_sharp_bwd_strip<D, Wd, false><<<grid, kThreads, 0, st>>>(a, nblk, nseg); }
@@ -1119,7 +1131,7 @@ int run_bwd(int op, const int* op_id, const float* img, const float* param, int 
   a.inv_n = 1.0f / ((float)B * 3.0f * (float)H * (float)W);
   hipStream_t st = (hipStream_t)stream;
   if (value_loss) {
-    if (op != OP_SHARPNESS || !target || !sharp_bwd_uses_strips(a, g)) return fail(T2O_EUNSUPPORTED, "value-and-gradient: sharpness on the strip kernels only");
+    if (op != OP_SHARPNESS || !target || mask_ch || !sharp_bwd_uses_strips(a, g)) return fail(T2O_EUNSUPPORTED, "value-and-gradient: unmasked sharpness on the strip kernels only");
     a.out = value_out;
     a.loss_partials = (float*)ws + ws_partials_floats(g, B, H, W);
   }
@@ -1360,7 +1372,8 @@ template <class SEQ, bool SV_LDS, int MINW>
 static void launch_static_bwd(ChainArgs& a, bool l1, hipStream_t st) {
   const unsigned grid = (unsigned)a.B * a.nblk;
   const size_t lds = sizeof(float) * ((size_t)a.bin_off[kMaxChain] * kAccStride + (SV_LDS ? chain_save_floats<1>(SEQ::K) : 0));
-  if (l1) k_chain_bwd_static<true, SEQ, SV_LDS, MINW><<<grid, kThreads, lds, st>>>(a);
+  if (l1 && a.loss_partials) k_chain_bwd_static<true, SEQ, SV_LDS, MINW, true><<<grid, kThreads, lds, st>>>(a);      // value-and-gradient
+  else if (l1) k_chain_bwd_static<true, SEQ, SV_LDS, MINW><<<grid, kThreads, lds, st>>>(a);
   else k_chain_bwd_static<false, SEQ, SV_LDS, MINW><<<grid, kThreads, lds, st>>>(a);
 }
 template <class SEQ>
