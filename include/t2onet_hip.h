@@ -367,6 +367,11 @@ int t2o_bn_relu_nhwc_bwd_acc(const float* x, const float* y, const float* dy, co
                              const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
                              float* dbias, int has_res, int relu, int accumulate, void* workspace, size_t workspace_bytes,
                              int M, int C, void* stream);
+/* ... with the sums supplied by the producer of dy (see t2o_conv3x3_dgrad_pre_bnsums_nhwc): finalize + apply only; no residual. */
+int t2o_bn_relu_nhwc_bwd_partials_acc(const float* x, const float* dy, const float* weight, const float* bias,
+                                      const float* save_mean, const float* save_invstd, float* dx, float* dweight,
+                                      float* dbias, int relu, int accumulate, const float* partial, int partial_rows,
+                                      void* workspace, size_t workspace_bytes, int M, int C, void* stream);
 
 /* Weight gradient of a 3x3 convolution, stride 1 or 2 ((N,Ho,Wo) = the dy grid; shapes / workspace as
  * t2o_conv3x3_wgrad_nhwc / t2o_conv3x3s2_wgrad_nhwc); accumulate != 0: dw += . */
@@ -387,6 +392,16 @@ int t2o_conv_weight_transform_batch(const float* const* w, float* const* wt, con
  * workspace: t2o_conv3x3_fwd_workspace_bytes(N, H, W, Co, Ci) (the zero region only). */
 int t2o_conv3x3_dgrad_pre_nhwc(const float* dy, const float* wt, const float* addend, float* dx, void* workspace,
                                size_t workspace_bytes, int N, int H, int W, int Ci, int Co, void* stream);
+/* The same data gradient (no addend) in front of y = relu(bn(bn_x)) -- a BasicBlock's second convolution, models/actor_resnet.py:
+ * 38-44: the epilogue ALSO leaves the batch norm's backward sums, rows (t2o_conv3x3_dgrad_bnsums_rows(...), 2, Ci): per pixel
+ * tile the channels' sums of g = dx * [bn_x * gamma * invstd + (beta - mean * gamma * invstd) > 0] and of g * xhat, the gate
+ * evaluated exactly as t2o_bn_relu_nhwc_bwd does.  Feed them to t2o_bn_relu_nhwc_bwd_partials_acc: that batch norm's own
+ * sums pass (one read of dx and one of bn_x) is not launched; bn_x is fetched under the last loop iteration's MFMAs. */
+int t2o_conv3x3_dgrad_bnsums_rows(int N, int H, int W, int Ci, int Co);
+int t2o_conv3x3_dgrad_pre_bnsums_nhwc(const float* dy, const float* wt, float* dx, const float* bn_x,
+                                      const float* save_mean, const float* save_invstd, const float* weight,
+                                      const float* bias, float* rows, void* workspace, size_t workspace_bytes,
+                                      int N, int H, int W, int Ci, int Co, void* stream);
 /* t2o_conv3x3s2_dgrad_nhwc with wt = t2o_conv_weight_transform(w, wt, Co, Ci, 9, 0) supplied. */
 int t2o_conv3x3s2_dgrad_pre_nhwc(const float* dy, const float* wt, float* dx, void* workspace, size_t workspace_bytes,
                                  int N, int Ho, int Wo, int Ci, int Co, void* stream);

@@ -81,6 +81,7 @@ SIGNATURES = {
     't2o_conv3x3s2_dgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
     't2o_conv3x3s2_dgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_bn_relu_nhwc_bwd_acc': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _Z, _I, _I, _P]),
+    't2o_bn_relu_nhwc_bwd_partials_acc': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _Z, _I, _I, _P]),
     't2o_conv3x3_wgrad_acc_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     't2o_conv_weight_transform': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     't2o_conv_weight_transform_batch': (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
@@ -101,6 +102,8 @@ SIGNATURES = {
     't2o_wino_dy_transforms_ld': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_wino_dw_transform': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     't2o_conv3x3_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    't2o_conv3x3_dgrad_bnsums_rows': (_I, [_I, _I, _I, _I, _I]),
+    't2o_conv3x3_dgrad_pre_bnsums_nhwc': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_stem_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_stem_fwd_any': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -437,6 +437,14 @@ struct FwdArgs {
   const float* addend;  // null, or (N,H,W,Co): added to y in the epilogue (the data gradient of a block's first convolution
                         // plus the gradient its input receives through the identity shortcut: one pass instead of an add kernel)
   unsigned long long* stamps;   // diagnostic builds only
+  // kBnb (data gradient in front of a batch norm + ReLU, y = relu(bn(bn_x))): the sums of the batch norm's backward, per pixel
+  // tile and channel, of the gated gradient g = y' [bn_x * sc + sh > 0] and of g * xhat, straight from the accumulators
+  const float* bn_x;            // (N,H,W,Co): the batch norm's input (the forward convolution's output)
+  const float* bn_mean;         // (Co) batch mean, inverse standard deviation, gamma, beta
+  const float* bn_invstd;
+  const float* bn_w;
+  const float* bn_b;
+  float* bn_rows;               // (tiles_p, 2, Co)
 };
 
 constexpr int kFwdThreads = 512;
@@ -453,8 +461,12 @@ constexpr int kFwdWBuf = 3 * kFwdCo * 128;                      // [kw][co][32 c
 // two stages = 5-10 us before they are needed): with one workgroup per CU nothing else hides that round trip, and every
 // workgroup of a round reaches its epilogue at the same time -- loading after the loop cost 20 us (128 channels) to 58 us (64
 // channels: 67 MB) per launch over the same kernel without addend.
-template <int kBM, int kS = 1, bool kAdd = false>
+// kBnb: the epilogue also forms the backward sums of the batch norm this data gradient flows into (FwdArgs::bn_*): its input
+// bn_x is fetched like the addend, the sums leave like the forward's statistics -- the batch norm's own sums pass (one read
+// of the gradient and one of bn_x) is not launched.
+template <int kBM, int kS = 1, bool kAdd = false, bool kBnb = false>
 __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
+  static_assert(!(kAdd && kBnb), "one prefetched epilogue operand");
   constexpr int kFwdPix = 128 * kBM;                              // output pixels per workgroup
   constexpr int kFwdXPieces = (kFwdPix + 2 * kFwdHalo) / 8;       // pieces of 8 rows (34 / 18)
   constexpr int kFwdPlane = kFwdXPieces * 1024;                   // one plane of the x tile
@@ -636,16 +648,17 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
 #ifdef T2O_CONV_DIAG
   t_loop = __builtin_amdgcn_s_memtime();
 #endif
-  float pre[kAdd ? kBM : 1][16];
+  float pre[(kAdd || kBnb) ? kBM : 1][16];
   for (int st = 0; st < stages; st += 2) {
-    if constexpr (kAdd) {
-      if (st + 2 >= stages) {                              // (uniform) the last iteration: fetch the addend under its MFMAs
+    if constexpr (kAdd || kBnb) {
+      if (st + 2 >= stages) {                              // (uniform) the last iteration: fetch the operand under its MFMAs
+        const float* __restrict__ src = kAdd ? a.addend : a.bn_x;
 #pragma unroll
         for (int i = 0; i < kBM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int p = p0 + wm * 32 * kBM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            pre[i][r] = p < P ? a.addend[(size_t)p * a.Co + co0 + wn * 32 + ln] : 0.0f;
+            pre[i][r] = p < P ? src[(size_t)p * a.Co + co0 + wn * 32 + ln] : 0.0f;
           }
       }
     }
@@ -671,20 +684,36 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
   // Batch-norm statistics of the layer that follows, straight from the accumulators (a lane holds 16 * kBM pixels of
   // ONE channel): the statistics pass over y (one full read of the activation) is not needed.  Rows past the end
   // of the image batch accumulated zeros.  Fixed order: lane, its partner lane + 32, the four pixel waves.
-  if (a.stats) {                       // (kernel argument: uniform)
+  if (kBnb || a.stats) {               // (kernel argument: uniform)
     __shared__ float red[2][4][kFwdCo];
     float s1 = 0.0f, s2 = 0.0f;
+    if constexpr (kBnb) {
+      // the gate exactly as the batch norm's own backward evaluates it (t2o_norm.hip gated<false>): x * sc + sh > 0
+      const int c = co0 + wn * 32 + ln;
+      const float mean = a.bn_mean[c], invstd = a.bn_invstd[c];
+      const float sc = a.bn_w[c] * invstd, sh = a.bn_b[c] - mean * sc;
 #pragma unroll
-    for (int i = 0; i < kBM; ++i)
+      for (int i = 0; i < kBM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s1 += acc[i][r]; s2 += acc[i][r] * acc[i][r]; }
+        for (int r = 0; r < 16; ++r) {
+          const float x = pre[i][r];
+          const float g = (x * sc + sh > 0.0f) ? acc[i][r] : 0.0f;        // (rows past the batch: acc = 0)
+          s1 += g;
+          s2 += g * ((x - mean) * invstd);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kBM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1 += acc[i][r]; s2 += acc[i][r] * acc[i][r]; }
+    }
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lh == 0) { red[0][wm][wn * 32 + ln] = s1; red[1][wm][wn * 32 + ln] = s2; }
     __syncthreads();
     if (tid < 2 * kFwdCo) {
       const int which = tid / kFwdCo, c = tid % kFwdCo;
-      a.stats[((size_t)pt * 2 + which) * a.Co + co0 + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+      (kBnb ? a.bn_rows : a.stats)[((size_t)pt * 2 + which) * a.Co + co0 + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
     }
   }
 #ifdef T2O_CONV_DIAG
@@ -1507,9 +1536,11 @@ int fwd_tile_pixels(int P, int Co, int stride) {
   return 128 * bm;
 }
 
+struct BnbOperands { const float *x, *mean, *invstd, *w, *b; float* rows; };
+
 int launch_fwd(const float* x, const float* w, float* y, const float* zero, int N, int H, int W, int Ci, int Co, hipStream_t st,
-               int stride = 1, float* stats = nullptr, const float* addend = nullptr) {
-  FwdArgs a;
+               int stride = 1, float* stats = nullptr, const float* addend = nullptr, const BnbOperands* bnb = nullptr) {
+  FwdArgs a = {};
   a.x = x; a.w = w; a.y = y; a.zero = zero;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   const int P = N * H * W;
@@ -1520,7 +1551,12 @@ int launch_fwd(const float* x, const float* w, float* y, const float* zero, int 
   a.addend = addend;
   a.stamps = nullptr;
   const unsigned grid = (unsigned)(((a.tiles_p + 7) / 8) * 8 * a.tiles_n);
-  if (stride == 2) {
+  if (bnb) {
+    if (addend || stats || stride != 1) return T2O_EINVAL;
+    a.bn_x = bnb->x; a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_w = bnb->w; a.bn_b = bnb->b; a.bn_rows = bnb->rows;
+    if (bm == 1) k_conv3x3_fwd<1, 1, false, true><<<grid, kFwdThreads, 0, st>>>(a);
+    else k_conv3x3_fwd<2, 1, false, true><<<grid, kFwdThreads, 0, st>>>(a);
+  } else if (stride == 2) {
     if (addend) return T2O_EINVAL;                       // (no caller: the stride-2 data gradient is its own kernel)
     k_conv3x3_fwd<1, 2><<<grid, kFwdThreads, 0, st>>>(a);
   } else if (bm == 1) {
@@ -1859,6 +1895,26 @@ int t2o_conv3x3_dgrad_nhwc(const float* dy, const float* w, float* dx, void* wor
   k_conv_flip_weight<<<dim3((unsigned)(Ci / 32), (unsigned)(Co / 32), 9), kConvThreads, 0, st>>>(w, wt, Co, Ci, 1);
   const int rc = launch_fwd(dy, wt, dx, zeros, N, H, W, Co, Ci, st);
   return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_dgrad launch failed");
+}
+
+int t2o_conv3x3_dgrad_bnsums_rows(int N, int H, int W, int Ci, int Co) {
+  if (!fwd_supported(N, H, W, Co, Ci) || Ci % 64 != 0) return 0;
+  const int P = N * H * W, px = fwd_tile_pixels(P, Ci, 1);
+  return (P + px - 1) / px;
+}
+
+int t2o_conv3x3_dgrad_pre_bnsums_nhwc(const float* dy, const float* wt, float* dx, const float* bn_x, const float* save_mean,
+                                      const float* save_invstd, const float* weight, const float* bias, float* rows, void* workspace,
+                                      size_t workspace_bytes, int N, int H, int W, int Ci, int Co, void* stream) {
+  if (!dy || !wt || !dx || !bn_x || !save_mean || !save_invstd || !weight || !bias || !rows || misaligned16(dy, wt, dx))
+    return set_error(T2O_EINVAL, "conv3x3_dgrad_pre_bnsums: null or not 16-byte aligned pointer");
+  if (!fwd_supported(N, H, W, Co, Ci) || Co % 32 != 0 || Ci % 64 != 0)
+    return set_error(T2O_EUNSUPPORTED, "conv3x3_dgrad_pre_bnsums: Co must be a multiple of 32, Ci of 64, the image width of 8");
+  if (!workspace || workspace_bytes < fwd_zero_bytes(Co)) return set_error(T2O_EWORKSPACE, "conv3x3_dgrad_pre_bnsums: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const BnbOperands bnb = {bn_x, save_mean, save_invstd, weight, bias, rows};
+  const int rc = launch_fwd(dy, wt, dx, zero_region(workspace, fwd_zero_bytes(Co), st), N, H, W, Co, Ci, st, 1, nullptr, nullptr, &bnb);
+  return rc == T2O_OK ? T2O_OK : set_error(rc, "conv3x3_dgrad_pre_bnsums launch failed");
 }
 
 int t2o_conv3x3_dgrad_pre_nhwc(const float* dy, const float* wt, const float* addend, float* dx, void* workspace, size_t workspace_bytes,

@@ -839,6 +839,31 @@ int t2o_bn_relu_nhwc_bwd_acc(const float* x, const float* y, const float* dy, co
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
+// The same backward (no residual) when the producer of dy already left the sums: partial (partial_rows, 2, C) = per row block
+// the channels' sums of the gated gradient and of gated gradient * xhat (t2o_conv3x3_dgrad_pre_bnsums_nhwc's epilogue) -- the
+// sums pass over dy and x is not launched.
+int t2o_bn_relu_nhwc_bwd_partials_acc(const float* x, const float* dy, const float* weight, const float* bias,
+                                      const float* save_mean, const float* save_invstd, float* dx, float* dweight, float* dbias,
+                                      int relu, int accumulate, const float* partial, int partial_rows, void* workspace,
+                                      size_t workspace_bytes, int M, int C, void* stream) {
+  if (!x || M <= 0 || !nhwc_channels_ok(C) || !dy || !weight || !bias || !save_mean || !save_invstd || !dx)
+    return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd_partials: null pointer or bad shape (C must be a power of two in [4, 1024])");
+  if (!partial || partial_rows <= 0) return set_error(T2O_EINVAL, "bn_relu_nhwc_bwd_partials: no partial sums");
+  if (!workspace || workspace_bytes < t2o_bn_nhwc_workspace_bytes(M, C)) return set_error(T2O_EWORKSPACE, "bn_relu_nhwc_bwd_partials: workspace too small");
+  BnArgs a = {};
+  a.x = x; a.dy = dy; a.out = dx; a.weight = weight; a.bias = bias;
+  a.save_mean = const_cast<float*>(save_mean); a.save_invstd = const_cast<float*>(save_invstd);
+  a.dweight = dweight; a.dbias = dbias;
+  a.N = M; a.C = C; a.HW = 1; a.splits = 1; a.relu = relu; a.acc = accumulate ? 1 : 0;
+  a.partials = (double*)workspace;
+  a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
+  hipStream_t st = (hipStream_t)stream;
+  k_bn_nhwc_finalize<true><<<C / 4, kThreads, 0, st>>>(a, partial, partial_rows);
+  const size_t total4 = (size_t)M * (C >> 2);
+  k_bn_nhwc_bwd_apply<false><<<flat_grid(total4, 1, 2), kThreads, 0, st>>>(a, total4);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
+}
+
 int t2o_bn_relu_nhwc_bwd(const float* x, const float* y, const float* dy, const float* weight, const float* bias,
                          const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dweight,
                          float* dbias, int has_res, int relu, void* workspace, size_t workspace_bytes, int M, int C,

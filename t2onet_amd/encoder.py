@@ -31,6 +31,7 @@ from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_works
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
 _WINO_MIN_C = int(os.environ.get('T2O_WINOGRAD_MIN_C', '256'))
 _DUAL_BN = True      # a shortcut block's two batch norms in one pass each way (t2o_bn_dual_*); module switch for the tests
+_BN_SUMS_EPILOGUE = True     # bn1's backward sums from the epilogue of conv2's data gradient (direct kernels); switch for the tests
 
 
 def _fast_direct(stride, Hi, Wi, Wo):
@@ -558,16 +559,34 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co, slot2)
             da1 = torch.empty_like(rec['a1'])
+            rows1 = None                                   # bn1's backward sums, when conv2's data gradient leaves them
             if plan.wino(b.conv2, Hn, Wn):
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
             else:
-                dgrad3(b.conv2, dy2, da1, None, Hn, Wn, Hn, Wn)
+                C2o, C2i = b.conv2.weight.shape[0], b.conv2.weight.shape[1]
+                n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and _fast_direct(1, Hn, Wn, Wn)) else 0
+                if n_rows > 0:
+                    # a1 = relu(bn1(y1)) is this data gradient's only consumer: its epilogue forms bn1's backward sums
+                    rows1 = torch.empty(n_rows * 2 * C2i, dtype=torch.float32, device=dev)
+                    rc = lib.t2o_conv3x3_dgrad_pre_bnsums_nhwc(_ptr(dy2), _ptr(wt[id(b.conv2)]), _ptr(da1), _ptr(rec['y1']), _ptr(rec['m1']),
+                                                               _ptr(rec['i1']), _ptr(b.bn1.weight), _ptr(b.bn1.bias), _ptr(rows1),
+                                                               _ptr(conv_ws), conv_ws.numel(), N, Hn, Wn, C2i, C2o, st)
+                    _lib.check(rc, 't2o_conv3x3_dgrad_pre_bnsums_nhwc')
+                else:
+                    dgrad3(b.conv2, dy2, da1, None, Hn, Wn, Hn, Wn)
                 if slot2 is None:
                     wgrad3(b.conv2, rec['a1'], dy2, Hn, Wn, Hn, Wn)
             del dy2
             # a1 = relu(bn1(y1))
             slot1 = deferred(b.conv1)
-            dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co, slot1)
+            if rows1 is not None:
+                dy1 = slot1 if slot1 is not None else torch.empty_like(rec['y1'])
+                rc = lib.t2o_bn_relu_nhwc_bwd_partials_acc(_ptr(rec['y1']), _ptr(da1), _ptr(b.bn1.weight), _ptr(b.bn1.bias), _ptr(rec['m1']),
+                                                           _ptr(rec['i1']), _ptr(dy1), _ptr(g(b.bn1.weight)), _ptr(g(b.bn1.bias)), 1, acc,
+                                                           _ptr(rows1), rows1.numel() // (2 * Co), _ptr(bn_ws), bn_ws.numel(), M, Co, st)
+                _lib.check(rc, 't2o_bn_relu_nhwc_bwd_partials_acc')
+            else:
+                dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co, slot1)
             del da1
             dx = torch.empty_like(rec['x'])
             if plan.wino(b.conv1, Hc, Wc) and not len(b.shortcut):

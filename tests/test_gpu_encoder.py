@@ -313,3 +313,62 @@ def test_dual_batch_norm_of_shortcut_blocks_is_bit_identical_to_the_separate_pas
         assert torch.equal(res[True][2][n], res[False][2][n]), n
     for n in res[True][3]:
         assert torch.equal(res[True][3][n], res[False][3][n]), n
+
+
+@pytest.mark.parametrize('size', [(64, 256), (96, 160), (256, 256)])
+def test_batch_norm_backward_sums_from_the_data_gradient_epilogue(monkeypatch, size):
+    """bn1's backward sums formed in the epilogue of conv2's data gradient (t2o_conv3x3_dgrad_pre_bnsums_nhwc +
+    t2o_bn_relu_nhwc_bwd_partials_acc; the direct-kernel stages) against the batch norm's own sums pass: the same gated terms
+    added in another order -- outputs identical, gradients equal to fp32 summation noise."""
+    import t2onet_amd.encoder as E
+    N, (H, W) = 3, size
+    img = synth.images(N, H, W, 81).to(DEV)
+    gout = synth.uniform((N, 512), 82, -1.0, 1.0).to(DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, '_BN_SUMS_EPILOGUE', fused)
+        net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+        res[fused] = _run(net, img, gout)
+    assert torch.equal(res[True][0], res[False][0])
+    assert not all(torch.equal(res[True][2][n], res[False][2][n]) for n in res[True][2])      # (the fused form did run)
+    _close(res[True][1], res[False][1], 2e-5)
+    for n in res[True][2]:
+        _close(res[True][2][n], res[False][2][n], 2e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 64, 16, 24), (64, 64, 64, 64, 64), (8, 128, 128, 32, 32), (3, 128, 64, 8, 40)])
+def test_data_gradient_with_batch_norm_sums_epilogue(shape):
+    """t2o_conv3x3_dgrad_pre_bnsums_nhwc alone: dx bit-identical to the plain data gradient; the rows add up to the batch
+    norm backward's sums (fp64 reference: sum of g and of g * xhat per channel, g = dx gated by bn_x * sc + sh > 0)."""
+    import ctypes
+    import t2onet_amd.functional as T
+    from t2onet_amd import _lib
+    N, Ci, Co, H, W = shape
+    lib = _lib.load()
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    dy, w = cl(synth.uniform((N, Co, H, W), 91, -1.0, 1.0)), cl(synth.uniform((Co, Ci, 3, 3), 92, -0.2, 0.2))
+    bn_x = cl(synth.uniform((N, Ci, H, W), 93, -2.0, 2.0))
+    mean, invstd = synth.uniform((Ci,), 94, -0.3, 0.3).to(DEV), synth.uniform((Ci,), 95, 0.5, 2.0).to(DEV)
+    gamma, beta = synth.uniform((Ci,), 96, -1.5, 1.5).to(DEV), synth.uniform((Ci,), 97, -0.5, 0.5).to(DEV)
+    wt = T.conv_weight_transform(w, 9, True)
+    ref_dx = T.conv3x3_dgrad_pre(dy, wt, Ci)
+    n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, H, W, Ci, Co)
+    assert n_rows > 0
+    rows = torch.full((n_rows, 2, Ci), float('nan'), device=DEV)
+    dx = torch.empty_like(ref_dx)
+    ws = torch.zeros(64 << 10, dtype=torch.uint8, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.t2o_conv3x3_dgrad_pre_bnsums_nhwc(p(dy), p(wt), p(dx), p(bn_x), p(mean), p(invstd), p(gamma), p(beta), p(rows), p(ws), ws.numel(),
+                                               N, H, W, Ci, Co, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, 't2o_conv3x3_dgrad_pre_bnsums_nhwc')
+    assert torch.equal(dx, ref_dx)
+    sc = gamma * invstd
+    sh = beta - mean * sc
+    v = lambda t: t.view(1, -1, 1, 1)
+    gate = (bn_x * v(sc) + v(sh)) > 0
+    g = torch.where(gate, dx, torch.zeros_like(dx)).double()
+    xhat = ((bn_x - v(mean)) * v(invstd)).double()
+    want = torch.stack([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))])
+    got = rows.double().sum(0)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale, (float((got - want).abs().max()), scale)

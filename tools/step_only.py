@@ -19,6 +19,9 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 if os.environ.get('T2O_NO_DUAL_BN'):
     import t2onet_amd.encoder as _E
     _E._DUAL_BN = False
+if os.environ.get('T2O_NO_BN_SUMS_EPI'):
+    import t2onet_amd.encoder as _E2
+    _E2._BN_SUMS_EPILOGUE = False
 if os.environ.get('T2O_NO_ARENA'):
     Trainer._arena = lambda self, img, passes: None
 tr = Trainer(model, opt, graph_encoder=(sys.argv[3] != '0') if len(sys.argv) > 3 else True, graph_step=(sys.argv[2] != '0') if len(sys.argv) > 2 else True)
