@@ -139,7 +139,8 @@ def test_each_transform_kernel_matches_the_numpy_restatement():
     np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=0, atol=4e-6)
 
 
-@pytest.mark.parametrize('shape', [(16, 1024, 512, 512), (16, 4096, 256, 256), (3, 5, 64, 32), (2, 300, 128, 96), (1, 257, 192, 64), (4, 8, 64, 160)])
+@pytest.mark.parametrize('shape', [(16, 1024, 512, 512), (16, 4096, 256, 256), (3, 5, 64, 32), (2, 300, 128, 96), (1, 257, 192, 64), (4, 8, 64, 160),
+                                   (20, 3500, 256, 64), (9, 7500, 512, 96)])
 def test_own_batched_gemm_matches_fp64(shape):
     """t2o_gemm_nt_batched (k_gemm_nt): both tile widths, ragged M (rows past M re-read the last row), one and many stages."""
     import t2onet_amd.functional as T
