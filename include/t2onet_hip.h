@@ -608,6 +608,19 @@ int t2o_graph_memsets_to_kernels(void* graph, int* replaced);
 int t2o_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                   float beta2, float eps, int step, void* stream);
 
+/* ---- Winograd F(2x2,3x3) with V and M kept on chip (t2o_wino_fused.hip): conv2d(x, w, None, 1, 1) on NHWC activations for the
+ * stride-1 3x3 layers of the 64- / 128-channel stages (models/actor_resnet.py:24-44), H and W multiples of 16, Ci of 8, Co of
+ * 64 -- ONE launch per layer where t2o_wino_input_transform + t2o_gemm_nt_batched + t2o_wino_output_transform move 8x the
+ * activation through HBM.  uc = t2o_wino_u_chunked(U) with U = t2o_wino_weight_transform(w) (or of the mirrored transpose
+ * for the data gradient): (Ci/8, 16, Co, 8).  addend (N,H,W,Co) or NULL is added in the epilogue; stats or NULL receives
+ * (t2o_wino_fused_stats_rows, 2, Co) partial sums / sums of squares of y for t2o_bn_relu_nhwc_fwd_partials.  zeros: >= Ci*4 +
+ * 32 bytes of zeros, 16-byte aligned (t2o_conv_set_zero_region's block serves). */
+int t2o_wino_fused_supported(int N, int H, int W, int Ci, int Co);
+int t2o_wino_fused_stats_rows(int N, int H, int W);
+int t2o_wino_u_chunked(const float* U, float* Uc, int Cn, int Ck, void* stream);
+int t2o_wino_fused_conv_nhwc(const float* x, const float* uc, const float* addend, float* y, float* stats,
+                             const float* zeros, int N, int H, int W, int Ci, int Co, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,341 @@
+// t2o_wino_fused.hip -- Winograd F(2x2, 3x3) with V and M kept ON CHIP, for the stride-1 3x3 convolutions of the encoder's
+// 64- and 128-channel stages (models/actor_resnet.py:24-44 BasicBlock; 64 x 64 and 32 x 32 maps at bs = 64, 256 x 256 input).
+//
+//   The separate-pass pipeline of t2o_winograd.hip (input transform -> 16 GEMMs -> output transform) moves V and M, 4 x the
+//   activation each, through HBM: it wins at 256 / 512 channels (small maps) and loses badly at 64 / 128 (T2O_WINOGRAD_MIN_C
+//   = 128 measured +2 ms per step).  Here ONE launch does all of it per block of 8 x 8 tiles (16 x 16 output pixels of one
+//   image) x 64 output channels:
+//     * the 18 x 18 input patch of the block arrives by LDS-DMA in chunks of 8 input channels (32 bytes per pixel);
+//     * the workgroup transforms a chunk to V[xi][tile][8] in LDS (B^T d B: 32 add/sub per (tile, channel));
+//     * each of the 4 waves owns 32 tiles x 32 output channels of ALL 16 xi planes: 16 accumulator blocks of
+//       v_mfma_f32_32x32x2_f32 = 256 registers (one wave per SIMD, the 512-register budget); the U = G g G^T operand of a
+//       chunk (16 planes x 64 channels x 8, 32 KiB contiguous per plane in a chunk-major layout (Ci/8, 16, Co, 8)) arrives
+//       by LDS-DMA one chunk ahead (first version: straight from L2 into registers -- the compiler waited for all of a
+//       chunk's loads at its end and copied 64 registers: 140 us);
+//     * the output transform A^T M A happens in registers: a lane holds the same (tile, channel) element of every plane.
+//   Per chunk: 64 MFMAs per wave; DMA of chunk c + 2, transform of chunk c + 1 and the MFMAs of chunk c overlap, one barrier
+//   per chunk.  16 multiplies per output and channel pair instead of 36: 8.6 GFLOP for the layer that costs the direct kernel
+//   19.3.  Epilogue options of the direct kernels: addend (identity-shortcut gradient), the following batch norm's
+//   statistics (per block and channel: sum, sum of squares).
+//
+//   LDS layouts (all conflict-free for the accesses below; 4-byte banks, 64 of them):
+//     Xs[buf][slot][8 ci]: pixel (r, c) of the 18 x 18 patch in slot r * 20 + (c & 1) * 9 + (c >> 1) (even columns first: the
+//       transform's lanes step over tiles = column pairs), the two 16-byte halves of a slot swapped when (slot >> 3) & 1;
+//     Vs[buf][xi][tile][8 ci]: the two halves swapped when (tile >> 3) & 1.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "t2onet_hip.h"
+
+namespace t2o { int set_error(int code, const char* msg); }
+using t2o::set_error;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWfThreads = 256;
+constexpr int kXRow = 20;                        // slots per patch row (18 used)
+constexpr int kXPieces = 12;                     // 1 KiB DMA pieces per chunk: 18 * 20 slots * 32 B = 11,520 B
+constexpr int kXBuf = kXPieces * 1024;
+constexpr int kVBuf = 16 * 64 * 32;              // 16 planes x 64 tiles x 32 B
+constexpr int kUBuf = 16 * 64 * 32;              // 16 planes x 64 output channels x 32 B
+
+struct WfArgs {
+  const float* x;        // (N,H,W,Ci)
+  const float* uc;       // (Ci/8, 16, Co, 8) chunk-major U = G g G^T
+  float* y;              // (N,H,W,Co)
+  const float* zero;     // >= Ci * 4 + 32 bytes of zeros
+  const float* addend;   // null or (N,H,W,Co)
+  float* stats;          // null or (blocks, 2, Co)
+  int N, H, W, Ci, Co;
+  int blocks, tiles_n;   // 16 x 16 pixel blocks (N * H/16 * W/16), 64-channel tiles
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// LDS-DMA, per-lane 64-bit address form: lane l's 16 bytes at addr[l] go to LDS byte lds_dst + 16 l
+__device__ __forceinline__ void glds16v(const void* addr, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(addr), "s"(lds_dst) : "memory");
+}
+// ... scalar base + 32-bit lane offset form
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int kFirst, int kLast, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (kFirst < kLast) {
+    f(std::integral_constant<int, kFirst>{});
+    static_for<kFirst + 1, kLast>(f);
+  }
+}
+
+template <bool kAdd>
+__global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
+  __shared__ __attribute__((aligned(16))) char Xs[2][kXBuf];
+  __shared__ __attribute__((aligned(16))) char Vs[2][kVBuf];
+  __shared__ __attribute__((aligned(16))) char Us[2][kUBuf];
+
+  // workgroup -> (pixel block, channel tile): the channel tiles of one block are neighbours inside an XCD
+  const int b = blockIdx.x;
+  const int xcd = b % 8, k8 = b / 8;
+  const int blk = (k8 / a.tiles_n) * 8 + xcd, ct = k8 % a.tiles_n;
+  if (blk >= a.blocks) return;
+  const int bw = a.W >> 4, bh = a.H >> 4;
+  const int n = blk / (bh * bw), rem = blk - n * bh * bw, by = rem / bw, bx = rem - by * bw;
+  const int co0 = ct * 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int th = wave >> 1, ch = wave & 1;
+  const int ln = lane & 31, lh = lane >> 5;
+  const int chunks = a.Ci >> 3;
+
+  // ---- DMA: this wave's pieces wave, wave + 4, wave + 8; per lane the global address of its 16 bytes (chunk 0)
+  const char* xaddr[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int piece = wave + 4 * k;
+    const int slot = (piece * 64 + lane) >> 1, phys = lane & 1;
+    const int half = phys ^ ((slot >> 3) & 1);
+    const int r = slot / kXRow, q = slot - r * kXRow;
+    const int c = q < 9 ? 2 * q : 2 * (q - 9) + 1;
+    const int h = by * 16 - 1 + r, w = bx * 16 - 1 + c;
+    const bool ok = r < 18 && q < 18 && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+    xaddr[k] = ok ? (const char*)(a.x + (((size_t)n * a.H + h) * a.W + w) * a.Ci) + half * 16 : (const char*)a.zero + half * 16;
+  }
+  const unsigned lds_x = lds_addr(&Xs[0][0]);
+  auto dma_chunk = [&](int buf) {                        // the chunk the addresses stand at; advances them
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      glds16v(xaddr[k], lds_x + (unsigned)(buf * kXBuf + (wave + 4 * k) * 1024));
+      xaddr[k] += 32;
+    }
+  };
+
+  // ---- transform: this thread's (tile, channel pair): tile = 16 wave + 8 tyl + tx, pair cp (channels 2 cp, 2 cp + 1)
+  const int tx = lane & 7, tyl = (lane >> 3) & 1, cp = lane >> 4;
+  const int tty = 2 * wave + tyl;
+  unsigned xoff[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = (2 * tty + i) * kXRow + (j & 1) * 9 + tx + (j >> 1);
+      xoff[i][j] = (unsigned)(slot * 32 + (((cp >> 1) ^ ((slot >> 3) & 1)) << 4) + (cp & 1) * 8);
+    }
+  const unsigned voff_w = (unsigned)((16 * wave + 8 * tyl + tx) * 32 + (((cp >> 1) ^ tyl) << 4) + (cp & 1) * 8);
+  float2 d[4][4];
+  auto transform_load = [&](int xb) {
+    const char* xs = &Xs[xb][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const float2*>(xs + xoff[i][j]);
+  };
+  auto transform_store = [&](int vb) {
+    char* vs = &Vs[vb][0];
+    // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3), then the same along the columns (t2o_winograd.hip k_wino_input)
+    float2 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[0][j] = make_float2(d[0][j].x - d[2][j].x, d[0][j].y - d[2][j].y);
+      r[1][j] = make_float2(d[1][j].x + d[2][j].x, d[1][j].y + d[2][j].y);
+      r[2][j] = make_float2(d[2][j].x - d[1][j].x, d[2][j].y - d[1][j].y);
+      r[3][j] = make_float2(d[1][j].x - d[3][j].x, d[1][j].y - d[3][j].y);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float2*>(vs + (4 * i + 0) * 2048 + voff_w) = make_float2(r[i][0].x - r[i][2].x, r[i][0].y - r[i][2].y);
+      *reinterpret_cast<float2*>(vs + (4 * i + 1) * 2048 + voff_w) = make_float2(r[i][1].x + r[i][2].x, r[i][1].y + r[i][2].y);
+      *reinterpret_cast<float2*>(vs + (4 * i + 2) * 2048 + voff_w) = make_float2(r[i][2].x - r[i][1].x, r[i][2].y - r[i][1].y);
+      *reinterpret_cast<float2*>(vs + (4 * i + 3) * 2048 + voff_w) = make_float2(r[i][1].x - r[i][3].x, r[i][1].y - r[i][3].y);
+    }
+  };
+
+  // ---- MFMA operands: A = V rows (this wave's 32 tiles), B = U rows (its 32 output channels), both from LDS
+  const int atile = 32 * th + ln;
+  const unsigned aoff = (unsigned)(atile * 32 + ((lh ^ ((atile >> 3) & 1)) << 4));
+  const unsigned boff = (unsigned)((32 * ch + ln) * 32 + (lh << 4));
+  // U chunk c = 16 planes x 64 channels x 32 bytes = 32 pieces, contiguous per plane in the chunk-major layout: piece j of
+  // this wave (plane xi = 2 j + (wave >> 1), half wave & 1) is 1 KiB at ((c * 16 + xi) * Co + co0 + 32 (wave & 1)) * 32 bytes
+  const unsigned lds_u = lds_addr(&Us[0][0]);
+  const char* ubase = (const char*)a.uc + ((size_t)co0 + 32 * (wave & 1)) * 32;
+  const unsigned ulane = (unsigned)(lane * 16);
+  const size_t uplane = (size_t)a.Co * 32;                // bytes per (chunk, xi) plane
+  auto dma_u = [&](int cc, int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int xi = 2 * j + (wave >> 1);
+      glds16(ulane, ubase + ((size_t)cc * 16 + xi) * uplane, lds_u + (unsigned)(buf * kUBuf + xi * 2048 + (wave & 1) * 1024));
+    }
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+  float4 fa[2][2], fb[2][2];                              // fragments of a plane pair, double-buffered across pairs
+  auto frag_read = [&](auto pc, auto slotc, int buf) {
+    constexpr int p = decltype(pc)::value, slot = decltype(slotc)::value;
+    fa[slot][0] = *reinterpret_cast<const float4*>(&Vs[buf][0] + p * 2048 + aoff);
+    fa[slot][1] = *reinterpret_cast<const float4*>(&Vs[buf][0] + (p + 1) * 2048 + aoff);
+    fb[slot][0] = *reinterpret_cast<const float4*>(&Us[buf][0] + p * 2048 + boff);
+    fb[slot][1] = *reinterpret_cast<const float4*>(&Us[buf][0] + (p + 1) * 2048 + boff);
+  };
+  auto mfma_pair = [&](auto pc, auto slotc) {
+    constexpr int p = decltype(pc)::value, slot = decltype(slotc)::value;
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].x, fb[slot][0].x, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].x, fb[slot][1].x, acc[p + 1], 0, 0, 0);
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].y, fb[slot][0].y, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].y, fb[slot][1].y, acc[p + 1], 0, 0, 0);
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].z, fb[slot][0].z, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].z, fb[slot][1].z, acc[p + 1], 0, 0, 0);
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].w, fb[slot][0].w, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].w, fb[slot][1].w, acc[p + 1], 0, 0, 0);
+  };
+  // plane pairs kFirst .. kFirst + 3 of a chunk: the next pair's fragments are requested before the current pair's MFMAs
+  auto mfma_half = [&](auto firstc, int buf) {
+    constexpr int kFirst = decltype(firstc)::value;       // 0 or 4 (pair index)
+    static_for<0, 4>([&](auto kc) {
+      constexpr int k = kFirst + decltype(kc)::value;
+      if constexpr (k + 1 < 8) frag_read(std::integral_constant<int, 2 * (k + 1)>{}, std::integral_constant<int, (k + 1) & 1>{}, buf);
+      mfma_pair(std::integral_constant<int, 2 * k>{}, std::integral_constant<int, k & 1>{});
+    });
+  };
+
+  // ---- pipeline: DMA x(c + 2), U(c + 1) | transform(c + 1) | MFMA(c), one barrier per chunk
+  dma_chunk(0);
+  dma_u(0, 0);
+  vm_wait0();
+  __syncthreads();
+  if (chunks > 1) dma_chunk(1);
+  transform_load(0);
+  transform_store(0);
+  vm_wait0();
+  __syncthreads();
+  for (int c = 0; c < chunks; ++c) {
+    const bool more = c + 1 < chunks;
+    const int buf = c & 1;
+    frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, buf);
+    if (c + 2 < chunks) dma_chunk(buf);                   // Xs[c & 1] was read by transform(c): free since the last barrier
+    if (more) {
+      dma_u(c + 1, buf ^ 1);                              // Us[(c + 1) & 1] was read by the MFMAs of chunk c - 1
+      transform_load(buf ^ 1);                            // the patch values travel while the first half of the planes is multiplied
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(std::integral_constant<int, 0>{}, buf);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) transform_store(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(std::integral_constant<int, 4>{}, buf);
+    vm_wait0();
+    __syncthreads();
+  }
+
+  // ---- output transform in registers: y tile = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]; lane = channel co0 + 32 ch + ln,
+  // register r = tile row (r & 3) + 8 (r >> 2) + 4 lh of this wave's 32 tiles
+  const int co = co0 + 32 * ch + ln;
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = 32 * th + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int ty = t >> 3, txx = t & 7;
+    float m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[i][j] = acc[4 * i + j][r];
+    float q[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q[0][j] = (m[0][j] + m[1][j]) + m[2][j];
+      q[1][j] = (m[1][j] - m[2][j]) - m[3][j];
+    }
+    const int oh = by * 16 + 2 * ty, ow = bx * 16 + 2 * txx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float o0 = (q[i][0] + q[i][1]) + q[i][2];
+      float o1 = (q[i][1] - q[i][2]) - q[i][3];
+      const size_t off = (((size_t)n * a.H + oh + i) * a.W + ow) * a.Co + co;
+      if constexpr (kAdd) { o0 += a.addend[off]; o1 += a.addend[off + a.Co]; }
+      a.y[off] = o0;
+      a.y[off + a.Co] = o1;
+      s1 += o0 + o1;
+      s2 += o0 * o0 + o1 * o1;
+    }
+  }
+  if (a.stats) {                                          // (uniform) fixed order: lane, its partner lane + 32, the two tile waves
+    __shared__ float red[2][2][64];
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lh == 0) { red[0][th][32 * ch + ln] = s1; red[1][th][32 * ch + ln] = s2; }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      a.stats[((size_t)blk * 2 + which) * a.Co + co0 + c] = red[which][0][c] + red[which][1][c];
+    }
+  }
+}
+
+// U (16, Cn, Ck) -> chunk-major (Ck/8, 16, Cn, 8)
+__global__ __launch_bounds__(256) void k_wino_u_chunked(const float* __restrict__ U, float* __restrict__ Uc, int Cn, int Ck) {
+  const size_t total = (size_t)16 * Cn * Ck / 4;          // float4s
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  // destination float4 index i = ((cc * 16 + xi) * Cn + n) * 2 + half
+  const int half = (int)(i & 1);
+  const size_t j = i >> 1;
+  const int nn = (int)(j % Cn);
+  const size_t k = j / Cn;
+  const int xi = (int)(k & 15), cc = (int)(k >> 4);
+  reinterpret_cast<float4*>(Uc)[i] = *reinterpret_cast<const float4*>(U + ((size_t)xi * Cn + nn) * Ck + cc * 8 + half * 4);
+}
+
+bool wf_supported(int N, int H, int W, int Ci, int Co) {
+  return N > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0 && Ci >= 8 && Ci % 8 == 0 && Co >= 64 && Co % 64 == 0 &&
+         (size_t)N * H * W * (size_t)(Ci > Co ? Ci : Co) < ((size_t)1 << 40);
+}
+
+}  // namespace
+
+extern "C" {
+
+int t2o_wino_fused_supported(int N, int H, int W, int Ci, int Co) { return wf_supported(N, H, W, Ci, Co) ? 1 : 0; }
+
+int t2o_wino_fused_stats_rows(int N, int H, int W) { return (H % 16 == 0 && W % 16 == 0 && N > 0) ? N * (H / 16) * (W / 16) : 0; }
+
+int t2o_wino_u_chunked(const float* U, float* Uc, int Cn, int Ck, void* stream) {
+  if (!U || !Uc || Cn <= 0 || Ck <= 0 || Ck % 8 != 0) return set_error(T2O_EINVAL, "wino_u_chunked: null pointer or Ck not a multiple of 8");
+  const size_t total = (size_t)16 * Cn * Ck / 4;
+  k_wino_u_chunked<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(U, Uc, Cn, Ck);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_u_chunked launch failed");
+}
+
+int t2o_wino_fused_conv_nhwc(const float* x, const float* uc, const float* addend, float* y, float* stats, const float* zeros,
+                             int N, int H, int W, int Ci, int Co, void* stream) {
+  if (!x || !uc || !y || !zeros) return set_error(T2O_EINVAL, "wino_fused_conv: null pointer");
+  if (((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(uc) | reinterpret_cast<size_t>(zeros)) & 15) != 0)
+    return set_error(T2O_EINVAL, "wino_fused_conv: x, uc and zeros must be 16-byte aligned");
+  if (!wf_supported(N, H, W, Ci, Co)) return set_error(T2O_EUNSUPPORTED, "wino_fused_conv: H, W multiples of 16, Ci of 8, Co of 64");
+  WfArgs a = {};
+  a.x = x; a.uc = uc; a.y = y; a.zero = zeros; a.addend = addend; a.stats = stats;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.blocks = N * (H / 16) * (W / 16);
+  a.tiles_n = Co / 64;
+  const unsigned grid = (unsigned)(((a.blocks + 7) / 8) * 8 * a.tiles_n);
+  hipStream_t st = (hipStream_t)stream;
+  if (addend) k_wino_fused<true><<<grid, kWfThreads, 0, st>>>(a);
+  else k_wino_fused<false><<<grid, kWfThreads, 0, st>>>(a);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_fused_conv launch failed");
+}
+
+}  // extern "C"

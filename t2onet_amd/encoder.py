@@ -24,13 +24,16 @@ import os
 import torch
 
 from . import _lib
-from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_wgrad_nhwc, wino_input,
+from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_fused_conv_nhwc, wino_wgrad_nhwc, wino_input,
                          wino_backward_nhwc, wino_dw_from)
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
 _WINO_MIN_C = int(os.environ.get('T2O_WINOGRAD_MIN_C', '256'))
 _DUAL_BN = True      # a shortcut block's two batch norms in one pass each way (t2o_bn_dual_*); module switch for the tests
+# Winograd F(2x2,3x3) with V and M kept on chip for the stride-1 layers of the 64- / 128-channel stages (t2o_wino_fused.hip);
+# T2O_WINOGRAD_FUSED=0: the direct kernels there (A/B)
+_WINO_FUSED = os.environ.get('T2O_WINOGRAD_FUSED', '1') != '0'
 _BN_SUMS_EPILOGUE = True     # bn1's backward sums from the epilogue of conv2's data gradient (direct kernels); switch for the tests
 
 
@@ -96,6 +99,34 @@ class TrunkPlan:
                 and w.shape[0] <= 1024 and w.shape[1] <= 1024 and (w.shape[0] & (w.shape[0] - 1)) == 0 and (w.shape[1] & (w.shape[1] - 1)) == 0
                 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0)          # (t2o_gemm_tn_batched: 128-wide tiles)
 
+    def fused_wino(self, conv, H, W):
+        """The on-chip Winograd kernel for this layer?  Stride 1, <= 128 channels (where the separate-pass pipeline loses: V and
+        M are 4x the activation each), maps that are multiples of 16 (8 x 8 tiles per workgroup)."""
+        w = conv.weight
+        return (_WINO_FUSED and _WINOGRAD and conv.stride[0] == 1 and not self.wino(conv, H, W) and w.shape[0] in (64, 128)
+                and w.shape[1] in (64, 128) and H % 16 == 0 and W % 16 == 0)
+
+    def fused_convs(self):
+        return [c for b in self.blocks for c in (b.conv1, b.conv2)
+                if c.stride[0] == 1 and c.weight.shape[0] in (64, 128) and c.weight.shape[1] in (64, 128)] if (_WINO_FUSED and _WINOGRAD) else []
+
+    def _chunked(self, lib, st, store, convs, src, swap):
+        """store[('c', id(conv))] = chunk-major Winograd filters (Ck/8, 16, Cn, 8) of src(conv) (Cn,3,3,Ck) for the on-chip kernel."""
+        ujobs = []
+        for conv in convs:
+            w = conv.weight
+            Cn, Ck = (w.shape[1], w.shape[0]) if swap else (w.shape[0], w.shape[1])
+            u = store.get(('u', id(conv)))
+            if u is None or u.device != w.device:
+                u = store[('u', id(conv))] = torch.empty((16, Cn, Ck), dtype=torch.float32, device=w.device)
+                store[('c', id(conv))] = torch.empty((Ck // 8, 16, Cn, 8), dtype=torch.float32, device=w.device)
+            ujobs.append((src(conv), u, Cn, Ck, store[('c', id(conv))]))
+        if ujobs:
+            _batched(lib.t2o_wino_weight_transform_batch, 't2o_wino_weight_transform_batch', st,
+                     [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
+            for _, u, Cn, Ck, uc in ujobs:
+                _lib.check(lib.t2o_wino_u_chunked(_ptr(u), _ptr(uc), Cn, Ck, st), 't2o_wino_u_chunked')
+
     def wino_convs(self):
         return [c for b in self.blocks for c in (b.conv1, b.conv2) if c.stride[0] == 1 and c.weight.shape[0] >= _WINO_MIN_C and c.weight.shape[1] >= _WINO_MIN_C
                 and c.weight.shape[0] % 128 == 0 and c.weight.shape[1] % 128 == 0]
@@ -117,6 +148,7 @@ class TrunkPlan:
         if ujobs:
             _batched(lib.t2o_wino_weight_transform_batch, 't2o_wino_weight_transform_batch', st,
                      [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
+        self._chunked(lib, st, uf, self.fused_convs(), lambda conv: conv.weight, False)
         if self.persistent_wt:
             self._uf, self._uf_valid, self._uf_ver = uf, True, self._versions()
         return uf
@@ -171,6 +203,7 @@ class TrunkPlan:
                 ub[id(conv)] = u
             _batched(lib.t2o_wino_weight_transform_batch, 't2o_wino_weight_transform_batch', st,
                      [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
+        self._chunked(lib, st, ub, self.fused_convs(), lambda conv: wt[id(conv)], True)     # data gradient: of the mirrored transpose
         wt['wino'] = ub
         if self.persistent_wt:
             self._wt, self._wt_valid, self._ub, self._wt_ver = wt, True, ub, self._versions()
@@ -372,6 +405,8 @@ class _TrunkFn(torch.autograd.Function):
                                           v_out=arena.wino_slot('V', conv, apass) if apass is not None else None)
                 kept_v[id(conv)] = keep[0]                     # (4x the layer's input: its weight gradient starts from it)
                 return y, stats
+            if plan.fused_wino(conv, Hi, Wi):
+                return wino_fused_conv_nhwc(x, uf[('c', id(conv))], Nn, Hi, Wi, None, True)
             y = _nhwc(Nn, Ho, Wo, Co, dev)
             if _fast_direct(s, Hi, Wi, Wo):
                 stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(Nn, Ho, Wo, Co, s), 2, Co), dtype=torch.float32, device=dev)
@@ -515,6 +550,9 @@ class _TrunkFn(torch.autograd.Function):
             if plan.wino(conv, Hi, Wi):
                 wino_conv_nhwc(dy, wt['wino'][id(conv)], N, Hi, Wi, addend, False, out=dx)
                 return
+            if plan.fused_wino(conv, Hi, Wi):
+                wino_fused_conv_nhwc(dy, wt['wino'][('c', id(conv))], N, Hi, Wi, addend, False, out=dx)
+                return
             if _fast_direct(s, Hi, Wi, Wn):
                 if s == 1:
                     rc = lib.t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy), _ptr(wt[id(conv)]), _ptr(addend), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
@@ -564,7 +602,7 @@ class _TrunkFn(torch.autograd.Function):
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
             else:
                 C2o, C2i = b.conv2.weight.shape[0], b.conv2.weight.shape[1]
-                n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and _fast_direct(1, Hn, Wn, Wn)) else 0
+                n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and _fast_direct(1, Hn, Wn, Wn) and not plan.fused_wino(b.conv2, Hn, Wn)) else 0
                 if n_rows > 0:
                     # a1 = relu(bn1(y1)) is this data gradient's only consumer: its epilogue forms bn1's backward sums
                     rows1 = torch.empty(n_rows * 2 * C2i, dtype=torch.float32, device=dev)

@@ -497,6 +497,14 @@ def _conv_workspace(device, need):
     return torch.empty(need, dtype=torch.uint8, device=device)
 
 
+def _zero_block(device):
+    """The persistent 64 KiB block of zeros registered with the library (padding source of the LDS-DMA kernels)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _conv_zeros:
+        _conv_workspace(device, 256)
+    return _conv_zeros[idx]
+
+
 def conv3x3_forward(x, weight, want_stats=False):
     """conv2d(x, weight, None, 1, 1) on the fp32 matrix cores (t2o_conv3x3_fwd_nhwc).  x (N,Ci,H,W) and weight
     (Co,Ci,3,3) channels-last; returns y (N,Co,H,W) channels-last.  want_stats: returns (y, stats) with stats
@@ -1497,6 +1505,28 @@ def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_
     y = out if out is not None else torch.empty((N, H, W, Co), dtype=torch.float32, device=dev)
     stats = torch.empty((lib.t2o_wino_stats_rows(N, H, W, Co), 2, Co), dtype=torch.float32, device=dev) if want_stats else None
     _lib.check(lib.t2o_wino_output_transform(_ptr(M), _ptr(addend), _ptr(y), _ptr(stats), N, H, W, Co, st), 't2o_wino_output_transform')
+    return y, stats
+
+
+def wino_u_chunked(U):
+    """U (16,Cn,Ck) -> the chunk-major layout (Ck/8, 16, Cn, 8) the on-chip Winograd kernel streams (t2o_wino_u_chunked)."""
+    _, Cn, Ck = U.shape
+    Uc = torch.empty((Ck // 8, 16, Cn, 8), dtype=torch.float32, device=U.device)
+    _lib.check(_lib.load().t2o_wino_u_chunked(_ptr(U), _ptr(Uc), Cn, Ck, _stream(U.device)), 't2o_wino_u_chunked')
+    return Uc
+
+
+def wino_fused_conv_nhwc(x, Uc, N, H, W, addend=None, want_stats=False, out=None):
+    """x (N,H,W,Ci) NHWC buffer, Uc = wino_u_chunked(U) -> y (N,H,W,Co) (+ addend) [, stats rows]: Winograd F(2x2,3x3) in ONE
+    launch, V and M never leave the chip (t2o_wino_fused_conv_nhwc; H, W multiples of 16, Co of 64)."""
+    lib = _lib.load()
+    dev = x.device
+    Ci, Co = Uc.shape[0] * 8, Uc.shape[2]
+    y = out if out is not None else torch.empty((N, H, W, Co), dtype=torch.float32, device=dev)
+    stats = torch.empty((lib.t2o_wino_fused_stats_rows(N, H, W), 2, Co), dtype=torch.float32, device=dev) if want_stats else None
+    zeros = _zero_block(dev)
+    _lib.check(lib.t2o_wino_fused_conv_nhwc(_ptr(x), _ptr(Uc), _ptr(addend), _ptr(y), _ptr(stats), _ptr(zeros), N, H, W, Ci, Co, _stream(dev)),
+               't2o_wino_fused_conv_nhwc')
     return y, stats
 
 

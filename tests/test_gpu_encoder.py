@@ -325,6 +325,7 @@ def test_batch_norm_backward_sums_from_the_data_gradient_epilogue(monkeypatch, s
     img = synth.images(N, H, W, 81).to(DEV)
     gout = synth.uniform((N, 512), 82, -1.0, 1.0).to(DEV)
     res = {}
+    monkeypatch.setattr(E, '_WINO_FUSED', False)            # (at 256 x 256 the on-chip Winograd kernel would take these layers)
     for fused in (True, False):
         monkeypatch.setattr(E, '_BN_SUMS_EPILOGUE', fused)
         net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
@@ -372,3 +373,23 @@ def test_data_gradient_with_batch_norm_sums_epilogue(shape):
     got = rows.double().sum(0)
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 2e-5 * scale, (float((got - want).abs().max()), scale)
+
+
+@pytest.mark.parametrize('size', [(256, 256), (128, 384)])
+def test_on_chip_winograd_stages_against_the_direct_kernels(monkeypatch, size):
+    """The 64- / 128-channel stride-1 layers on t2o_wino_fused_conv_nhwc (forward and data gradient) against the same trunk
+    on the direct kernels: output, image gradient and every parameter gradient to Winograd's fp32 accuracy."""
+    import t2onet_amd.encoder as E
+    N, (H, W) = 2, size
+    img = synth.images(N, H, W, 85).to(DEV)
+    gout = synth.uniform((N, 512), 86, -1.0, 1.0).to(DEV)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(E, '_WINO_FUSED', fused)
+        net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+        res[fused] = _run(net, img, gout)
+    assert not torch.equal(res[True][0], res[False][0])      # (two algorithms did run)
+    _close(res[True][0], res[False][0], 2e-5)
+    _close(res[True][1], res[False][1], 1e-4)
+    for n in res[True][2]:
+        _close(res[True][2][n], res[False][2][n], 1e-4)

@@ -215,3 +215,39 @@ def test_batched_weight_transforms_equal_the_single_ones():
     _batched(lib.t2o_wino_weight_transform_batch, 'batch', st, banks, us, [[b.shape[0] for b in banks], [b.shape[3] for b in banks]])
     for b, u in zip(banks, us):
         assert torch.equal(u, T.wino_weight(b, b.shape[0], b.shape[3]))
+
+
+# (N, Ci, Co, H, W): the 64- and 128-channel stage shapes (small batch), several channel tiles, Ci != Co, one block, wide maps
+WF_SHAPES = [(2, 64, 64, 16, 16), (3, 64, 64, 32, 48), (2, 128, 128, 32, 32), (1, 64, 128, 16, 32), (2, 128, 64, 48, 16), (1, 8, 64, 16, 16),
+             (5, 64, 64, 64, 64)]
+
+
+@pytest.mark.parametrize('shape', WF_SHAPES)
+@pytest.mark.parametrize('with_addend', [False, True])
+def test_on_chip_winograd_matches_conv2d_fp64(shape, with_addend):
+    """t2o_wino_fused_conv_nhwc (input transform, 16 products and output transform in one launch, V and M in LDS / registers)
+    against fp64 conv2d: Winograd F(2x2,3x3) in fp32 is good to a few 1e-6 of the output scale; the batch-norm statistics
+    rows add up to the sums of y and y^2; a repeat is bit-identical."""
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    dev = torch.device('cuda:0')
+    x = synth.uniform((N, Ci, H, W), 1801, -1.0, 1.0)
+    w = synth.uniform((Co, Ci, 3, 3), 1802, -1.0, 1.0)
+    add = synth.uniform((N, Co, H, W), 1803, -1.0, 1.0) if with_addend else None
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    if with_addend:
+        ref = ref + add.double()
+    xh = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    U = T.wino_weight(w.to(dev).permute(0, 2, 3, 1).contiguous(), Co, Ci)
+    Uc = T.wino_u_chunked(U)
+    assert torch.equal(Uc.permute(1, 2, 0, 3).reshape(16, Co, Ci), U)
+    ah = None if add is None else add.to(dev).permute(0, 2, 3, 1).contiguous()
+    y, stats = T.wino_fused_conv_nhwc(xh, Uc, N, H, W, ah, want_stats=True)
+    scale = float(ref.abs().max())
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref).abs().max()) <= 1e-5 * scale, float((got - ref).abs().max()) / scale
+    s = stats.double().sum(0).cpu()
+    want = torch.stack([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
+    assert float((s - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    y2, stats2 = T.wino_fused_conv_nhwc(xh, Uc, N, H, W, ah, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(stats, stats2)
