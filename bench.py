@@ -727,6 +727,9 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             for conv in (blk.conv1, blk.conv2):
                 if plan.wino(conv, hh, ww):
                     wino_saved += 3 * 5 * 2.0 * 9 * conv.weight.shape[0] * conv.weight.shape[1] * B * hh * ww * (1.0 - 16.0 / 36.0)
+                elif conv is not blk.conv1 or s1 == 1:
+                    if plan.fused_wino(conv, hh, ww):      # on-chip Winograd: forward + data gradient only (the weight gradient stays direct)
+                        wino_saved += 2 * 5 * 2.0 * 9 * conv.weight.shape[0] * conv.weight.shape[1] * B * hh * ww * (1.0 - 16.0 / 36.0)
     executed = flop - wino_saved
     finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())   # (a step that produced inf/nan gradients is no measurement)
     if not finite:
@@ -817,17 +820,54 @@ def conv_kernel_table(B, H, W, device, reps=40):
                 'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2), 'effective': True,
                 'kernel': ('k_wino_input + k_gemm_nt (16 GEMMs) + k_wino_output<stats>' if name == 'wino_fwd'
                            else 'k_wino_dy + k_gemm_tn (16 GEMMs over the tiles) + k_wino_dw (V kept from the forward)')}
-    dom = [v for k, v in rows.items() if v['kernel'] == 'k_conv3x3_fwd<2,1>' and ('_c64_' in k or '_c128_' in k)]
+    # the kernel that runs these layers in the train step since round 4: Winograd F(2x2,3x3) with V and M kept on chip
+    for C, div in ((64, 4), (128, 8)):
+        h, w = H // div, W // div
+        if not lib.t2o_wino_fused_supported(B, h, w, C, C):
+            continue
+        x = torch.rand(B, h, w, C, generator=g).to(device) - 0.5
+        wt = (torch.rand(C, 3, 3, C, generator=g).to(device) - 0.5) * 0.05
+        Uc = T.wino_u_chunked(T.wino_weight(wt, C, C))
+        add = torch.rand(B, h, w, C, generator=g).to(device)
+        y = torch.empty_like(x)
+        flop = 2.0 * 9 * C * C * B * h * w
+        for name, fn in (('onchip_wino_fwd', lambda: T.wino_fused_conv_nhwc(x, Uc, B, h, w, None, True, out=y)),
+                         ('onchip_wino_dgrad', lambda: T.wino_fused_conv_nhwc(x, Uc, B, h, w, None, False, out=y)),
+                         ('onchip_wino_dgrad_addend', lambda: T.wino_fused_conv_nhwc(x, Uc, B, h, w, add, False, out=y))):
+            for _ in range(3):
+                fn()
+            evs = []
+            for _ in range(max(reps // 10, 2)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in evs) / (len(evs) * 10)
+            rows['%s_c%d_%dx%d' % (name, C, h, w)] = {
+                'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2), 'effective': True,
+                'executed_GFLOP': round(flop * 16.0 / 36.0 / 1e9, 3), 'executed_TFLOPs': round(flop * 16.0 / 36.0 / ms / 1e9, 2),
+                'kernel': 'k_wino_fused'}
+    dom = [v for k, v in rows.items() if v['kernel'] == 'k_wino_fused' and '_addend' not in k]
+    if not dom:                                             # (an image size the on-chip kernel does not take: the direct kernel runs)
+        dom = [v for k, v in rows.items() if v['kernel'] == 'k_conv3x3_fwd<2,1>' and ('_c64_' in k or '_c128_' in k)]
+    kernel = dom[0]['kernel']
     avg_ms = sum(v['ms'] for v in dom) / len(dom)
     flop = dom[0]['GFLOP'] * 1e9
-    tf = flop / avg_ms / 1e9
-    return rows, {'bound': 'mfma', 'kernel': 'k_conv3x3_fwd<2,1>', 'of': 'train step (encoder 3x3 stride-1 convolutions, forward + data gradient, 64- and 128-channel stages)',
+    executed = dom[0].get('executed_GFLOP', dom[0]['GFLOP']) * 1e9
+    tf = executed / avg_ms / 1e9
+    return rows, {'bound': 'mfma', 'kernel': kernel, 'of': 'train step (encoder 3x3 stride-1 convolutions, forward + data gradient, 64- and 128-channel stages)',
                   'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(tf / FP32_MATRIX_PEAK_TF, 4),
-                  'traffic': None, 'algorithmic_flop_per_launch': flop, 'avg_launch_ms': round(avg_ms, 5),
-                  'launches_per_step': 60,
-                  'note': 'dominant kernel of the train step (about a quarter of its GPU time): algorithmic FLOP per launch = '
-                          '2 x 9 x C^2 x pixels (SURVEY 8(d)), duration = mean of HIP-event timed launches over the four '
-                          '(stage, direction) shapes it runs with, equally often; v_mfma_f32_32x32x2_f32 dense peak'}
+                  'traffic': None, 'executed_flop_per_launch': executed, 'algorithmic_flop_per_launch': flop,
+                  'credited_achieved': round(flop / avg_ms / 1e9, 2), 'credited_frac': round(flop / avg_ms / 1e9 / FP32_MATRIX_PEAK_TF, 4),
+                  'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': 60,
+                  'note': 'dominant kernel of the train step.  k_wino_fused: Winograd F(2x2,3x3) in one launch, 16 of the direct '
+                          'convolution\'s 36 multiplies.  frac = the MFMA work the launch EXECUTES (2 x 16/36 x 9 x C^2 x pixels) / time / '
+                          'the v_mfma_f32_32x32x2_f32 dense peak -- a physical fraction; credited_* use the direct convolution\'s '
+                          'algorithmic FLOP (2 x 9 x C^2 x pixels, SURVEY 8(d)) and may exceed 1.  Duration = mean of HIP-event timed '
+                          'launches over the four (stage, direction) shapes it runs with, equally often'}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -970,7 +1010,7 @@ def worker(args):
     line['executor'] = executor
     try:                                   # the train step's dominant kernel on its own, HIP-event timed: the line's `roofline`
         line['conv_kernels'], line['roofline'] = conv_kernel_table(B, H, W, device)
-        line['roofline']['traffic'] = pmc_launch_traffic('k_conv3x3_fwd<2, 1>')
+        line['roofline']['traffic'] = pmc_launch_traffic('k_wino_fused<false>' if line['roofline'].get('kernel') == 'k_wino_fused' else 'k_conv3x3_fwd<2, 1>')
     except Exception as e:                 # noqa: BLE001
         line['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

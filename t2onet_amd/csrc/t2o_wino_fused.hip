@@ -51,6 +51,7 @@ struct WfArgs {
   float* stats;          // null or (blocks, 2, Co)
   int N, H, W, Ci, Co;
   int blocks, tiles_n;   // 16 x 16 pixel blocks (N * H/16 * W/16), 64-channel tiles
+  unsigned long long* stamps;   // diagnostic builds only (tools/diag/wf_clock.hip)
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -111,11 +112,11 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     xaddr[k] = ok ? (const char*)(a.x + (((size_t)n * a.H + h) * a.W + w) * a.Ci) + half * 16 : (const char*)a.zero + half * 16;
   }
   const unsigned lds_x = lds_addr(&Xs[0][0]);
-  auto dma_chunk = [&](int buf) {                        // the chunk the addresses stand at; advances them
+  auto dma_chunk = [&](int buf, int advance) {           // the chunk the addresses stand at; advances them
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       glds16v(xaddr[k], lds_x + (unsigned)(buf * kXBuf + (wave + 4 * k) * 1024));
-      xaddr[k] += 32;
+      xaddr[k] += advance;
     }
   };
 
@@ -131,32 +132,35 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
       xoff[i][j] = (unsigned)(slot * 32 + (((cp >> 1) ^ ((slot >> 3) & 1)) << 4) + (cp & 1) * 8);
     }
   const unsigned voff_w = (unsigned)((16 * wave + 8 * tyl + tx) * 32 + (((cp >> 1) ^ tyl) << 4) + (cp & 1) * 8);
-  float2 d[4][4];
-  auto transform_load = [&](int xb) {
-    const char* xs = &Xs[xb][0];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const float2*>(xs + xoff[i][j]);
+  // B^T d B of this thread's (tile, channel pair), statement by statement (the chunk loop deals the statements out between
+  // MFMAs): 16 loads d[i][j]; rows tr = B^T d: (d0 - d2, d1 + d2, d2 - d1, d1 - d3) per column; the same along the columns
+  // (t2o_winograd.hip k_wino_input); 16 stores, plane xi = 4 i + j
+  float2 d[4][4], tr[4][4], tv[4][4];
+  auto t_load = [&](auto kc, int xb) {
+    constexpr int k = decltype(kc)::value;
+    d[k >> 2][k & 3] = *reinterpret_cast<const float2*>(&Xs[xb][0] + xoff[k >> 2][k & 3]);
   };
-  auto transform_store = [&](int vb) {
-    char* vs = &Vs[vb][0];
-    // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3), then the same along the columns (t2o_winograd.hip k_wino_input)
-    float2 r[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      r[0][j] = make_float2(d[0][j].x - d[2][j].x, d[0][j].y - d[2][j].y);
-      r[1][j] = make_float2(d[1][j].x + d[2][j].x, d[1][j].y + d[2][j].y);
-      r[2][j] = make_float2(d[2][j].x - d[1][j].x, d[2][j].y - d[1][j].y);
-      r[3][j] = make_float2(d[1][j].x - d[3][j].x, d[1][j].y - d[3][j].y);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<float2*>(vs + (4 * i + 0) * 2048 + voff_w) = make_float2(r[i][0].x - r[i][2].x, r[i][0].y - r[i][2].y);
-      *reinterpret_cast<float2*>(vs + (4 * i + 1) * 2048 + voff_w) = make_float2(r[i][1].x + r[i][2].x, r[i][1].y + r[i][2].y);
-      *reinterpret_cast<float2*>(vs + (4 * i + 2) * 2048 + voff_w) = make_float2(r[i][2].x - r[i][1].x, r[i][2].y - r[i][1].y);
-      *reinterpret_cast<float2*>(vs + (4 * i + 3) * 2048 + voff_w) = make_float2(r[i][1].x - r[i][3].x, r[i][1].y - r[i][3].y);
-    }
+  auto t_row = [&](auto kc) {                             // k = 4 j + r
+    constexpr int k = decltype(kc)::value, j = k >> 2, r = k & 3;
+    constexpr int p = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1, q = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3;
+    if constexpr (r == 1) tr[r][j] = make_float2(d[p][j].x + d[q][j].x, d[p][j].y + d[q][j].y);
+    else tr[r][j] = make_float2(d[p][j].x - d[q][j].x, d[p][j].y - d[q][j].y);
+  };
+  auto t_col = [&](auto kc) {                             // k = 4 i + c
+    constexpr int k = decltype(kc)::value, i = k >> 2, c = k & 3;
+    constexpr int p = c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 2 : 1, q = c == 0 ? 2 : c == 1 ? 2 : c == 2 ? 1 : 3;
+    if constexpr (c == 1) tv[i][c] = make_float2(tr[i][p].x + tr[i][q].x, tr[i][p].y + tr[i][q].y);
+    else tv[i][c] = make_float2(tr[i][p].x - tr[i][q].x, tr[i][p].y - tr[i][q].y);
+  };
+  auto t_store = [&](auto kc, int vb) {
+    constexpr int k = decltype(kc)::value;
+    *reinterpret_cast<float2*>(&Vs[vb][0] + k * 2048 + voff_w) = tv[k >> 2][k & 3];
+  };
+  auto transform_all = [&](int xb, int vb) {              // (prologue: chunk 0)
+    static_for<0, 16>([&](auto kc) { t_load(kc, xb); });
+    static_for<0, 16>([&](auto kc) { t_row(kc); });
+    static_for<0, 16>([&](auto kc) { t_col(kc); });
+    static_for<0, 16>([&](auto kc) { t_store(kc, vb); });
   };
 
   // ---- MFMA operands: A = V rows (this wave's 32 tiles), B = U rows (its 32 output channels), both from LDS
@@ -166,16 +170,20 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   // U chunk c = 16 planes x 64 channels x 32 bytes = 32 pieces, contiguous per plane in the chunk-major layout: piece j of
   // this wave (plane xi = 2 j + (wave >> 1), half wave & 1) is 1 KiB at ((c * 16 + xi) * Co + co0 + 32 (wave & 1)) * 32 bytes
   const unsigned lds_u = lds_addr(&Us[0][0]);
-  const char* ubase = (const char*)a.uc + ((size_t)co0 + 32 * (wave & 1)) * 32;
   const unsigned ulane = (unsigned)(lane * 16);
   const size_t uplane = (size_t)a.Co * 32;                // bytes per (chunk, xi) plane
-  auto dma_u = [&](int cc, int buf) {
+  // scalar bases of this wave's 8 pieces at chunk 0 (the chunk loop adds chunk * 16 planes: two scalar instructions per piece --
+  // formed in the loop, the 64-bit products cost ~16 each and the DMA issue stopped hiding behind the MFMAs it sits between)
+  const char* upiece[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int xi = 2 * j + (wave >> 1);
-      glds16(ulane, ubase + ((size_t)cc * 16 + xi) * uplane, lds_u + (unsigned)(buf * kUBuf + xi * 2048 + (wave & 1) * 1024));
-    }
+  for (int j = 0; j < 8; ++j) upiece[j] = (const char*)a.uc + ((size_t)co0 + 32 * (wave & 1)) * 32 + (size_t)(2 * j + (wave >> 1)) * uplane;
+  const size_t uchunk = 16 * uplane;
+  const unsigned lds_u_wave = lds_u + (unsigned)((wave >> 1) * 2048 + (wave & 1) * 1024);
+  auto dma_u_piece = [&](auto jc, size_t uoff, unsigned ldsb) {      // uoff = chunk * uchunk, ldsb = lds_u_wave + buf * kUBuf
+    constexpr int j = decltype(jc)::value;
+    glds16(ulane, upiece[j] + uoff, ldsb + (unsigned)(j * 4096));
   };
+  auto dma_u = [&](int cc, int buf) { static_for<0, 8>([&](auto jc) { dma_u_piece(jc, (size_t)cc * uchunk, lds_u_wave + (unsigned)(buf * kUBuf)); }); };
 
   f32x16 acc[16];
 #pragma unroll
@@ -184,6 +192,10 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
   float4 fa[2][2], fb[2][2];                              // fragments of a plane pair, double-buffered across pairs
+#ifdef T2O_WF_DIAG
+  unsigned ph[9] = {};
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
   auto frag_read = [&](auto pc, auto slotc, int buf) {
     constexpr int p = decltype(pc)::value, slot = decltype(slotc)::value;
     fa[slot][0] = *reinterpret_cast<const float4*>(&Vs[buf][0] + p * 2048 + aoff);
@@ -191,55 +203,91 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     fb[slot][0] = *reinterpret_cast<const float4*>(&Us[buf][0] + p * 2048 + boff);
     fb[slot][1] = *reinterpret_cast<const float4*>(&Us[buf][0] + (p + 1) * 2048 + boff);
   };
-  auto mfma_pair = [&](auto pc, auto slotc) {
-    constexpr int p = decltype(pc)::value, slot = decltype(slotc)::value;
-    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].x, fb[slot][0].x, acc[p], 0, 0, 0);
-    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].x, fb[slot][1].x, acc[p + 1], 0, 0, 0);
-    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].y, fb[slot][0].y, acc[p], 0, 0, 0);
-    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].y, fb[slot][1].y, acc[p + 1], 0, 0, 0);
-    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].z, fb[slot][0].z, acc[p], 0, 0, 0);
-    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].z, fb[slot][1].z, acc[p + 1], 0, 0, 0);
-    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0].w, fb[slot][0].w, acc[p], 0, 0, 0);
-    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1].w, fb[slot][1].w, acc[p + 1], 0, 0, 0);
+  // MFMA m (0..7) of a plane pair: component m >> 1 of the fragments, plane p + (m & 1)
+  auto mfma_one = [&](auto pc, auto slotc, auto mc) {
+    constexpr int p = decltype(pc)::value, slot = decltype(slotc)::value, m = decltype(mc)::value, w = m & 1, e = m >> 1;
+    const float av = e == 0 ? fa[slot][w].x : e == 1 ? fa[slot][w].y : e == 2 ? fa[slot][w].z : fa[slot][w].w;
+    const float bv = e == 0 ? fb[slot][w].x : e == 1 ? fb[slot][w].y : e == 2 ? fb[slot][w].z : fb[slot][w].w;
+    acc[p + w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p + w], 0, 0, 0);
   };
-  // plane pairs kFirst .. kFirst + 3 of a chunk: the next pair's fragments are requested before the current pair's MFMAs
-  auto mfma_half = [&](auto firstc, int buf) {
-    constexpr int kFirst = decltype(firstc)::value;       // 0 or 4 (pair index)
-    static_for<0, 4>([&](auto kc) {
-      constexpr int k = kFirst + decltype(kc)::value;
-      if constexpr (k + 1 < 8) frag_read(std::integral_constant<int, 2 * (k + 1)>{}, std::integral_constant<int, (k + 1) & 1>{}, buf);
-      mfma_pair(std::integral_constant<int, 2 * k>{}, std::integral_constant<int, k & 1>{});
+  auto x_piece = [&](auto kc, int buf, int adv) {
+    constexpr int k = decltype(kc)::value;
+    glds16v(xaddr[k], lds_x + (unsigned)(buf * kXBuf + (wave + 4 * k) * 1024));
+    xaddr[k] += adv;
+  };
+
+  // One chunk, branch-free: chunk c's MFMAs from Vs / Us[kBuf]; DMA of x chunk c + 2 into Xs[kBuf] and of U chunk c + 1 into
+  // Us[kBuf ^ 1]; transform of chunk c + 1 from Xs[kBuf ^ 1] into Vs[kBuf ^ 1].  Past the end the same work is done on the last
+  // chunks again, into buffers nobody reads any more.  Measured (tools/diag/wf_clock.hip): a wave's 64 MFMAs take their 4,096
+  // pipe cycles whatever else happens, and everything issued OUTSIDE them is added time (first version: 877 cycles of DMA issue
+  // and loads + 551 of transform per chunk) -- so every other instruction sits BETWEEN two MFMAs of this wave, pinned there:
+  //   pair 0: the 11 DMA pieces; pair 1: the transform's 16 loads; pair 2: its 16 row steps; pair 3: its 16 column steps;
+  //   pair 4: its 16 stores; every pair's fragments are requested one pair ahead.
+  auto chunk_body = [&](int kBuf, int c) {              // (kBuf as a run-time value: unrolled by two with constant buffers the
+                                                        // register allocation spilled 86 values)
+#ifdef T2O_WF_DIAG
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+    const int adv = c + 3 < chunks ? 32 : 0;              // (the addresses stop at the last chunk)
+    const int cu = c + 1 < chunks ? c + 1 : chunks - 1;
+    const size_t uoff = (size_t)cu * uchunk;
+    const unsigned ulds = lds_u_wave + (unsigned)((kBuf ^ 1) * kUBuf);
+    frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kBuf);
+    frag_read(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, kBuf);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 8>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;              // plane pair
+      static_for<0, 8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        mfma_one(std::integral_constant<int, 2 * k>{}, std::integral_constant<int, k & 1>{}, mc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k == 0) {
+          if constexpr (m < 3) x_piece(mc, kBuf, adv);
+          dma_u_piece(mc, uoff, ulds);
+        } else if constexpr (k == 1) {
+          t_load(std::integral_constant<int, 2 * m>{}, kBuf ^ 1);
+          t_load(std::integral_constant<int, 2 * m + 1>{}, kBuf ^ 1);
+        } else if constexpr (k == 2) {
+          t_row(std::integral_constant<int, 2 * m>{});
+          t_row(std::integral_constant<int, 2 * m + 1>{});
+        } else if constexpr (k == 3) {
+          t_col(std::integral_constant<int, 2 * m>{});
+          t_col(std::integral_constant<int, 2 * m + 1>{});
+        } else if constexpr (k == 4) {
+          t_store(std::integral_constant<int, 2 * m>{}, kBuf ^ 1);
+          t_store(std::integral_constant<int, 2 * m + 1>{}, kBuf ^ 1);
+        }
+        // the fragments of pair k + 2 go into the slot pair k is leaving, behind its last MFMA
+        if constexpr (m == 7 && k + 2 < 8) frag_read(std::integral_constant<int, 2 * (k + 2)>{}, std::integral_constant<int, k & 1>{}, kBuf);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#ifdef T2O_WF_DIAG
+      { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += (unsigned)(tn - tprev); tprev = tn; }
+#endif
     });
+    vm_wait0();
+    __syncthreads();
+#ifdef T2O_WF_DIAG
+    { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[8] += (unsigned)(tn - tprev); }
+#endif
   };
 
   // ---- pipeline: DMA x(c + 2), U(c + 1) | transform(c + 1) | MFMA(c), one barrier per chunk
-  dma_chunk(0);
+  dma_chunk(0, chunks > 1 ? 32 : 0);
   dma_u(0, 0);
   vm_wait0();
   __syncthreads();
-  if (chunks > 1) dma_chunk(1);
-  transform_load(0);
-  transform_store(0);
+  dma_chunk(1, chunks > 2 ? 32 : 0);                      // (a one-chunk layer: the same chunk again, never used)
+  transform_all(0, 0);
   vm_wait0();
   __syncthreads();
-  for (int c = 0; c < chunks; ++c) {
-    const bool more = c + 1 < chunks;
-    const int buf = c & 1;
-    frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, buf);
-    if (c + 2 < chunks) dma_chunk(buf);                   // Xs[c & 1] was read by transform(c): free since the last barrier
-    if (more) {
-      dma_u(c + 1, buf ^ 1);                              // Us[(c + 1) & 1] was read by the MFMAs of chunk c - 1
-      transform_load(buf ^ 1);                            // the patch values travel while the first half of the planes is multiplied
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_half(std::integral_constant<int, 0>{}, buf);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) transform_store(buf ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_half(std::integral_constant<int, 4>{}, buf);
-    vm_wait0();
-    __syncthreads();
-  }
+#ifdef T2O_WF_DIAG
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+  for (int c = 0; c < chunks; ++c) chunk_body(c & 1, c);
+#ifdef T2O_WF_DIAG
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- output transform in registers: y tile = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]; lane = channel co0 + 32 ch + ln,
   // register r = tile row (r & 3) + 8 (r >> 2) + 4 lh of this wave's 32 tiles
@@ -284,6 +332,13 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
       a.stats[((size_t)blk * 2 + which) * a.Co + co0 + c] = red[which][0][c] + red[which][1][c];
     }
   }
+#ifdef T2O_WF_DIAG
+  if (a.stamps && lane == 0) {         // per wave: [prologue, loop, epilogue issue, pairs 0..7, wait + barrier]
+    unsigned long long* q = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+    q[0] = t_loop - t_start; q[1] = t_end - t_loop; q[2] = __builtin_amdgcn_s_memtime() - t_end;
+    for (int i = 0; i < 9; ++i) q[3 + i] = ph[i];
+  }
+#endif
 }
 
 // U (16, Cn, Ck) -> chunk-major (Ck/8, 16, Cn, 8)

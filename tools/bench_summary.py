@@ -22,8 +22,10 @@ for name, leg in d.get('executor', {}).items():
     if not isinstance(leg, dict):
         print('executor', name, leg)
         continue
-    for path in ('fused', 'materialised'):
-        m = leg[path]
+    for path in ('value_grad', 'fused', 'materialised'):
+        m = leg.get(path)
+        if m is None:
+            continue
         print('%-12s %-12s %9.0f img/s  %8.4f ms/step  frac %.3f' % (name, path, m['value'], m['ms_per_step'], m['frac_of_peak']) + ('  fused-min frac %.3f' % m['fused_min_frac'] if 'fused_min_frac' in m else ''))
         for k, v in m['kernels'].items():
             print('      %-22s %8.2f us  %7.0f GB/s alg  %7.0f GB/s moved' % (k, v['ms'] * 1e3, v['GBps'], v.get('hbm_min_GBps', 0)))
