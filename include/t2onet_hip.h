@@ -620,6 +620,11 @@ int t2o_wino_fused_stats_rows(int N, int H, int W);
 int t2o_wino_u_chunked(const float* U, float* Uc, int Cn, int Ck, void* stream);
 int t2o_wino_fused_conv_nhwc(const float* x, const float* uc, const float* addend, float* y, float* stats,
                              const float* zeros, int N, int H, int W, int Ci, int Co, void* stream);
+/* ... as a data gradient in front of y = relu(bn(bn_x)) (see t2o_conv3x3_dgrad_pre_bnsums_nhwc): rows (t2o_wino_fused_stats_rows,
+ * 2, Co) receive that batch norm's backward sums for t2o_bn_relu_nhwc_bwd_partials_acc; bn_x is fetched under the last chunk. */
+int t2o_wino_fused_conv_bnsums_nhwc(const float* x, const float* uc, float* y, const float* bn_x, const float* save_mean,
+                                    const float* save_invstd, const float* weight, const float* bias, float* rows,
+                                    const float* zeros, int N, int H, int W, int Ci, int Co, void* stream);
 
 #ifdef __cplusplus
 }

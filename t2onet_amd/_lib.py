@@ -107,6 +107,7 @@ SIGNATURES = {
     't2o_wino_fused_stats_rows': (_I, [_I, _I, _I]),
     't2o_wino_u_chunked': (_I, [_P, _P, _I, _I, _P]),
     't2o_wino_fused_conv_nhwc': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_wino_fused_conv_bnsums_nhwc': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3_dgrad_pre_bnsums_nhwc': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3s2_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_stem_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -49,6 +49,13 @@ struct WfArgs {
   const float* zero;     // >= Ci * 4 + 32 bytes of zeros
   const float* addend;   // null or (N,H,W,Co)
   float* stats;          // null or (blocks, 2, Co)
+  // kEpi == 2 (data gradient in front of y = relu(bn(bn_x))): the batch norm's backward sums per block and channel of the gated
+  // gradient g = dx [bn_x * sc + sh > 0] and of g * xhat go to `stats` instead (as k_conv3x3_fwd's kBnb form)
+  const float* bn_x;     // (N,H,W,Co)
+  const float* bn_mean;  // (Co) batch mean, inverse standard deviation, gamma, beta
+  const float* bn_invstd;
+  const float* bn_w;
+  const float* bn_b;
   int N, H, W, Ci, Co;
   int blocks, tiles_n;   // 16 x 16 pixel blocks (N * H/16 * W/16), 64-channel tiles
   unsigned long long* stamps;   // diagnostic builds only (tools/diag/wf_clock.hip)
@@ -78,8 +85,12 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <bool kAdd>
+// kEpi: 0 plain, 1 addend, 2 batch-norm backward sums.  The epilogue operand of 1 / 2 (64 values per lane) is requested in ONE
+// batch behind the loop: loaded value by value in the output transform it cost 39 us per launch (141 vs 102 us: nothing else
+// runs on the CU to hide a round trip).
+template <int kEpi>
 __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
+  constexpr bool kAdd = kEpi == 1, kBnb = kEpi == 2;
   __shared__ __attribute__((aligned(16))) char Xs[2][kXBuf];
   __shared__ __attribute__((aligned(16))) char Vs[2][kVBuf];
   __shared__ __attribute__((aligned(16))) char Us[2][kUBuf];
@@ -284,19 +295,40 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
 #ifdef T2O_WF_DIAG
   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
+  // offset of output pixel (2 ty, 2 tx) of register r's tile, channel of this lane
+  auto out_off = [&](int r) {
+    const int t = 32 * th + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    return (((size_t)n * a.H + by * 16 + 2 * (t >> 3)) * a.W + bx * 16 + 2 * (t & 7)) * a.Co + co0 + 32 * ch + ln;
+  };
   for (int c = 0; c < chunks; ++c) chunk_body(c & 1, c);
 #ifdef T2O_WF_DIAG
   const unsigned long long t_end = __builtin_amdgcn_s_memtime();
 #endif
+  // the epilogue operand: all 64 loads of the lane at once (one round trip; fetched under the last chunk's MFMAs they would
+  // not fit -- the loop leaves ~50 of the 256 non-accumulator registers free, 64 more spilled 130 values)
+  float pre[kEpi ? 16 : 1][4];
+  if constexpr (kEpi != 0) {
+    const float* __restrict__ src = kAdd ? a.addend : a.bn_x;
+    const size_t rowstep = (size_t)a.W * a.Co;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t off = out_off(r);
+      pre[r][0] = src[off]; pre[r][1] = src[off + a.Co]; pre[r][2] = src[off + rowstep]; pre[r][3] = src[off + rowstep + a.Co];
+    }
+    __builtin_amdgcn_sched_barrier(0);                    // (all requested before the first is waited for)
+  }
 
   // ---- output transform in registers: y tile = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]; lane = channel co0 + 32 ch + ln,
   // register r = tile row (r & 3) + 8 (r >> 2) + 4 lh of this wave's 32 tiles
   const int co = co0 + 32 * ch + ln;
   float s1 = 0.0f, s2 = 0.0f;
+  float bmean = 0.0f, binv = 0.0f, bsc = 0.0f, bsh = 0.0f;
+  if constexpr (kBnb) {                                   // the gate exactly as t2o_norm.hip gated<false>: x * sc + sh > 0
+    bmean = a.bn_mean[co]; binv = a.bn_invstd[co];
+    bsc = a.bn_w[co] * binv; bsh = a.bn_b[co] - bmean * bsc;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int t = 32 * th + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    const int ty = t >> 3, txx = t & 7;
     float m[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -308,17 +340,24 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
       q[0][j] = (m[0][j] + m[1][j]) + m[2][j];
       q[1][j] = (m[1][j] - m[2][j]) - m[3][j];
     }
-    const int oh = by * 16 + 2 * ty, ow = bx * 16 + 2 * txx;
+    const size_t off0 = out_off(r);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float o0 = (q[i][0] + q[i][1]) + q[i][2];
       float o1 = (q[i][1] - q[i][2]) - q[i][3];
-      const size_t off = (((size_t)n * a.H + oh + i) * a.W + ow) * a.Co + co;
-      if constexpr (kAdd) { o0 += a.addend[off]; o1 += a.addend[off + a.Co]; }
+      const size_t off = off0 + (size_t)i * a.W * a.Co;
+      if constexpr (kAdd) { o0 += pre[r][2 * i]; o1 += pre[r][2 * i + 1]; }
       a.y[off] = o0;
       a.y[off + a.Co] = o1;
-      s1 += o0 + o1;
-      s2 += o0 * o0 + o1 * o1;
+      if constexpr (kBnb) {
+        const float x0 = pre[r][2 * i], x1 = pre[r][2 * i + 1];
+        const float g0 = (x0 * bsc + bsh > 0.0f) ? o0 : 0.0f, g1 = (x1 * bsc + bsh > 0.0f) ? o1 : 0.0f;
+        s1 += g0 + g1;
+        s2 += g0 * ((x0 - bmean) * binv) + g1 * ((x1 - bmean) * binv);
+      } else {
+        s1 += o0 + o1;
+        s2 += o0 * o0 + o1 * o1;
+      }
     }
   }
   if (a.stats) {                                          // (uniform) fixed order: lane, its partner lane + 32, the two tile waves
@@ -388,9 +427,28 @@ int t2o_wino_fused_conv_nhwc(const float* x, const float* uc, const float* adden
   a.tiles_n = Co / 64;
   const unsigned grid = (unsigned)(((a.blocks + 7) / 8) * 8 * a.tiles_n);
   hipStream_t st = (hipStream_t)stream;
-  if (addend) k_wino_fused<true><<<grid, kWfThreads, 0, st>>>(a);
-  else k_wino_fused<false><<<grid, kWfThreads, 0, st>>>(a);
+  if (addend) k_wino_fused<1><<<grid, kWfThreads, 0, st>>>(a);
+  else k_wino_fused<0><<<grid, kWfThreads, 0, st>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_fused_conv launch failed");
+}
+
+int t2o_wino_fused_conv_bnsums_nhwc(const float* x, const float* uc, float* y, const float* bn_x, const float* save_mean,
+                                    const float* save_invstd, const float* weight, const float* bias, float* rows, const float* zeros,
+                                    int N, int H, int W, int Ci, int Co, void* stream) {
+  if (!x || !uc || !y || !zeros || !bn_x || !save_mean || !save_invstd || !weight || !bias || !rows)
+    return set_error(T2O_EINVAL, "wino_fused_conv_bnsums: null pointer");
+  if (((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(uc) | reinterpret_cast<size_t>(zeros)) & 15) != 0)
+    return set_error(T2O_EINVAL, "wino_fused_conv_bnsums: x, uc and zeros must be 16-byte aligned");
+  if (!wf_supported(N, H, W, Ci, Co)) return set_error(T2O_EUNSUPPORTED, "wino_fused_conv_bnsums: H, W multiples of 16, Ci of 8, Co of 64");
+  WfArgs a = {};
+  a.x = x; a.uc = uc; a.y = y; a.zero = zeros; a.stats = rows;
+  a.bn_x = bn_x; a.bn_mean = save_mean; a.bn_invstd = save_invstd; a.bn_w = weight; a.bn_b = bias;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.blocks = N * (H / 16) * (W / 16);
+  a.tiles_n = Co / 64;
+  const unsigned grid = (unsigned)(((a.blocks + 7) / 8) * 8 * a.tiles_n);
+  k_wino_fused<2><<<grid, kWfThreads, 0, (hipStream_t)stream>>>(a);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_fused_conv_bnsums launch failed");
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, wino_conv_nhwc, wino_fused_conv_nhwc, wino_wgrad_nhwc, wino_input,
+from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, _zero_block, wino_conv_nhwc, wino_fused_conv_nhwc, wino_wgrad_nhwc, wino_input,
                          wino_backward_nhwc, wino_dw_from)
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
@@ -602,8 +602,16 @@ class _TrunkFn(torch.autograd.Function):
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
             else:
                 C2o, C2i = b.conv2.weight.shape[0], b.conv2.weight.shape[1]
-                n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and _fast_direct(1, Hn, Wn, Wn) and not plan.fused_wino(b.conv2, Hn, Wn)) else 0
-                if n_rows > 0:
+                fused2 = plan.fused_wino(b.conv2, Hn, Wn)
+                n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and _fast_direct(1, Hn, Wn, Wn) and not fused2) else 0
+                if fused2 and _BN_SUMS_EPILOGUE:
+                    # the on-chip Winograd data gradient with bn1's backward sums in its epilogue
+                    rows1 = torch.empty(lib.t2o_wino_fused_stats_rows(N, Hn, Wn) * 2 * C2i, dtype=torch.float32, device=dev)
+                    rc = lib.t2o_wino_fused_conv_bnsums_nhwc(_ptr(dy2), _ptr(wt['wino'][('c', id(b.conv2))]), _ptr(da1), _ptr(rec['y1']),
+                                                             _ptr(rec['m1']), _ptr(rec['i1']), _ptr(b.bn1.weight), _ptr(b.bn1.bias), _ptr(rows1),
+                                                             _ptr(_zero_block(dev)), N, Hn, Wn, C2o, C2i, st)
+                    _lib.check(rc, 't2o_wino_fused_conv_bnsums_nhwc')
+                elif n_rows > 0:
                     # a1 = relu(bn1(y1)) is this data gradient's only consumer: its epilogue forms bn1's backward sums
                     rows1 = torch.empty(n_rows * 2 * C2i, dtype=torch.float32, device=dev)
                     rc = lib.t2o_conv3x3_dgrad_pre_bnsums_nhwc(_ptr(dy2), _ptr(wt[id(b.conv2)]), _ptr(da1), _ptr(rec['y1']), _ptr(rec['m1']),

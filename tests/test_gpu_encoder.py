@@ -315,8 +315,8 @@ def test_dual_batch_norm_of_shortcut_blocks_is_bit_identical_to_the_separate_pas
         assert torch.equal(res[True][3][n], res[False][3][n]), n
 
 
-@pytest.mark.parametrize('size', [(64, 256), (96, 160), (256, 256)])
-def test_batch_norm_backward_sums_from_the_data_gradient_epilogue(monkeypatch, size):
+@pytest.mark.parametrize('size,wino', [((64, 256), False), ((96, 160), False), ((256, 256), False), ((256, 256), True)])
+def test_batch_norm_backward_sums_from_the_data_gradient_epilogue(monkeypatch, size, wino):
     """bn1's backward sums formed in the epilogue of conv2's data gradient (t2o_conv3x3_dgrad_pre_bnsums_nhwc +
     t2o_bn_relu_nhwc_bwd_partials_acc; the direct-kernel stages) against the batch norm's own sums pass: the same gated terms
     added in another order -- outputs identical, gradients equal to fp32 summation noise."""
@@ -325,7 +325,7 @@ def test_batch_norm_backward_sums_from_the_data_gradient_epilogue(monkeypatch, s
     img = synth.images(N, H, W, 81).to(DEV)
     gout = synth.uniform((N, 512), 82, -1.0, 1.0).to(DEV)
     res = {}
-    monkeypatch.setattr(E, '_WINO_FUSED', False)            # (at 256 x 256 the on-chip Winograd kernel would take these layers)
+    monkeypatch.setattr(E, '_WINO_FUSED', wino)             # (the direct kernels' epilogue, or -- 256 x 256 -- the on-chip Winograd kernel's)
     for fused in (True, False):
         monkeypatch.setattr(E, '_BN_SUMS_EPILOGUE', fused)
         net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 50; ++rep) {
     if (rep == 49) hipEventRecord(e0);
-    k_wino_fused<false><<<grid, kWfThreads>>>(a);
+    k_wino_fused<0><<<grid, kWfThreads>>>(a);
     if (rep == 49) hipEventRecord(e1);
   }
   hipEventSynchronize(e1);
