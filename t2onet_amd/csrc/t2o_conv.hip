@@ -710,7 +710,9 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_conv3x3_fwd(FwdArgs a) {
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lh == 0) { red[0][wm][wn * 32 + ln] = s1; red[1][wm][wn * 32 + ln] = s2; }
-    __syncthreads();
+    // (not __syncthreads(): that also waits for this wave's output stores to be acknowledged, ~2 us with nothing else on the CU)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (tid < 2 * kFwdCo) {
       const int which = tid / kFwdCo, c = tid % kFwdCo;
       (kBnb ? a.bn_rows : a.stats)[((size_t)pt * 2 + which) * a.Co + co0 + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);

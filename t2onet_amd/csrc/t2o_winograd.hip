@@ -124,7 +124,8 @@ __global__ __launch_bounds__(kThreads) void k_wino_output(const float* __restric
     __shared__ float4 sm[2][kThreads];
     sm[0][threadIdx.x] = s1;
     sm[1][threadIdx.x] = s2;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (not __syncthreads(): no need to wait for the y stores)
+    __builtin_amdgcn_s_barrier();
     if ((int)threadIdx.x < q) {
       float4 a = sm[0][threadIdx.x], b = sm[1][threadIdx.x];
       for (int k = threadIdx.x + q; k < kThreads; k += q) { a = add4(a, sm[0][k]); b = add4(b, sm[1][k]); }      // fixed order
