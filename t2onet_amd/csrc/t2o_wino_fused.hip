@@ -65,16 +65,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 // LDS-DMA, per-lane 64-bit address form: lane l's 16 bytes at addr[l] go to LDS byte lds_dst + 16 l
+// (M0 is declared clobbered, not saved and restored: nothing else in these kernels uses it, and every instruction between two
+// MFMAs of a one-wave-per-SIMD kernel costs its ~10 issue cycles in full)
 __device__ __forceinline__ void glds16v(const void* addr, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(addr), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(addr), "s"(lds_dst) : "memory", "m0");
 }
 // ... scalar base + 32-bit lane offset form
 __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int kFirst, int kLast, class F>
@@ -185,14 +183,15 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   const size_t uplane = (size_t)a.Co * 32;                // bytes per (chunk, xi) plane
   // scalar bases of this wave's 8 pieces at chunk 0 (the chunk loop adds chunk * 16 planes: two scalar instructions per piece --
   // formed in the loop, the 64-bit products cost ~16 each and the DMA issue stopped hiding behind the MFMAs it sits between)
-  const char* upiece[8];
+  const char* const ubase = (const char*)a.uc + ((size_t)co0 + 32 * (wave & 1)) * 32 + (size_t)(wave >> 1) * uplane;
+  unsigned upiece[8];                                     // lane offsets of the 8 pieces from the chunk's base (a chunk is < 4 GiB)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) upiece[j] = (const char*)a.uc + ((size_t)co0 + 32 * (wave & 1)) * 32 + (size_t)(2 * j + (wave >> 1)) * uplane;
+  for (int j = 0; j < 8; ++j) upiece[j] = ulane + (unsigned)(2 * j * uplane);
   const size_t uchunk = 16 * uplane;
   const unsigned lds_u_wave = lds_u + (unsigned)((wave >> 1) * 2048 + (wave & 1) * 1024);
   auto dma_u_piece = [&](auto jc, size_t uoff, unsigned ldsb) {      // uoff = chunk * uchunk, ldsb = lds_u_wave + buf * kUBuf
     constexpr int j = decltype(jc)::value;
-    glds16(ulane, upiece[j] + uoff, ldsb + (unsigned)(j * 4096));
+    glds16(upiece[j], ubase + uoff, ldsb + (unsigned)(j * 4096));
   };
   auto dma_u = [&](int cc, int buf) { static_for<0, 8>([&](auto jc) { dma_u_piece(jc, (size_t)cc * uchunk, lds_u_wave + (unsigned)(buf * kUBuf)); }); };
 
