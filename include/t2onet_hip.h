@@ -468,6 +468,8 @@ int t2o_conv3x3_any_wgrad_nhwc(const float* x, const float* dy, float* dw, void*
 int t2o_wino_padded_tiles(int N, int H, int W);
 int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* stream);
 int t2o_wino_weight_transform_batch(const float* const* w, float* const* U, const int* Cn, const int* Ck, int n, void* stream);   /* n <= 32 banks, one launch */
+/* ... straight into the chunk-major layout (Ck/8, 16, Cn, 8) of t2o_wino_fused_conv_nhwc (= t2o_wino_u_chunked of the above) */
+int t2o_wino_weight_transform_chunked_batch(const float* const* w, float* const* Uc, const int* Cn, const int* Ck, int n, void* stream);
 int t2o_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
 /* the same into rows [0, Tpad) of every plane of a LARGER (16, plane_rows, C) tensor whose first plane starts at V (a train
  * step's passes side by side: the weight gradient then runs once over all of them); plane_rows = 0: Tpad */

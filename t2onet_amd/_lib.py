@@ -86,6 +86,7 @@ SIGNATURES = {
     't2o_conv_weight_transform': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     't2o_conv_weight_transform_batch': (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     't2o_wino_weight_transform_batch': (_I, [_P, _P, _P, _P, _I, _P]),
+    't2o_wino_weight_transform_chunked_batch': (_I, [_P, _P, _P, _P, _I, _P]),
     't2o_end_select_l1_fwd': (_I, [_P, _I, _P, _P, _P, _I, _Z, _P, _Z, _P]),
     't2o_end_select_l1_bwd': (_I, [_P, _P, _I, _P, _P, _P, _I, _Z, _P]),
     't2o_wino_padded_tiles': (_I, [_I, _I, _I]),

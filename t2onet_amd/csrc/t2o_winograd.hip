@@ -295,6 +295,7 @@ struct UJobs {
   int Cn[kMaxUJobs], Ck[kMaxUJobs];
   unsigned first[kMaxUJobs + 1];
   int n;
+  int chunked;      // U in the on-chip kernel's chunk-major layout (Ck/8, 16, Cn, 8) instead of (16, Cn, Ck)
 };
 
 __global__ __launch_bounds__(kThreads) void k_wino_weight_batch(UJobs jb) {
@@ -319,12 +320,15 @@ __global__ __launch_bounds__(kThreads) void k_wino_weight_batch(UJobs jb) {
     r[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
     r[3][b] = g[2][b];
   }
+  // element (xi, n, k): plane-major xi * Cn * Ck + n * Ck + k, or chunk-major ((k / 8 * 16 + xi) * Cn + n) * 8 + k % 8
+  const size_t step = jb.chunked ? (size_t)jb.Cn[j] * 8 : total;
+  const size_t base = jb.chunked ? ((size_t)(k >> 3) * 16 * jb.Cn[j] + n) * 8 + (k & 7) : idx;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    U[(size_t)(4 * a + 0) * total + idx] = r[a][0];
-    U[(size_t)(4 * a + 1) * total + idx] = 0.5f * ((r[a][0] + r[a][2]) + r[a][1]);
-    U[(size_t)(4 * a + 2) * total + idx] = 0.5f * ((r[a][0] + r[a][2]) - r[a][1]);
-    U[(size_t)(4 * a + 3) * total + idx] = r[a][2];
+    U[(size_t)(4 * a + 0) * step + base] = r[a][0];
+    U[(size_t)(4 * a + 1) * step + base] = 0.5f * ((r[a][0] + r[a][2]) + r[a][1]);
+    U[(size_t)(4 * a + 2) * step + base] = 0.5f * ((r[a][0] + r[a][2]) - r[a][1]);
+    U[(size_t)(4 * a + 3) * step + base] = r[a][2];
   }
 }
 
@@ -352,10 +356,23 @@ int t2o_wino_weight_transform(const float* w, float* U, int Cn, int Ck, void* st
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_weight_transform: launch failed");
 }
 
+static int wino_weight_batch(const float* const* w, float* const* U, const int* Cn, const int* Ck, int n, int chunked, void* stream);
+
 int t2o_wino_weight_transform_batch(const float* const* w, float* const* U, const int* Cn, const int* Ck, int n, void* stream) {
+  return wino_weight_batch(w, U, Cn, Ck, n, 0, stream);
+}
+
+int t2o_wino_weight_transform_chunked_batch(const float* const* w, float* const* Uc, const int* Cn, const int* Ck, int n, void* stream) {
+  for (int j = 0; Ck && j < n && j < kMaxUJobs; ++j)
+    if (Ck[j] % 8 != 0) return set_error(T2O_EINVAL, "wino_weight_transform_chunked_batch: Ck must be a multiple of 8");
+  return wino_weight_batch(w, Uc, Cn, Ck, n, 1, stream);
+}
+
+static int wino_weight_batch(const float* const* w, float* const* U, const int* Cn, const int* Ck, int n, int chunked, void* stream) {
   if (!w || !U || !Cn || !Ck || n < 1 || n > kMaxUJobs) return set_error(T2O_EINVAL, "wino_weight_transform_batch: null pointer or more than 32 jobs");
   UJobs jb = {};
   jb.n = n;
+  jb.chunked = chunked;
   unsigned total = 0;
   for (int j = 0; j < n; ++j) {
     if (!w[j] || !U[j] || Cn[j] <= 0 || Ck[j] <= 0) return set_error(T2O_EINVAL, "wino_weight_transform_batch: null pointer or bad shape");

@@ -111,21 +111,19 @@ class TrunkPlan:
                 if c.stride[0] == 1 and c.weight.shape[0] in (64, 128) and c.weight.shape[1] in (64, 128)] if (_WINO_FUSED and _WINOGRAD) else []
 
     def _chunked(self, lib, st, store, convs, src, swap):
-        """store[('c', id(conv))] = chunk-major Winograd filters (Ck/8, 16, Cn, 8) of src(conv) (Cn,3,3,Ck) for the on-chip kernel."""
+        """store[('c', id(conv))] = chunk-major Winograd filters (Ck/8, 16, Cn, 8) of src(conv) (Cn,3,3,Ck) for the on-chip kernel:
+        every layer's in ONE launch (t2o_wino_weight_transform_chunked_batch)."""
         ujobs = []
         for conv in convs:
             w = conv.weight
             Cn, Ck = (w.shape[1], w.shape[0]) if swap else (w.shape[0], w.shape[1])
-            u = store.get(('u', id(conv)))
-            if u is None or u.device != w.device:
-                u = store[('u', id(conv))] = torch.empty((16, Cn, Ck), dtype=torch.float32, device=w.device)
-                store[('c', id(conv))] = torch.empty((Ck // 8, 16, Cn, 8), dtype=torch.float32, device=w.device)
-            ujobs.append((src(conv), u, Cn, Ck, store[('c', id(conv))]))
+            uc = store.get(('c', id(conv)))
+            if uc is None or uc.device != w.device:
+                uc = store[('c', id(conv))] = torch.empty((Ck // 8, 16, Cn, 8), dtype=torch.float32, device=w.device)
+            ujobs.append((src(conv), uc, Cn, Ck))
         if ujobs:
-            _batched(lib.t2o_wino_weight_transform_batch, 't2o_wino_weight_transform_batch', st,
+            _batched(lib.t2o_wino_weight_transform_chunked_batch, 't2o_wino_weight_transform_chunked_batch', st,
                      [j[0] for j in ujobs], [j[1] for j in ujobs], [[j[2] for j in ujobs], [j[3] for j in ujobs]])
-            for _, u, Cn, Ck, uc in ujobs:
-                _lib.check(lib.t2o_wino_u_chunked(_ptr(u), _ptr(uc), Cn, Ck, st), 't2o_wino_u_chunked')
 
     def wino_convs(self):
         return [c for b in self.blocks for c in (b.conv1, b.conv2) if c.stride[0] == 1 and c.weight.shape[0] >= _WINO_MIN_C and c.weight.shape[1] >= _WINO_MIN_C

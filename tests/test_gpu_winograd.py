@@ -241,6 +241,15 @@ def test_on_chip_winograd_matches_conv2d_fp64(shape, with_addend):
     U = T.wino_weight(w.to(dev).permute(0, 2, 3, 1).contiguous(), Co, Ci)
     Uc = T.wino_u_chunked(U)
     assert torch.equal(Uc.permute(1, 2, 0, 3).reshape(16, Co, Ci), U)
+    import ctypes
+    from t2onet_amd import _lib
+    wl = w.to(dev).permute(0, 2, 3, 1).contiguous()
+    Ucb = torch.empty_like(Uc)                               # the batched transform writes the chunk-major layout directly
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    ints = lambda v: (ctypes.c_int * len(v))(*v)
+    _lib.check(_lib.load().t2o_wino_weight_transform_chunked_batch(arr([wl, wl]), arr([Ucb, torch.empty_like(Uc)]), ints([Co, Co]), ints([Ci, Ci]), 2,
+                                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'chunked batch')
+    assert torch.equal(Ucb, Uc)
     ah = None if add is None else add.to(dev).permute(0, 2, 3, 1).contiguous()
     y, stats = T.wino_fused_conv_nhwc(xh, Uc, N, H, W, ah, want_stats=True)
     scale = float(ref.abs().max())
