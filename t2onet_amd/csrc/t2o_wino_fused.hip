@@ -75,6 +75,13 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ void vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The MFMA as a volatile asm statement: the intrinsic has no memory dependence, and the compiler moved the MFMAs of neighbouring
+// plane pairs across sched_barriers to where their operands had only just been requested (lgkmcnt stalls of ~100 cycles each).
+// Volatile asm statements keep their order.  (The accumulators are read only after the loop's last barrier and an explicit
+// s_nop: the hazard recognizer does not see an MFMA here.)
+__device__ __forceinline__ void mfma_asm(f32x16& c, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
 template <int kFirst, int kLast, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (kFirst < kLast) {
@@ -154,12 +161,14 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     constexpr int p = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1, q = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3;
     if constexpr (r == 1) tr[r][j] = make_float2(d[p][j].x + d[q][j].x, d[p][j].y + d[q][j].y);
     else tr[r][j] = make_float2(d[p][j].x - d[q][j].x, d[p][j].y - d[q][j].y);
+    asm volatile("" : "+v"(tr[r][j].x), "+v"(tr[r][j].y));      // (pins the step between the MFMAs it was written between)
   };
   auto t_col = [&](auto kc) {                             // k = 4 i + c
     constexpr int k = decltype(kc)::value, i = k >> 2, c = k & 3;
     constexpr int p = c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 2 : 1, q = c == 0 ? 2 : c == 1 ? 2 : c == 2 ? 1 : 3;
     if constexpr (c == 1) tv[i][c] = make_float2(tr[i][p].x + tr[i][q].x, tr[i][p].y + tr[i][q].y);
     else tv[i][c] = make_float2(tr[i][p].x - tr[i][q].x, tr[i][p].y - tr[i][q].y);
+    asm volatile("" : "+v"(tv[i][c].x), "+v"(tv[i][c].y));
   };
   auto t_store = [&](auto kc, int vb) {
     constexpr int k = decltype(kc)::value;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     constexpr int p = decltype(pc)::value, slot = decltype(slotc)::value, m = decltype(mc)::value, w = m & 1, e = m >> 1;
     const float av = e == 0 ? fa[slot][w].x : e == 1 ? fa[slot][w].y : e == 2 ? fa[slot][w].z : fa[slot][w].w;
     const float bv = e == 0 ? fb[slot][w].x : e == 1 ? fb[slot][w].y : e == 2 ? fb[slot][w].z : fb[slot][w].w;
-    acc[p + w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p + w], 0, 0, 0);
+    mfma_asm(acc[p + w], av, bv);
   };
   auto x_piece = [&](auto kc, int buf, int adv) {
     constexpr int k = decltype(kc)::value;
@@ -231,8 +240,9 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   // chunks again, into buffers nobody reads any more.  Measured (tools/diag/wf_clock.hip): a wave's 64 MFMAs take their 4,096
   // pipe cycles whatever else happens, and everything issued OUTSIDE them is added time (first version: 877 cycles of DMA issue
   // and loads + 551 of transform per chunk) -- so every other instruction sits BETWEEN two MFMAs of this wave, pinned there:
-  //   pair 0: the 11 DMA pieces; pair 1: the transform's 16 loads; pair 2: its 16 row steps; pair 3: its 16 column steps;
-  //   pair 4: its 16 stores; every pair's fragments are requested one pair ahead.
+  //   behind the barrier (before pair 7): the NEXT transform's 16 loads; pair 1: this one's 16 row steps; pair 2: its 16 column
+  //   steps; pair 3: its 16 stores;
+  //   pairs 0, 5, 6: the 11 DMA pieces, one per second gap; every pair's fragments are requested one pair ahead.
   auto chunk_body = [&](int kBuf, int c) {              // (kBuf as a run-time value: unrolled by two with constant buffers the
                                                         // register allocation spilled 86 values)
 #ifdef T2O_WF_DIAG
@@ -242,44 +252,47 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     const int cu = c + 1 < chunks ? c + 1 : chunks - 1;
     const size_t uoff = (size_t)cu * uchunk;
     const unsigned ulds = lds_u_wave + (unsigned)((kBuf ^ 1) * kUBuf);
-    frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kBuf);
-    frag_read(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, kBuf);
-    __builtin_amdgcn_sched_barrier(0);
+    // The chunk's barrier sits between plane pairs 6 and 7: behind it this wave requests the NEXT chunk's first fragments and
+    // the next transform's 16 patch values, and pair 7's MFMAs (operands in registers since pair 5) cover their latency.  (With
+    // the barrier at the chunk's end, pair 0 took 1,330 cycles: reads, LDS latency and only then its first MFMA.)
     static_for<0, 8>([&](auto kc) {
       constexpr int k = decltype(kc)::value;              // plane pair
+      if constexpr (k == 7) {
+        vm_wait0();
+        __syncthreads();
+        frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kBuf ^ 1);     // pair 0 of chunk c + 1
+        static_for<0, 16>([&](auto jc) { t_load(jc, kBuf); });                                        // patch of chunk c + 2
+        __builtin_amdgcn_sched_barrier(0);
+      }
       static_for<0, 8>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         mfma_one(std::integral_constant<int, 2 * k>{}, std::integral_constant<int, k & 1>{}, mc);
         __builtin_amdgcn_sched_barrier(0);
+        // the 11 DMA pieces one per second MFMA gap (back to back they cost ~50 cycles each beyond the MFMA they hide behind)
         if constexpr (k == 0) {
-          if constexpr (m < 3) x_piece(mc, kBuf, adv);
           dma_u_piece(mc, uoff, ulds);
+        } else if constexpr (k == 4 && (m & 1) == 0 && m < 6) {
+          x_piece(std::integral_constant<int, m / 2>{}, kBuf, adv);
         } else if constexpr (k == 1) {
-          t_load(std::integral_constant<int, 2 * m>{}, kBuf ^ 1);
-          t_load(std::integral_constant<int, 2 * m + 1>{}, kBuf ^ 1);
-        } else if constexpr (k == 2) {
           t_row(std::integral_constant<int, 2 * m>{});
           t_row(std::integral_constant<int, 2 * m + 1>{});
-        } else if constexpr (k == 3) {
+        } else if constexpr (k == 2) {
           t_col(std::integral_constant<int, 2 * m>{});
           t_col(std::integral_constant<int, 2 * m + 1>{});
-        } else if constexpr (k == 4) {
+        } else if constexpr (k == 3) {
           t_store(std::integral_constant<int, 2 * m>{}, kBuf ^ 1);
           t_store(std::integral_constant<int, 2 * m + 1>{}, kBuf ^ 1);
         }
-        // the fragments of pair k + 2 go into the slot pair k is leaving, behind its last MFMA
+        // the fragments of pair k + 2 go into the slot pair k is leaving, behind its last MFMA (pair 6's successor, pair 0 of the
+        // next chunk, is requested behind the barrier above; pair 7's is pair 1 of the next chunk)
         if constexpr (m == 7 && k + 2 < 8) frag_read(std::integral_constant<int, 2 * (k + 2)>{}, std::integral_constant<int, k & 1>{}, kBuf);
+        if constexpr (m == 7 && k == 7) frag_read(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, kBuf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       });
 #ifdef T2O_WF_DIAG
       { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += (unsigned)(tn - tprev); tprev = tn; }
 #endif
     });
-    vm_wait0();
-    __syncthreads();
-#ifdef T2O_WF_DIAG
-    { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[8] += (unsigned)(tn - tprev); }
-#endif
   };
 
   // ---- pipeline: DMA x(c + 2), U(c + 1) | transform(c + 1) | MFMA(c), one barrier per chunk
@@ -291,6 +304,9 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   transform_all(0, 0);
   vm_wait0();
   __syncthreads();
+  frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);        // chunk 0: pairs 0 and 1, the patch of chunk 1
+  frag_read(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, 0);
+  static_for<0, 16>([&](auto jc) { t_load(jc, 1); });
 #ifdef T2O_WF_DIAG
   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
@@ -300,6 +316,7 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     return (((size_t)n * a.H + by * 16 + 2 * (t >> 3)) * a.W + bx * 16 + 2 * (t & 7)) * a.Co + co0 + 32 * ch + ln;
   };
   for (int c = 0; c < chunks; ++c) chunk_body(c & 1, c);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // (the last MFMA's 16 passes, before any accumulator is read)
 #ifdef T2O_WF_DIAG
   const unsigned long long t_end = __builtin_amdgcn_s_memtime();
 #endif

@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
   printf("C=%d %dx%d: kernel %.1f us, %u workgroups, %d chunks (shader cycles)\n", C, H, W, ms * 1e3, grid, chunks);
   printf("  per wave (median): prologue %.0f, loop %.0f (= %.0f per chunk; its 64 MFMAs alone: 4096), epilogue issue %.0f cycles\n",
          med(v[0]), med(v[1]), med(v[1]) / chunks, med(v[2]));
-  const char* what[8] = {"DMA pieces", "transform loads", "transform rows", "transform columns", "transform stores", "-", "-", "-"};
+  const char* what[8] = {"8 U pieces", "transform rows", "transform columns", "transform stores", "3 x pieces", "-", "-", "barrier, reads"};
   for (int k = 0; k < 8; ++k) printf("  plane pair %d (8 MFMAs = 512 cycles) + %-18s %6.0f cycles per chunk\n", k, what[k], med(v[3 + k]) / chunks);
   printf("  wait for the DMA + barrier %6.0f cycles per chunk\n", med(v[11]) / chunks);
   return 0;
