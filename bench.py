@@ -704,7 +704,8 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
             return ctx['max_over_ranks'](time.perf_counter() - t1) / n * 1e3
         sup = timed(lambda: tr.supervised_step(x, y, img, img_y, gt, lengths=lengths), n_sup, 2)
         pair = timed(lambda: (tr.supervised_step(x, y, img, img_y, gt, lengths=lengths),
-                              tr.episode_step(x, img, img_y[:, -1], lengths=lengths)), max(2, n_sup // 2), 1)
+                              tr.episode_step(x, img, img_y[:, -1], lengths=lengths)), max(3, n_sup // 2), 2)   # (2 warm-up pairs: the
+                                                                                   # caching allocator settles on the alternation's pattern)
         extra = {'supervised_step': {'ms_per_step': round(sup, 3), 'images_per_sec': round(world * B / sup * 1e3, 1), 'steps': n_sup,
                                      'what': 'teacher-forced step (train_seq2seqL1.py:51-65): START + 5 operators + END, NLL + MSE, '
                                              'six encoder passes'},
@@ -1010,12 +1011,9 @@ def worker(args):
     line['executor'] = executor
     try:                                   # the train step's dominant kernel on its own, HIP-event timed: the line's `roofline`
         line['conv_kernels'], line['roofline'] = conv_kernel_table(B, H, W, device)
-        line['roofline']['traffic'] = pmc_launch_traffic('k_wino_fused<false>' if line['roofline'].get('kernel') == 'k_wino_fused' else 'k_conv3x3_fwd<2, 1>')
+        line['roofline']['traffic'] = pmc_launch_traffic('k_wino_fused<0>' if line['roofline'].get('kernel') == 'k_wino_fused' else 'k_conv3x3_fwd<2, 1>')
     except Exception as e:                 # noqa: BLE001
         line['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line['cpu_baseline'] = cpu_baselines(H, W, args.cpu_sample, args.cpu_train_sample)
-
     rc = [0]
     if args.no_train:
         line['error'] = '--no-train: executor legs only, no headline value'
@@ -1052,6 +1050,14 @@ def worker(args):
         line['error'] = 'train step: %s: %s' % (type(e).__name__, e)
         rc[0] = 1
     watchdog.cancel()
+    # the CPU baseline LAST (reported, never the target): run before the train leg, its eager CPU autograd over 64 images left
+    # the process in a state in which the supervised / episode alternation read 100-113 ms per pair instead of 83 (the headline
+    # and each step on its own were unaffected; not the intra-op thread count -- pinned to 1, the same)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            line['cpu_baseline'] = cpu_baselines(H, W, args.cpu_sample, args.cpu_train_sample)
+        except Exception as e:             # noqa: BLE001
+            line['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     emit()
     if dist is not None:
         dist.barrier()
