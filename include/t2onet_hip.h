@@ -479,7 +479,9 @@ int t2o_wino_output_transform(const float* M, const float* addend, float* y, flo
 int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C, void* stream);
 /* t2o_wino_input_transform(dy) and t2o_wino_dy_transform(dy) in one pass over dy (a layer's backward needs both) */
 int t2o_wino_dy_transforms(const float* dy, float* V, float* Ad, int N, int H, int W, int C, void* stream);
-int t2o_wino_dy_transforms_ld(const float* dy, float* V, float* Ad, int N, int H, int W, int C, int ad_plane_rows, void* stream);   /* Ad as a row range of a (16, ad_plane_rows, C) tensor */
+int t2o_wino_dy_transforms_ld(const float* dy, float* V, float* Ad, int N, int H, int W, int C, int ad_plane_rows, void* stream);
+/* A dY A^T alone into a row range of a larger (16, plane_rows, C) tensor (the data gradient then runs on t2o_wino_fused_conv_nhwc) */
+int t2o_wino_dy_transform_ld(const float* dy, float* Ad, int N, int H, int W, int C, int plane_rows, void* stream);   /* Ad as a row range of a (16, ad_plane_rows, C) tensor */
 int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int splits, int accumulate, void* stream);
 /* the batched fp32 matrix-core GEMMs behind them (t2o_conv.hip k_gemm_nt / k_gemm_tn: the forward convolution's LDS-DMA
  * machinery without taps), dense row-major operands:

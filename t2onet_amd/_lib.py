@@ -101,6 +101,7 @@ SIGNATURES = {
     't2o_wino_dy_transform': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     't2o_wino_dy_transforms': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     't2o_wino_dy_transforms_ld': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_wino_dy_transform_ld': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_wino_dw_transform': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     't2o_conv3x3_dgrad_pre_nhwc': (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     't2o_conv3x3_dgrad_bnsums_rows': (_I, [_I, _I, _I, _I, _I]),

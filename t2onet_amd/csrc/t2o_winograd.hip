@@ -417,6 +417,17 @@ int t2o_wino_dy_transform(const float* dy, float* Ad, int N, int H, int W, int C
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transform: launch failed");
 }
 
+int t2o_wino_dy_transform_ld(const float* dy, float* Ad, int N, int H, int W, int C, int plane_rows, void* stream) {
+  if (!dy || !Ad || !wino_shape_ok(N, H, W, C)) return set_error(T2O_EINVAL, "wino_dy_transform: null pointer or bad shape (H, W even; C a power of two in [4, 1024])");
+  if ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(Ad)) & 15) return set_error(T2O_EINVAL, "wino_dy_transform: tensors must be 16-byte aligned");
+  const int Tpad = t2o_wino_padded_tiles(N, H, W);
+  if (Tpad <= 0) return set_error(T2O_EUNSUPPORTED, "wino_dy_transform: too many tiles");
+  if (plane_rows != 0 && plane_rows < Tpad) return set_error(T2O_EINVAL, "wino_dy_transform: plane_rows smaller than the padded tile count");
+  const size_t work = (size_t)Tpad * (C / 4);
+  k_wino_dy<<<(unsigned)((work + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(dy, Ad, N, H, W, C, Tpad, plane_rows ? plane_rows : Tpad);
+  return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "wino_dy_transform: launch failed");
+}
+
 int t2o_wino_dy_transforms(const float* dy, float* V, float* Ad, int N, int H, int W, int C, void* stream) {
   return t2o_wino_dy_transforms_ld(dy, V, Ad, N, H, W, C, 0, stream);
 }

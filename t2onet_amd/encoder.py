@@ -108,7 +108,7 @@ class TrunkPlan:
 
     def fused_convs(self):
         return [c for b in self.blocks for c in (b.conv1, b.conv2)
-                if c.stride[0] == 1 and c.weight.shape[0] in (64, 128) and c.weight.shape[1] in (64, 128)] if (_WINO_FUSED and _WINOGRAD) else []
+                if c.stride[0] == 1 and c.weight.shape[0] in (64, 128, 256, 512) and c.weight.shape[1] in (64, 128, 256, 512)] if (_WINO_FUSED and _WINOGRAD) else []
 
     def _chunked(self, lib, st, store, convs, src, swap):
         """store[('c', id(conv))] = chunk-major Winograd filters (Ck/8, 16, Cn, 8) of src(conv) (Cn,3,3,Ck) for the on-chip kernel:
@@ -400,7 +400,8 @@ class _TrunkFn(torch.autograd.Function):
             if plan.wino(conv, Hi, Wi):
                 keep = []
                 y, stats = wino_conv_nhwc(x, uf[id(conv)], Nn, Hi, Wi, None, True, keep_v=keep,
-                                          v_out=arena.wino_slot('V', conv, apass) if apass is not None else None)
+                                          v_out=arena.wino_slot('V', conv, apass) if apass is not None else None,
+                                          uc=uf.get(('c', id(conv))))      # (the on-chip kernel where the map is a multiple of 16)
                 kept_v[id(conv)] = keep[0]                     # (4x the layer's input: its weight gradient starts from it)
                 return y, stats
             if plan.fused_wino(conv, Hi, Wi):
@@ -538,7 +539,8 @@ class _TrunkFn(torch.autograd.Function):
             if V is None:
                 V = wino_input(x, N, Hi, Wi)
             ad_out = arena.wino_slot('Ad', conv, apass) if arena is not None else None
-            wino_backward_nhwc(dy, V, wt['wino'][id(conv)], g(conv.weight), dx, N, Hi, Wi, addend, acc, ad_out)
+            wino_backward_nhwc(dy, V, wt['wino'][id(conv)], g(conv.weight), dx, N, Hi, Wi, addend, acc, ad_out,
+                               uc=wt['wino'].get(('c', id(conv))))
 
         def dgrad3(conv, dy, dx, addend, Hi, Wi, Hn, Wn):
             """dx (N,Hi,Wi,Ci) = data gradient of conv for dy (N,Hn,Wn,Co) (+ addend, stride 1 only)."""
@@ -546,7 +548,7 @@ class _TrunkFn(torch.autograd.Function):
             Co, Ci = w.shape[0], w.shape[1]
             s = conv.stride[0]
             if plan.wino(conv, Hi, Wi):
-                wino_conv_nhwc(dy, wt['wino'][id(conv)], N, Hi, Wi, addend, False, out=dx)
+                wino_conv_nhwc(dy, wt['wino'][id(conv)], N, Hi, Wi, addend, False, out=dx, uc=wt['wino'].get(('c', id(conv))))
                 return
             if plan.fused_wino(conv, Hi, Wi):
                 wino_fused_conv_nhwc(dy, wt['wino'][('c', id(conv))], N, Hi, Wi, addend, False, out=dx)

@@ -1455,7 +1455,7 @@ def wino_wgrad_nhwc(V, dy, dw, N, H, W, accumulate):
     _lib.check(lib.t2o_wino_dw_transform(_ptr(dU), _ptr(dw), Co, Ci, dU.shape[0], 1 if accumulate else 0, st), 't2o_wino_dw_transform')
 
 
-def wino_backward_nhwc(dy, Vx, Ud, dw, dx, N, H, W, addend, accumulate, ad_out=None):
+def wino_backward_nhwc(dy, Vx, Ud, dw, dx, N, H, W, addend, accumulate, ad_out=None, uc=None):
     """Both gradients of a Winograd layer from one pass over dy (N,H,W,Co): dx (N,H,W,Ci) = data gradient (+ addend) with
     Ud (16,Ci,Co) the transformed mirrored filter, dw (Co,3,3,Ci) (+)= weight gradient with Vx (16,Tpad,Ci) the forward's
     transformed input.  ad_out: a (16, Tpad, Co) row range of a larger tensor that receives A dY A^T instead -- the weight
@@ -1465,6 +1465,15 @@ def wino_backward_nhwc(dy, Vx, Ud, dw, dx, N, H, W, addend, accumulate, ad_out=N
     st = _stream(dev)
     Co, Ci = dy.shape[-1], Vx.shape[2]
     Tpad = Vx.shape[1]
+    if uc is not None and lib.t2o_wino_fused_supported(N, H, W, Co, Ci):
+        # uc = the mirrored filter in the on-chip kernel's layout: the data gradient in ONE launch; only A dY A^T (the weight
+        # gradient's operand) is still formed by a transform pass
+        Ad = ad_out if ad_out is not None else torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
+        _lib.check(lib.t2o_wino_dy_transform_ld(_ptr(dy), _ptr(Ad), N, H, W, Co, Ad.stride(0) // Co, st), 't2o_wino_dy_transform_ld')
+        wino_fused_conv_nhwc(dy, uc, N, H, W, addend, False, out=dx)
+        if ad_out is None and not wino_dw_from(Ad, Vx.contiguous(), dw, accumulate):
+            raise RuntimeError('wino_backward_nhwc: no split for %d tile rows' % Tpad)
+        return
     Vd = torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
     if ad_out is None:
         Ad = torch.empty((16, Tpad, Co), dtype=torch.float32, device=dev)
@@ -1490,7 +1499,7 @@ def wino_dw_from(Ad, V, dw, accumulate):
     return True
 
 
-def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_v=None, v_out=None):
+def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_v=None, v_out=None, uc=None):
     """x (N,H,W,Ci) NHWC buffer, U (16,Co,Ci) -> y (N,H,W,Co) (+ addend) [, stats rows for the batch norm that follows].
     keep_v: a list that receives V (the weight gradient reuses it: wino_wgrad_nhwc); v_out: where V is to be written
     (wino_input's `out`)."""
@@ -1498,6 +1507,14 @@ def wino_conv_nhwc(x, U, N, H, W, addend=None, want_stats=False, out=None, keep_
     dev = x.device
     st = _stream(dev)
     Co = U.shape[1]
+    if uc is not None and lib.t2o_wino_fused_supported(N, H, W, x.shape[-1], Co):
+        # uc = U in the on-chip kernel's layout: the convolution in ONE launch; V is formed only when the weight gradient
+        # will want it (keep_v / v_out)
+        if keep_v is not None or v_out is not None:
+            V = wino_input(x, N, H, W, v_out)
+            if keep_v is not None:
+                keep_v.append(V)
+        return wino_fused_conv_nhwc(x, uc, N, H, W, addend, want_stats, out=out)
     V = wino_input(x, N, H, W, v_out)
     if keep_v is not None:
         keep_v.append(V)

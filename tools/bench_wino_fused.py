@@ -21,13 +21,18 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for c, h in ((64, 64), (128, 32)):
+for c, h in ((64, 64), (128, 32), (256, 16)):
     x = torch.randn(B, c, h, h, device=dev).contiguous(memory_format=torch.channels_last)
     w = torch.randn(c, c, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
     xh = x.permute(0, 2, 3, 1)
     Uc = T.wino_u_chunked(T.wino_weight(w.permute(0, 2, 3, 1).contiguous(), c, c))
     out = torch.empty(B, h, h, c, device=dev)
     d = timeit(lambda: T.conv3x3_forward(x, w, want_stats=True))
+    if c >= 256:
+        U = T.wino_weight(w.permute(0, 2, 3, 1).contiguous(), c, c)
+        xc = xh.contiguous()
+        sp = timeit(lambda: T.wino_conv_nhwc(xc, U, B, h, h, None, True))
+        print('   separate-pass Winograd pipeline %.1f us (input transform + 16 GEMMs + output transform)' % sp)
     f = timeit(lambda: T.wino_fused_conv_nhwc(xh, Uc, B, h, h, None, True, out=out))
     f2 = timeit(lambda: T.wino_fused_conv_nhwc(xh, Uc, B, h, h, None, False, out=out))
     ref = torch.nn.functional.conv2d(x, w, None, 1, 1)
