@@ -34,6 +34,7 @@ using t2o::set_error;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kWfThreads = 256;
 constexpr int kXRow = 20;                        // slots per patch row (18 used)
@@ -151,28 +152,28 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   // B^T d B of this thread's (tile, channel pair), statement by statement (the chunk loop deals the statements out between
   // MFMAs): 16 loads d[i][j]; rows tr = B^T d: (d0 - d2, d1 + d2, d2 - d1, d1 - d3) per column; the same along the columns
   // (t2o_winograd.hip k_wino_input); 16 stores, plane xi = 4 i + j
-  float2 d[4][4], tr[4][4], tv[4][4];
+  v2f d[4][4], tr[4][4], tv[4][4];                        // (two channels per register pair: v_pk_add_f32, half the vector instructions)
   auto t_load = [&](auto kc, int xb) {
     constexpr int k = decltype(kc)::value;
-    d[k >> 2][k & 3] = *reinterpret_cast<const float2*>(&Xs[xb][0] + xoff[k >> 2][k & 3]);
+    d[k >> 2][k & 3] = *reinterpret_cast<const v2f*>(&Xs[xb][0] + xoff[k >> 2][k & 3]);
   };
   auto t_row = [&](auto kc) {                             // k = 4 j + r
     constexpr int k = decltype(kc)::value, j = k >> 2, r = k & 3;
     constexpr int p = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1, q = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3;
-    if constexpr (r == 1) tr[r][j] = make_float2(d[p][j].x + d[q][j].x, d[p][j].y + d[q][j].y);
-    else tr[r][j] = make_float2(d[p][j].x - d[q][j].x, d[p][j].y - d[q][j].y);
-    asm volatile("" : "+v"(tr[r][j].x), "+v"(tr[r][j].y));      // (pins the step between the MFMAs it was written between)
+    if constexpr (r == 1) tr[r][j] = d[p][j] + d[q][j];
+    else tr[r][j] = d[p][j] - d[q][j];
+    asm volatile("" : "+v"(tr[r][j]));                      // (pins the step between the MFMAs it was written between)
   };
   auto t_col = [&](auto kc) {                             // k = 4 i + c
     constexpr int k = decltype(kc)::value, i = k >> 2, c = k & 3;
     constexpr int p = c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 2 : 1, q = c == 0 ? 2 : c == 1 ? 2 : c == 2 ? 1 : 3;
-    if constexpr (c == 1) tv[i][c] = make_float2(tr[i][p].x + tr[i][q].x, tr[i][p].y + tr[i][q].y);
-    else tv[i][c] = make_float2(tr[i][p].x - tr[i][q].x, tr[i][p].y - tr[i][q].y);
-    asm volatile("" : "+v"(tv[i][c].x), "+v"(tv[i][c].y));
+    if constexpr (c == 1) tv[i][c] = tr[i][p] + tr[i][q];
+    else tv[i][c] = tr[i][p] - tr[i][q];
+    asm volatile("" : "+v"(tv[i][c]));
   };
   auto t_store = [&](auto kc, int vb) {
     constexpr int k = decltype(kc)::value;
-    *reinterpret_cast<float2*>(&Vs[vb][0] + k * 2048 + voff_w) = tv[k >> 2][k & 3];
+    *reinterpret_cast<v2f*>(&Vs[vb][0] + k * 2048 + voff_w) = tv[k >> 2][k & 3];
   };
   auto transform_all = [&](int xb, int vb) {              // (prologue: chunk 0)
     static_for<0, 16>([&](auto kc) { t_load(kc, xb); });
