@@ -1539,6 +1539,12 @@ def wino_fused_conv_nhwc(x, Uc, N, H, W, addend=None, want_stats=False, out=None
     lib = _lib.load()
     dev = x.device
     Ci, Co = Uc.shape[0] * 8, Uc.shape[2]
+    if not (x.is_contiguous() and x.numel() == N * H * W * Ci and Uc.is_contiguous()):
+        raise ValueError('wino_fused_conv_nhwc: x must be a dense (N,H,W,%d) buffer and Uc dense' % Ci)
+    if addend is not None and not (addend.is_contiguous() and addend.numel() == N * H * W * Co):
+        raise ValueError('wino_fused_conv_nhwc: addend must be a dense (N,H,W,%d) buffer' % Co)
+    if out is not None and not (out.is_contiguous() and out.numel() == N * H * W * Co):
+        raise ValueError('wino_fused_conv_nhwc: out must be a dense (N,H,W,%d) buffer' % Co)
     y = out if out is not None else torch.empty((N, H, W, Co), dtype=torch.float32, device=dev)
     stats = torch.empty((lib.t2o_wino_fused_stats_rows(N, H, W), 2, Co), dtype=torch.float32, device=dev) if want_stats else None
     zeros = _zero_block(dev)
