@@ -479,24 +479,13 @@ def _median_time(fn, reps, budget_s):
     return ts[len(ts) // 2], len(ts)
 
 
-def _pick_threads(probe):
-    """Eager ATen ops on 50 MB tensors do not scale to every core of a big host (256 threads ran 50x slower
-    than 32 on the first MI355X node): pick the thread count on a short probe."""
+def _pick_threads(probe=None):
+    """Eager ATen ops on 50 MB tensors do not scale to every core of a big host (256 threads ran 50x slower than 32 on the
+    first MI355X node, and a timing probe chose 16 in one run and 32 in the next): a FIXED count, min(32, logical CPUs)."""
     import torch
-    ncpu = os.cpu_count() or 1
-    best = None
-    for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
-        torch.set_num_threads(nt)
-        probe()
-        t0 = time.perf_counter()
-        probe()
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, nt)
-        elif dt > 1.5 * best[0]:
-            break                                   # past the knee: more threads only get slower
-    torch.set_num_threads(best[1])
-    return best[1]
+    nt = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(nt)
+    return nt
 
 
 def _host_info():
@@ -522,8 +511,8 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
     """BASELINE.md section 3 through oracle/cpu_ref.py -- the eager-PyTorch restatement of the reference, validated against
     it by the committed goldens -- on this node's host cores.  The object's own value is configs[2], the headline's
     workload (the episode/L1 train step at its full batch); `configs_0` (one image, brightness->contrast->saturation) and
-    `configs_1` (6-op sequence fwd + L1 + bwd, bs=64) are sub-objects.  `cores` = `threads` = torch threads used (chosen by
-    a probe: all hardware threads are far slower on eager 50 MB ops), `physical_cores` = what the node has."""
+    `configs_1` (6-op sequence fwd + L1 + bwd, bs=64) are sub-objects.  `cores` = `threads` = torch threads used (fixed at
+    min(32, logical CPUs): all hardware threads are far slower on eager 50 MB ops), `physical_cores` = what the node has."""
     import torch
     from oracle import cpu_ref, synth
     opt = cpu_ref.default_opt()
@@ -536,23 +525,23 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
         cpu_ref.l1_loss(out, tgt).backward()
 
     img, tgt, params = make_inputs(CFG2_OPS, sample_cfg2, H, W, 'cpu')
-    threads = _pick_threads(lambda: seq_once(CFG2_OPS, img[:8], tgt[:8], params[:, :8]))
+    threads = _pick_threads()
     med2, n2 = _median_time(lambda: seq_once(CFG2_OPS, img, tgt, params), 7, 25.0)
-    cfg1 = {'value': round(sample_cfg2 / med2, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+    cfg1 = {'value': round(sample_cfg2 / med2, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'reps': n2,
             'config': 'configs[1]',
             'sample': 'oracle/cpu_ref.py eager fp32, ops %s fwd+L1+bwd, bs=%d %dx%d, median of %d reps (%.2f s each), '
-                      '%d torch threads (chosen by a probe)' % (CFG2_OPS, sample_cfg2, H, W, n2, med2, threads)}
+                      '%d torch threads (fixed)' % (CFG2_OPS, sample_cfg2, H, W, n2, med2, threads)}
     # configs[0]: single 256x256 image, 3-op sequence, forward + L1 + backward
     ops1 = [0, 1, 2]
     i1, t1, p1 = make_inputs(ops1, 1, H, W, 'cpu')
     torch.set_num_threads(min(threads, 8))
     med1, n1 = _median_time(lambda: seq_once(ops1, i1, t1, p1), 15, 5.0)
-    cfg0 = {'value': round(1.0 / med1, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+    cfg0 = {'value': round(1.0 / med1, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port', 'reps': n1,
             'config': 'configs[0]', 'sample': 'one %dx%d image, ops %s fwd+L1+bwd, median of %d reps (%.4f s each)'
                                               % (H, W, ops1, n1, med1)}
     torch.set_num_threads(threads)
-    # configs[2] -- the HEADLINE's own baseline: the episode/L1 train step at its full batch (fwd + END select + L1 + bwd +
-    # Adam), 1 warm-up + 1..2 reps
+    # configs[2] -- the HEADLINE's own baseline: the episode/L1 train step (fwd + END select + L1 + bwd + Adam) on a bounded
+    # sample of the batch (default 32 of the 64 images: ~6 s per step on the MI355X host), 1 warm-up + exactly 3 reps
     res = {'value': None, 'unit': 'images/sec', 'cores': threads, 'threads': threads, 'physical_cores': host['physical_cores'],
            'logical_cpus': host['logical_cpus'], 'kind': 'port', 'config': 'configs[2]', 'sample': None, 'host': host}
     try:
@@ -570,10 +559,11 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
             pred = cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], opt.end_id)
             cpu_ref.l1_loss(pred, xtgt).backward()
             adam.step()
-        med3, n3 = _median_time(train_once, 2, 12.0)
+        med3, n3 = _median_time(train_once, 3, 1e9)
         res['value'] = round(B3 / med3, 3)
+        res['reps'] = n3
         res['sample'] = ('oracle/cpu_ref.py episode_forward (training mode, sampled ops) + END select + L1 + backward + Adam, '
-                         'bs=%d %dx%d fp32, median of %d reps after 1 warm-up (%.2f s each), %d torch threads (chosen by a probe) of '
+                         'bs=%d %dx%d fp32, median of %d reps after 1 warm-up (%.2f s each), %d torch threads (fixed) of '
                          '%s physical cores' % (B3, H, W, n3, med3, threads, host['physical_cores']))
     except Exception as e:                     # noqa: BLE001
         res['error'] = '%s: %s' % (type(e).__name__, e)
@@ -822,7 +812,9 @@ def conv_kernel_table(B, H, W, device, reps=40):
                 'kernel': ('k_wino_input + k_gemm_nt (16 GEMMs) + k_wino_output<stats>' if name == 'wino_fwd'
                            else 'k_wino_dy + k_gemm_tn (16 GEMMs over the tiles) + k_wino_dw (V kept from the forward)')}
     # the kernel that runs these layers in the train step since round 4: Winograd F(2x2,3x3) with V and M kept on chip
-    for C, div in ((64, 4), (128, 8)):
+    # (4 + 3 + 3 stride-1 layers of the 64- / 128- / 256-channel stages x forward + data gradient x 5 encoder passes = 100 launches
+    # per step over its epilogue variants)
+    for C, div in ((64, 4), (128, 8), (256, 16)):
         h, w = H // div, W // div
         if not lib.t2o_wino_fused_supported(B, h, w, C, C):
             continue
@@ -859,16 +851,123 @@ def conv_kernel_table(B, H, W, device, reps=40):
     flop = dom[0]['GFLOP'] * 1e9
     executed = dom[0].get('executed_GFLOP', dom[0]['GFLOP']) * 1e9
     tf = executed / avg_ms / 1e9
-    return rows, {'bound': 'mfma', 'kernel': kernel, 'of': 'train step (encoder 3x3 stride-1 convolutions, forward + data gradient, 64- and 128-channel stages)',
+    return rows, {'bound': 'mfma', 'kernel': kernel, 'of': 'train step: encoder 3x3 stride-1 convolutions, forward + data gradient, 64/128/256-channel stages',
                   'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(tf / FP32_MATRIX_PEAK_TF, 4),
                   'traffic': None, 'executed_flop_per_launch': executed, 'algorithmic_flop_per_launch': flop,
                   'credited_achieved': round(flop / avg_ms / 1e9, 2), 'credited_frac': round(flop / avg_ms / 1e9 / FP32_MATRIX_PEAK_TF, 4),
-                  'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': 60,
+                  'avg_launch_ms': round(avg_ms, 5), 'launches_per_step': 100 if len(dom) == 6 else None,
                   'note': 'dominant kernel of the train step.  k_wino_fused: Winograd F(2x2,3x3) in one launch, 16 of the direct '
                           'convolution\'s 36 multiplies.  frac = the MFMA work the launch EXECUTES (2 x 16/36 x 9 x C^2 x pixels) / time / '
                           'the v_mfma_f32_32x32x2_f32 dense peak -- a physical fraction; credited_* use the direct convolution\'s '
                           'algorithmic FLOP (2 x 9 x C^2 x pixels, SURVEY 8(d)) and may exceed 1.  Duration = mean of HIP-event timed '
-                          'launches over the four (stage, direction) shapes it runs with, equally often'}
+                          'launches over the (stage, direction) shapes it runs with, equally often'}
+
+
+# ---------------------------------------------------------------------------------------------
+# the printed line: compact (the driver parses the LAST stdout line); everything else goes to bench_detail.json
+# ---------------------------------------------------------------------------------------------
+LINE_LIMIT = 6144                       # bytes; round 4's 24 KB line was not parsed by the driver
+REQUIRED_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short(s, n=160):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + '...'
+
+
+def compact_line(detail, detail_path=None):
+    """The one JSON line bench.py prints: the contract's keys, the three roofline objects, the CPU baseline and a few
+    numbers per leg -- no per-kernel tables, no prose.  `detail` is the full record (written to bench_detail.json)."""
+    out = _pick(detail, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                         'vs_baseline', 'dtype', 'data'))
+    out['metric'] = _short(out.get('metric'), 200)
+    cfg = detail.get('config', {})
+    out['config'] = {k: _short(v, 200) for k, v in cfg.items()}
+    if 'error' in detail:
+        out['error'] = _short(detail['error'], 300)
+    rf = detail.get('roofline') or {}
+    out['roofline'] = rf if 'error' in rf else _pick(rf, (
+        'bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'launches_per_step',
+        'executed_flop_per_launch', 'credited_frac'))
+    if 'of' in rf:
+        out['roofline']['of'] = _short(rf['of'], 120)
+    er = detail.get('executor_roofline')
+    if er:
+        out['executor_roofline'] = _pick(er, ('bound', 'kernel', 'of', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                                              'moved_bytes_per_launch', 'avg_launch_ms', 'credited_frac'))
+    tr = detail.get('train_roofline')
+    if tr:
+        out['train_roofline'] = _pick(tr, ('bound', 'achieved', 'peak', 'unit', 'frac', 'executed_TFLOPs', 'executed_frac'))
+    ex = {}
+    for name, leg in (detail.get('executor') or {}).items():
+        if not isinstance(leg, dict):
+            ex[name] = _short(leg, 200)
+            continue
+        row = {}
+        for kind in ('fused', 'value_grad', 'materialised'):
+            if kind in leg:
+                row[kind] = _pick(leg[kind], ('value', 'ms_per_step', 'frac_of_peak', 'fused_min_frac'))
+        if 'api_path' in leg:
+            row['api_path_ms'] = leg['api_path'].get('ms_per_step', leg['api_path'].get('error'))
+        ex[name] = row
+    if ex:
+        out['executor'] = ex
+    ts = detail.get('train_step')
+    if ts:
+        t = _pick(ts, ('host_enqueue_ms_per_step', 'global_batch', 'loss', 'step_hipgraphs', 'ms_per_step_over_ranks',
+                       'allreduce_ms', 'allreduce_bytes'))
+        if isinstance(ts.get('supervised_step'), dict):
+            t['supervised_ms'] = ts['supervised_step'].get('ms_per_step', _short(ts['supervised_step'].get('error'), 120))
+        if isinstance(ts.get('alternating_pair'), dict):
+            t['alternating_pair_ms'] = ts['alternating_pair'].get('ms_per_pair')
+        out['train_step'] = t
+    cb = detail.get('cpu_baseline')
+    if cb is not None:
+        c = _pick(cb, ('value', 'unit', 'cores', 'kind', 'config', 'physical_cores', 'reps', 'error'))
+        c['sample'] = _short(cb.get('sample'), 240)
+        if isinstance(cb.get('host'), dict):
+            c['cpu_model'] = cb['host'].get('cpu_model')
+        for sub in ('configs_0', 'configs_1'):
+            if isinstance(cb.get(sub), dict):
+                c[sub] = _pick(cb[sub], ('value', 'unit', 'cores', 'reps'))
+        out['cpu_baseline'] = c
+        if isinstance(cb.get('parity'), dict):
+            out['parity'] = {k: (float('%.3g' % v) if isinstance(v, float) else _short(v, 120)) for k, v in cb['parity'].items()}
+    if detail_path:
+        out['detail'] = detail_path
+    return out
+
+
+def emit_line(detail, extra_keys=()):
+    """Write the full record next to bench.py (and under gpurun_out/ when that exists; T2O_BENCH_DETAIL_DIR overrides both),
+    print the compact line LAST."""
+    rel = None
+    override = os.environ.get('T2O_BENCH_DETAIL_DIR')
+    for d in ((override,) if override else (ROOT, os.path.join(ROOT, 'gpurun_out'))):
+        if d != ROOT and not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, 'bench_detail.json'), 'w') as f:
+                json.dump(detail, f, indent=1)
+            rel = rel or 'bench_detail.json'
+        except OSError:
+            pass
+    c = compact_line(detail, rel)
+    c.update({k: detail[k] for k in extra_keys if k in detail})
+    s = json.dumps(c, separators=(',', ':'))
+    if len(s) > LINE_LIMIT:               # never a line the driver cannot parse: drop the optional blocks, largest first
+        for k in ('executor', 'train_step', 'parity', 'executor_roofline', 'train_roofline'):
+            c.pop(k, None)
+            s = json.dumps(c, separators=(',', ':'))
+            if len(s) <= LINE_LIMIT:
+                break
+    sys.stdout.flush()
+    sys.stderr.flush()
+    print(s, flush=True)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -917,11 +1016,23 @@ def selftest_worker(args):
     else:
         pids = [os.getpid()]
     if rank == 0:
-        print(json.dumps({'metric': 'selftest steps/sec (launcher path only, not a benchmark)', 'selftest': True,
-                          'value': round(args.steps / dt, 1), 'unit': 'steps/sec', 'n_gpus': world, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-                          'config': {'world_size': world, 'backend': 'gloo', 'rank_pids': pids},
-                          'mean_after_allreduce': float(buf[0])}), flush=True)
+        # the printed line goes through the real emission path (emit_line) with a record shaped -- and sized -- like a real run's:
+        # bulky per-kernel tables and prose that must end up in bench_detail.json, not on stdout
+        kernels = {'bwd_kernel_%02d' % i: {'ms': 0.03 + i * 1e-3, 'algorithmic_MB': 150.99, 'GBps': 4400.0 + i, 'hbm_min_MB': 150.99,
+                                           'hbm_min_GBps': 4400.0 + i} for i in range(12)}
+        leg = {k: {'value': 3.0e5, 'unit': 'images/sec', 'ms_per_step': 0.2, 'frac_of_peak': 1.0, 'fused_min_frac': 0.1, 'kernels': kernels,
+                   'what': 'selftest stand-in ' * 10} for k in ('fused', 'value_grad', 'materialised')}
+        emit_line({'metric': 'selftest steps/sec (launcher path only, not a benchmark)', 'selftest': True,
+                   'value': round(args.steps / dt, 1), 'unit': 'steps/sec', 'n_gpus': world, 'steps': args.steps,
+                   'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
+                   'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                   'config': {'workload': 'selftest', 'world_size': world, 'backend': 'gloo', 'rank_pids': pids},
+                   'roofline': {'bound': 'mfma', 'kernel': 'selftest', 'achieved': 0.0, 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
+                                'frac': 0.0, 'traffic': None, 'note': 'selftest stand-in ' * 40},
+                   'cpu_baseline': {'value': 0.0, 'unit': 'steps/sec', 'cores': 1, 'kind': 'port', 'sample': 'selftest stand-in ' * 40},
+                   'executor': {n: dict(leg) for n in ('cfg2_bs64', 'bs256', 'cfg5_16x512', 'cfg2_generic')},
+                   'conv_kernels': {'row_%02d' % i: {'ms': 0.1, 'GFLOP': 19.3, 'TFLOPs': 100.0, 'kernel': 'selftest'} for i in range(24)},
+                   'mean_after_allreduce': float(buf[0])}, extra_keys=('selftest', 'mean_after_allreduce'))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1018,7 +1129,7 @@ def worker(args):
     if args.no_train:
         line['error'] = '--no-train: executor legs only, no headline value'
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            emit_line(line)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -1026,7 +1137,7 @@ def worker(args):
 
     def emit():
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            emit_line(line)
 
     # the train leg is the headline.  A hang in it (one rank failing inside a collective) must still leave a line
     # with everything measured so far: a timer THREAD prints it and exits non-zero (a signal handler would not run
@@ -1079,7 +1190,7 @@ def main():
     ap.add_argument('--no-train', action='store_true',
                     help='executor legs only (profiling passes; the line then has no headline value)')
     ap.add_argument('--cpu-sample', type=int, default=64, help='images of the configs[1] CPU baseline')
-    ap.add_argument('--cpu-train-sample', type=int, default=64, help='images of the configs[2] CPU baseline (its full batch; 1 warm-up + <= 2 reps)')
+    ap.add_argument('--cpu-train-sample', type=int, default=32, help='images of the configs[2] CPU baseline (a bounded sample of the 64-image batch; 1 warm-up + 3 reps)')
     ap.add_argument('--train-timeout', type=int, default=600, help='seconds before the train-step leg is abandoned')
     ap.add_argument('--launch-timeout', type=int, default=1500, help='launcher: seconds before the ranks are stopped')
     ap.add_argument('--selftest', action='store_true',

@@ -60,3 +60,40 @@ def test_a_dying_rank_stops_the_job_quickly():
     r = _run(['--gpus', '2', '--selftest', '--steps', '3', '--warmup', '1'], env={'T2O_SELFTEST_FAIL_RANK': '1'})
     assert r.returncode != 0 and 'exited with code' in r.stderr
     assert time.time() - t0 < 60
+
+
+REQUIRED = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+
+
+def test_last_stdout_line_is_small_and_carries_the_contract_keys(tmp_path):
+    """the driver parses the LAST stdout line; round 4's was 24 KB and was not parsed.  The selftest sends a
+    record as bulky as a real run's through the real emission path: the line stays small, the bulk lands in the side file."""
+    r = _run(['--gpus', '1', '--selftest', '--steps', '2', '--warmup', '1'], env={'T2O_BENCH_DETAIL_DIR': str(tmp_path)})
+    assert r.returncode == 0, r.stderr
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 6144
+    d = json.loads(last)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d['roofline']['bound'] == 'mfma' and 'note' not in d['roofline'] and 'kernels' not in d['executor']['bs256']['fused']
+    full = json.load(open(os.path.join(str(tmp_path), 'bench_detail.json')))
+    assert len(json.dumps(full)) > 20000 and 'conv_kernels' in full and 'kernels' in full['executor']['bs256']['fused']
+    assert d['detail'] == 'bench_detail.json'
+
+
+def test_compact_line_of_a_real_record():
+    """Round 4's own 24 KB record (profiles/r04_bench.json) through compact_line: < 6 KB, every contract key, the three
+    roofline objects and the CPU baseline with its sub-configs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench.json')))
+    assert len(json.dumps(full)) > 20000
+    c = bench.compact_line(full, 'bench_detail.json')
+    s = json.dumps(c, separators=(',', ':'))
+    assert len(s) < bench.LINE_LIMIT
+    for k in REQUIRED + ('executor_roofline', 'train_roofline', 'parity'):
+        assert k in c, k
+    assert c['value'] == full['value'] and c['ms_per_step'] == full['ms_per_step']
+    assert c['roofline']['frac'] == full['roofline']['frac'] and c['cpu_baseline']['value'] == full['cpu_baseline']['value']
+    assert c['cpu_baseline']['configs_1']['value'] == full['cpu_baseline']['configs_1']['value']
