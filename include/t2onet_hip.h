@@ -490,6 +490,10 @@ int t2o_wino_dw_transform(const float* dU, float* dw, int Co, int Ci, int splits
 int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, int M, int N, int K, int a_rows, void* stream);
 int t2o_gemm_tn_splits(int batches, int rows, int M, int N);
 int t2o_gemm_tn_batched(const float* A, const float* B, float* C, int batches, int rows, int M, int N, int splits, void* stream);
+/* ... with A / B row ranges [0, rows) of every plane of LARGER (batches, a_plane_rows | b_plane_rows, .) tensors: the weight
+ * gradient over the first passes of a train step's V / A dY A^T arenas when a step used fewer passes than the arena holds */
+int t2o_gemm_tn_batched_ld(const float* A, const float* B, float* C, int batches, int rows, int a_plane_rows, int b_plane_rows, int M, int N,
+                           int splits, void* stream);
 
 /* ---- LSTM layers of the request encoder (models/lang_encoder.py:70-113: 2-layer bidirectional LSTM over packed, i.e.
  * per-sample-length, sequences; nn.LSTM gate order i, f, g, o), one launch per time step for both directions (t2o_rnn.hip).

@@ -94,6 +94,7 @@ SIGNATURES = {
     't2o_gemm_nt_batched': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_gemm_tn_splits': (_I, [_I, _I, _I, _I]),
     't2o_gemm_tn_batched': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_gemm_tn_batched_ld': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     't2o_wino_input_transform': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     't2o_wino_input_transform_ld': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_wino_stats_rows': (_I, [_I, _I, _I, _I]),

@@ -896,6 +896,7 @@ struct GemmTnArgs {
   float* C;             // (splits, batches, M, N)
   int M, N, Tpad, batches, splits;
   int tiles_m, tiles_n;
+  int ldA, ldB;         // rows per plane of the tensors A / B live in (>= Tpad: a row range of a larger (batches, R, .) arena)
 };
 
 __global__ __launch_bounds__(kFwdThreads, 1) void k_gemm_tn(GemmTnArgs a) {
@@ -911,8 +912,8 @@ __global__ __launch_bounds__(kFwdThreads, 1) void k_gemm_tn(GemmTnArgs a) {
   const int split = sb / a.batches, batch = sb - split * a.batches;
   const int m0 = mt * kT, n0 = nt * kT;
   const int rows_per_split = a.Tpad / a.splits, t0 = split * rows_per_split;
-  const char* const Ab = (const char*)(a.A + ((size_t)batch * a.Tpad + t0) * a.M + m0);
-  const char* const Bb = (const char*)(a.B + ((size_t)batch * a.Tpad + t0) * a.N + n0);
+  const char* const Ab = (const char*)(a.A + ((size_t)batch * a.ldA + t0) * a.M + m0);
+  const char* const Bb = (const char*)(a.B + ((size_t)batch * a.ldB + t0) * a.N + n0);
   float* const Cb = a.C + (size_t)sb * a.M * a.N;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1848,19 +1849,24 @@ int t2o_gemm_tn_splits(int batches, int Tpad, int M, int N) {
   return s;
 }
 
-int t2o_gemm_tn_batched(const float* A, const float* B, float* C, int batches, int Tpad, int M, int N, int splits, void* stream) {
+int t2o_gemm_tn_batched_ld(const float* A, const float* B, float* C, int batches, int Tpad, int ldA, int ldB, int M, int N, int splits,
+                           void* stream) {
   if (!A || !B || !C || misaligned16(A, B, C)) return set_error(T2O_EINVAL, "gemm_tn_batched: null or not 16-byte aligned pointer");
   if (batches <= 0 || M < 128 || M % 128 != 0 || N < 128 || N % 128 != 0 || Tpad <= 0 || (splits != 1 && splits != 2 && splits != 4) ||
-      Tpad % (64 * splits) != 0 || (size_t)Tpad * (M > N ? M : N) * 4 >= ((size_t)1 << 40))
-    return set_error(T2O_EUNSUPPORTED, "gemm_tn_batched: M, N multiples of 128, rows a multiple of 64 * splits (1, 2, 4)");
+      Tpad % (64 * splits) != 0 || ldA < Tpad || ldB < Tpad || (size_t)(ldA > ldB ? ldA : ldB) * (M > N ? M : N) * 4 >= ((size_t)1 << 40))
+    return set_error(T2O_EUNSUPPORTED, "gemm_tn_batched: M, N multiples of 128, rows a multiple of 64 * splits (1, 2, 4), plane strides >= rows");
   GemmTnArgs a;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.Tpad = Tpad; a.batches = batches; a.splits = splits;
-  a.tiles_m = M / 128; a.tiles_n = N / 128;
+  a.tiles_m = M / 128; a.tiles_n = N / 128; a.ldA = ldA; a.ldB = ldB;
   const long long rows = (long long)splits * batches * a.tiles_m;
   const long long grid = ((rows + 7) / 8) * 8 * a.tiles_n;
   if (grid >= ((long long)1 << 31)) return set_error(T2O_EUNSUPPORTED, "gemm_tn_batched: too many tiles");
   k_gemm_tn<<<(unsigned)grid, kFwdThreads, 0, (hipStream_t)stream>>>(a);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "gemm_tn_batched launch failed");
+}
+
+int t2o_gemm_tn_batched(const float* A, const float* B, float* C, int batches, int Tpad, int M, int N, int splits, void* stream) {
+  return t2o_gemm_tn_batched_ld(A, B, C, batches, Tpad, Tpad, Tpad, M, N, splits, stream);
 }
 
 size_t t2o_conv3x3s2_fwd_workspace_bytes(int N, int Ho, int Wo, int Ci, int Co) {

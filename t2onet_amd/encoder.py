@@ -342,12 +342,12 @@ class WgradArena:
                     _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
         for conv, Hi, Wi, Tpad in self.wino:
             V, Ad, dw = self.V[id(conv)], self.Ad[id(conv)], conv.weight.grad
-            got = self.rec.get(id(conv), set())
-            if len(got) == self.P and wino_dw_from(Ad, V, dw, True):
-                continue                                       # every pass recorded: ONE batch of GEMMs over all tiles
-            for q in sorted(got):                              # (an unused pass, or a row count without a valid split)
-                if not wino_dw_from(Ad[:, q * Tpad:(q + 1) * Tpad].contiguous(), V[:, q * Tpad:(q + 1) * Tpad].contiguous(), dw, True):
-                    raise RuntimeError('WgradArena: no split for the Winograd weight gradient of %d tiles' % Tpad)
+            for first, count in runs_of(self.rec.get(id(conv), ())):
+                # a run of passes = a row range of every plane: ONE batch of GEMMs over its tiles (a step that made fewer passes
+                # than the arena holds -- the episode step in an arena sized for the teacher-forced one -- uses the first rows)
+                rows = slice(first * Tpad, (first + count) * Tpad)
+                if not wino_dw_from(Ad[:, rows], V[:, rows], dw, True):
+                    raise RuntimeError('WgradArena: no split for the Winograd weight gradient of %d tiles' % (count * Tpad))
         self.begin()
 
 

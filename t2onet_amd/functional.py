@@ -1414,19 +1414,30 @@ def gemm_nt_batched(A, B, M=None):
     return C
 
 
+def _plane_rows(t, what):
+    """Rows per plane of the (batches, R, width) tensor a row-range view t (batches, rows, width) lives in."""
+    width = t.shape[2]
+    if t.stride(2) != 1 or t.stride(1) != width or t.stride(0) % width or t.stride(0) < t.shape[1] * width:
+        raise ValueError('%s must have dense rows (a row range of a larger (batches, R, width) tensor is fine)' % what)
+    return t.stride(0) // width
+
+
 def gemm_tn_batched(A, B):
     """(splits, batches, M, N) pieces of C[b] = A[b]^T @ B[b] for A (batches, rows, M), B (batches, rows, N) (rows % 256 == 0,
-    M, N % 128 == 0: t2o_gemm_tn_batched); the caller adds the pieces in order (t2o_wino_dw_transform does)."""
+    M, N % 128 == 0: t2o_gemm_tn_batched); the caller adds the pieces in order (t2o_wino_dw_transform does).  A and B may be
+    row ranges of larger tensors (the first passes of encoder.WgradArena's arenas)."""
     batches, rows, M = A.shape
     N = B.shape[2]
     if not _OWN_WINO_GEMM:
         return torch.bmm(A.transpose(1, 2), B).unsqueeze(0)
     lib = _lib.load()
+    ldA, ldB = _plane_rows(A, 'gemm_tn_batched: A'), _plane_rows(B, 'gemm_tn_batched: B')
     splits = lib.t2o_gemm_tn_splits(batches, rows, M, N)
     if splits <= 0:
         raise RuntimeError('gemm_tn_batched: M, N must be multiples of 128 and the row count of 256 (got %d x %d over %d rows)' % (M, N, rows))
     C = torch.empty((splits, batches, M, N), dtype=torch.float32, device=A.device)
-    _lib.check(lib.t2o_gemm_tn_batched(_ptr(A), _ptr(B), _ptr(C), batches, rows, M, N, splits, _stream(A.device)), 't2o_gemm_tn_batched')
+    _lib.check(lib.t2o_gemm_tn_batched_ld(_ptr(A), _ptr(B), _ptr(C), batches, rows, ldA, ldB, M, N, splits, _stream(A.device)),
+               't2o_gemm_tn_batched_ld')
     return C
 
 

@@ -208,13 +208,19 @@ class GraphedEpisodeStep:
         if tr._trunk is not None:
             tr._trunk.weights_changed()                        # the weights were updated since the last step: transform them again
         tr.grads.zero()
-        tr._tape(self.s_img.shape[0])
-        tr._arena(self.s_img, tr.opt.decoder_max_len)
-        lengths = (self.s_x != tr.opt.null_id).sum(1)         # on the device, inside the graph: no host-side lengths to copy
-        _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, lengths, self.longest, stack=False)
-        loss = end_l1_loss(imgs, ops, tr.opt.end_id, self.s_target)
-        loss.backward()
-        tr._flush_tape()                                       # the decoder's weight gradients: one product per weight, in the graph
+        try:
+            tr._tape(self.s_img.shape[0])
+            tr._arena(self.s_img, tr.opt.decoder_max_len)
+            # the captured kernels read and write the tape's and the arena's storage: this graph keeps both alive whatever the
+            # trainer's caches do later (another batch size, the arena cache's eviction)
+            self._keep = (tr.__dict__.get('_tape_obj'), tr._trunk.__dict__.get('arena') if tr._trunk is not None else None)
+            lengths = (self.s_x != tr.opt.null_id).sum(1)     # on the device, inside the graph: no host-side lengths to copy
+            _, imgs, ops, _ = model.episode_forward(self.s_x, self.s_img, None, self.reinforce_sample, lengths, self.longest, stack=False)
+            loss = end_l1_loss(imgs, ops, tr.opt.end_id, self.s_target)
+            loss.backward()
+            tr._flush_tape()                                   # the decoder's weight gradients: one product per weight, in the graph
+        finally:
+            tr._release()
         return loss.detach()
 
     def run(self, x, img, target):

@@ -207,17 +207,20 @@ class Trainer:
         self._tape_owner = model if (self.grads.flat.is_cuda and hasattr(model, 'decoder') and hasattr(model, 'bn1')) else None
 
     def _tape(self, B):
-        """The persistent tape for batches of B rows (re-allocated when B changes; None for models without a decoder)."""
+        """The persistent tape for batches of B rows (re-allocated when B changes; None for models without a decoder),
+        INSTALLED on the model for the duration of one train step: _release() takes it off again, so that a grad-enabled
+        forward + backward outside the Trainer (a custom loss, a gradient check, a stock optimiser) gets private one-slot
+        tapes and ordinary autograd gradients."""
         model = self._tape_owner
         if model is None:
             return None
-        tape = model.__dict__.get('_tape')
+        tape = self.__dict__.get('_tape_obj')
         if tape is None or tape.B != B:
             from .decoder_step import DecoderTape
             dec = model.decoder
-            tape = DecoderTape(B, dec.hidden_size, dec.word_vec_dim, dec.output_size, model.vis_encoder.fc.in_features,
-                               self.opt.decoder_max_len + 1, self.grads.flat.device, persistent=True)
-            model.__dict__['_tape'] = model.decoder.__dict__['_tape'] = tape
+            tape = self._tape_obj = DecoderTape(B, dec.hidden_size, dec.word_vec_dim, dec.output_size, model.vis_encoder.fc.in_features,
+                                                self.opt.decoder_max_len + 1, self.grads.flat.device, persistent=True)
+        model.__dict__['_tape'] = model.decoder.__dict__['_tape'] = tape
         tape.begin()
         return tape
 
@@ -230,21 +233,37 @@ class Trainer:
         if arena is not None:
             arena.flush(self._trunk)
 
+    def _release(self):
+        """End of a train step (also after an exception inside it): tape and arena off the model."""
+        model = self._tape_owner
+        if model is not None:
+            model.__dict__.pop('_tape', None)
+            model.decoder.__dict__.pop('_tape', None)
+        if self._trunk is not None:
+            self._trunk.__dict__['arena'] = None
+
+    MAX_ARENAS = 2      # batch shapes whose arenas are kept (a loader's full and last batch); least recently used goes first
+
     def _arena(self, img, passes):
-        """The encoder's per-layer (x, dy) / (V, A dY A^T) arenas for this batch shape and number of encoder passes
-        (encoder.WgradArena): the convolutions' weight gradients are then ONE launch per layer and train step (formed by
-        _flush_tape) instead of one per encoder pass.  Not with per-pass encoder graphs (their backward graphs accumulate
-        inside the graph).  One arena per (shape, passes) met: the episode step runs decoder_max_len passes, the
-        teacher-forced step one more."""
+        """The encoder's per-layer (x, dy) / (V, A dY A^T) arenas for this batch shape (encoder.WgradArena): the
+        convolutions' weight gradients are then ONE launch per layer and train step (formed by _flush_tape) instead of one
+        per encoder pass.  Not with per-pass encoder graphs (their backward graphs accumulate inside the graph).  ONE arena
+        per (N, H, W), sized for the most passes a step can make (decoder_max_len + 1: the teacher-forced step with a full
+        operator sequence) and used by steps that make fewer -- not one per pass count met (up to decoder_max_len
+        arenas of P x 1.1 GB each at bs = 64, 256 x 256); at most MAX_ARENAS shapes are kept."""
         if self._trunk is None or self.graph_encoder or not img.is_cuda:
             return
-        key = (img.shape[0], img.shape[2], img.shape[3], int(passes))
+        key = (img.shape[0], img.shape[2], img.shape[3])
         arenas = self.__dict__.setdefault('_arenas', {})
-        arena = arenas.get(key)
-        if arena is None and key not in arenas:
+        if key in arenas:
+            arena = arenas.pop(key)                           # (re-inserted below: most recently used last)
+        else:
             from .encoder import WgradArena
-            arena = arenas[key] = (WgradArena(self._trunk, key[0], key[1], key[2], key[3], img.device)
-                                   if (passes > 0 and self._trunk.supported(img)) else None)
+            while len(arenas) >= self.MAX_ARENAS:
+                arenas.pop(next(iter(arenas)))
+            arena = (WgradArena(self._trunk, key[0], key[1], key[2], self.opt.decoder_max_len + 1, img.device)
+                     if (passes > 0 and self._trunk.supported(img)) else None)
+        arenas[key] = arena
         self._trunk.__dict__['arena'] = arena
         if arena is not None:
             arena.begin()
@@ -316,14 +335,17 @@ class Trainer:
         """train_seq2seqL1.py:51-65: NLL (mean, no ignore_index) + MSE(sum)/count_nonzero."""
         step = int((y != self.opt.null_id).sum(1).max())
         self._maybe_graph(img_x)
-        self._tape(img_x.shape[0])
-        self._arena(img_x, step - 1)
-        _, pred_params, logp = self.model.supervised_forward(x, y, img_x, img_y, gt_params, None, lengths)
-        target = y[:, 1:step].contiguous().view(-1)
-        op_loss = F.nll_loss(logp.reshape(-1, logp.shape[-1]), target)
-        gt = gt_params[:, :step - 2]
-        param_loss = F.mse_loss(pred_params, gt, reduction='sum') / ((gt != 0).sum())
-        self._finish(op_loss + param_loss)
+        try:
+            self._tape(img_x.shape[0])
+            self._arena(img_x, step - 1)
+            _, pred_params, logp = self.model.supervised_forward(x, y, img_x, img_y, gt_params, None, lengths)
+            target = y[:, 1:step].contiguous().view(-1)
+            op_loss = F.nll_loss(logp.reshape(-1, logp.shape[-1]), target)
+            gt = gt_params[:, :step - 2]
+            param_loss = F.mse_loss(pred_params, gt, reduction='sum') / ((gt != 0).sum())
+            self._finish(op_loss + param_loss)
+        finally:
+            self._release()
         return op_loss.detach(), param_loss.detach()
 
     def episode_step(self, x, img_x, target, reinforce_sample=1, lengths=None):
@@ -333,11 +355,14 @@ class Trainer:
             if loss is not None:
                 return loss
         self._maybe_graph(img_x)
-        self._tape(img_x.shape[0])
-        self._arena(img_x, self.opt.decoder_max_len)
-        _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths, stack=False)
-        loss = end_l1_loss(pred_imgs, pred_ops, self.opt.end_id, target)
-        self._finish(loss)
+        try:
+            self._tape(img_x.shape[0])
+            self._arena(img_x, self.opt.decoder_max_len)
+            _, pred_imgs, pred_ops, _ = self.model.episode_forward(x, img_x, None, reinforce_sample, lengths, stack=False)
+            loss = end_l1_loss(pred_imgs, pred_ops, self.opt.end_id, target)
+            self._finish(loss)
+        finally:
+            self._release()
         return loss.detach()
 
     def step(self, batch):

@@ -124,6 +124,51 @@ def test_trainer_alternates_and_learns():
     assert sum(p.numel() for p in tr.grads.params) == 22165917 and tr.grads.flat.numel() >= 22165917      # (+ segment padding)
 
 
+def test_backward_outside_the_trainer_after_a_trainer_step():
+    """the Trainer's persistent decoder tape and weight-gradient arena are installed for the duration of a train
+    step only.  After a step, a grad-enabled forward + loss.backward() OUTSIDE the Trainer (a custom loss, a gradient check)
+    must deliver every gradient -- with the tape / arena left installed the decoder, fc, bn1 and convolution weight
+    gradients were deferred into storage nobody flushes.  Checked against a second model without any Trainer."""
+    from t2onet_amd.train import Trainer
+    dev = torch.device('cuda:0')
+    model, opt = make_model(dev)
+    model.train()
+    tr = Trainer(model, opt)
+    x = synth.requests(B, L, 41).to(dev)
+    img = synth.images(B, H, W, 42).to(dev)
+    tgt = synth.images(B, H, W, 43).to(dev)
+    y = synth.op_targets(B, 45).to(dev)
+    img_y = synth.uniform((B, 6, 3, H, W), 46).to(dev)
+    gt = synth.uniform((B, 5, 24), 47, -1, 1).to(dev)
+    tr.episode_step(x, img, tgt, reinforce_sample=0)
+    tr.supervised_step(x, y, img, img_y, gt)
+    assert '_tape' not in model.__dict__ and '_tape' not in model.decoder.__dict__
+    assert model.vis_encoder.trunk_plan().__dict__.get('arena') is None
+    assert len(tr._arenas) == 1                              # one arena per batch shape, whatever the number of passes
+    other, _ = make_model(dev)
+    other.load_state_dict(model.state_dict())
+    other.train()
+
+    def custom_loss(m):
+        _, pred_params, logp = m.supervised_forward(x, y, img, img_y, gt, None, None)
+        return (logp * logp).sum() + pred_params.abs().sum()
+    tr.grads.zero()
+    custom_loss(model).backward()
+    custom_loss(other).backward()
+    ref = dict(other.named_parameters())
+    checked = 0
+    for n, p in model.named_parameters():
+        g_ref = ref[n].grad
+        if g_ref is None or float(g_ref.abs().max()) == 0.0:
+            continue
+        scale = float(g_ref.abs().max())
+        assert float((p.grad - g_ref).abs().max()) <= 3e-3 * scale, n
+        checked += 1
+    assert checked >= 150                                    # decoder, encoder trunk, request encoder, the used heads
+    # and the Trainer still works afterwards
+    assert torch.isfinite(tr.episode_step(x, img, tgt))
+
+
 def test_evaluation_loop_full_resolution():
     """test() of test_seq2seqL1.py at inference shapes (bs=1, non-square, short side 600 -> here a
     smaller 150x225 so the test stays quick): runs end to end and reports L1 / SSIM."""

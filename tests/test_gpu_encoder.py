@@ -239,7 +239,8 @@ def test_weight_gradients_once_per_step_equal_per_pass_gradients(size, spare):
     launch per layer over the passes' (x, dy) arenas (Winograd layers: one batch of GEMMs over the passes' V and A dY A^T),
     against the same passes with a weight-gradient launch each.  Same kernels over 3 N images instead of 3 x N: equal up to
     the order of the split-K sums; everything else bit-identical.  spare = 1: the arena holds one pass more than is used
-    (the Winograd layers then go pass by pass)."""
+    (the Trainer's one arena per batch shape, sized for the teacher-forced step: the Winograd layers' GEMMs then run over the
+    first rows of every arena plane -- t2o_gemm_tn_batched_ld)."""
     import t2onet_amd.functional as T
     from t2onet_amd.encoder import WgradArena
     N, (H, W), P = 2, size, 3

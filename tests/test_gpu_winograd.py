@@ -170,6 +170,14 @@ def test_own_row_gemm_matches_fp64(shape):
     scale = float(ref.abs().max())
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * scale)
     assert torch.equal(C, T.gemm_tn_batched(A.to(dev), B.to(dev)))
+    # t2o_gemm_tn_batched_ld: the operands as row ranges of larger arenas (different plane strides): bit-identical
+    bigA = torch.full((b, rows + 512, M), float('nan'), device=dev)
+    bigB = torch.full((b, rows + 256, N), float('nan'), device=dev)
+    bigA[:, 256:256 + rows] = A.to(dev)
+    bigB[:, :rows] = B.to(dev)
+    assert torch.equal(C, T.gemm_tn_batched(bigA[:, 256:256 + rows], bigB[:, :rows]))
+    with pytest.raises(ValueError):
+        T.gemm_tn_batched(bigA[:, :, :M // 2], bigB[:, :rows])
 
 
 def test_combined_backward_equals_the_two_separate_pipelines():
