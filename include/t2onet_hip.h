@@ -182,13 +182,19 @@ int t2o_op_candidates_multi_l1(const int* ops, const int* img_index, int J, cons
                                const float* target, const float* params, int C, int param_stride, float* loss,
                                void* workspace, size_t workspace_bytes, int H, int W, void* stream);
 
-/* ---- SSIM (evaluation metric, forward only): utils/ssim/__init__.py:20-40 ----
+/* ---- SSIM: utils/ssim/__init__.py:20-40 (forward: the evaluation metric; backward: its closed-form gradient) ----
  * 11x11 Gaussian window (sigma 1.5), zero padding, C1 = 1e-4, C2 = 9e-4.
  * out[b] = mean over (C,H,W) of the SSIM map of sample b (size_average=False of the reference;
  * its size_average=True is the mean of out).  workspace: t2o_ssim_workspace_bytes(B,C,H,W). */
 size_t t2o_ssim_workspace_bytes(int B, int C, int H, int W);
 int t2o_ssim_fwd(const float* img1, const float* img2, float* out,
                  void* workspace, size_t workspace_bytes, int B, int C, int H, int W, void* stream);
+/* Backward of t2o_ssim_fwd (the reference differentiates utils/ssim/__init__.py:20-40 by autograd; there is no reference
+ * kernel): gout (B) = gradient w.r.t. out[b]; g1 / g2 (B,C,H,W) = gradients w.r.t. img1 / img2, either may be NULL.
+ * One launch, one workgroup per 32 x 32 tile of a plane; the four derivative maps live in LDS only.  Writes (does not
+ * accumulate); no workspace; deterministic. */
+int t2o_ssim_bwd(const float* img1, const float* img2, const float* gout, float* g1, float* g2,
+                 int B, int C, int H, int W, void* stream);
 
 /* ---- dot-product attention core, models/attention.py:37-40 ----
  * q (B,D), ctx (B,L,D) -> attn (B,L) = softmax_l(q . ctx_l) over ALL L rows (no padding
@@ -616,13 +622,28 @@ int t2o_graph_memsets_to_kernels(void* graph, int* replaced);
 int t2o_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                   float beta2, float eps, int step, void* stream);
 
+/* ---- the train step's one collective (the reference runs one process: train_seq2seqL1.py:74-88 has no
+ * counterpart).  t2o_allreduce: in-place SUM all-reduce of n fp32 values over the caller's communicator (an ncclComm_t, passed
+ * as void*), stream-ordered on `stream`, no host synchronisation; t2o_allreduce_mean: the same followed by x 1/nranks (the
+ * data-parallel gradient average; flat 16-byte aligned).  RCCL is resolved at first use (dlopen: the copy the process already
+ * holds, else librccl.so) -- not a link-time dependency; without it every entry point here returns T2O_EUNSUPPORTED and
+ * t2o_comm_available() is 0.  For a host that has no communicator of its own: rank 0 calls t2o_comm_unique_id (128 bytes),
+ * hands them to every rank by any means, all ranks call t2o_comm_init_rank (collective; the calling thread's current HIP
+ * device is the rank's GPU) and, at the end, t2o_comm_destroy. */
+int t2o_comm_available(void);
+int t2o_comm_unique_id(void* id128);
+int t2o_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
+int t2o_comm_destroy(void* comm);
+int t2o_allreduce(float* flat, size_t n, void* comm, void* stream);
+int t2o_allreduce_mean(float* flat, size_t n, void* comm, void* stream);
+
 /* ---- Winograd F(2x2,3x3) with V and M kept on chip (t2o_wino_fused.hip): conv2d(x, w, None, 1, 1) on NHWC activations for the
  * stride-1 3x3 layers of the 64- / 128-channel stages (models/actor_resnet.py:24-44), H and W multiples of 16, Ci of 8, Co of
  * 64 -- ONE launch per layer where t2o_wino_input_transform + t2o_gemm_nt_batched + t2o_wino_output_transform move 8x the
  * activation through HBM.  uc = t2o_wino_u_chunked(U) with U = t2o_wino_weight_transform(w) (or of the mirrored transpose
  * for the data gradient): (Ci/8, 16, Co, 8).  addend (N,H,W,Co) or NULL is added in the epilogue; stats or NULL receives
  * (t2o_wino_fused_stats_rows, 2, Co) partial sums / sums of squares of y for t2o_bn_relu_nhwc_fwd_partials.  zeros: >= Ci*4 +
- * 32 bytes of zeros, 16-byte aligned (t2o_conv_set_zero_region's block serves). */
+ * 32 bytes of zeros, 16-byte aligned (t2o_conv_set_zero_region's block serves); Ci, Co <= 1024 (so 4,128 bytes always suffice). */
 int t2o_wino_fused_supported(int N, int H, int W, int Ci, int Co);
 int t2o_wino_fused_stats_rows(int N, int H, int W);
 int t2o_wino_u_chunked(const float* U, float* Uc, int Cn, int Ck, void* stream);

@@ -233,8 +233,8 @@ def _gauss_window(size, sigma):                     # ssim/__init__.py:7-17
 def ssim(img1, img2, window_size=11, size_average=True):
     """_ssim: utils/ssim/__init__.py:20-40 (11x11, sigma 1.5, C1=0.01^2, C2=0.03^2)."""
     ch = img1.shape[1]
-    w = _gauss_window(window_size, 1.5).expand(ch, 1, window_size, window_size).contiguous()
-    pad = window_size // 2
+    w = _gauss_window(window_size, 1.5).expand(ch, 1, window_size, window_size).contiguous().to(img1.dtype)     # (fp64 runs: the
+    pad = window_size // 2                                                                                     # reference's fp32 window values, exactly)
     mu1 = F.conv2d(img1, w, padding=pad, groups=ch)
     mu2 = F.conv2d(img2, w, padding=pad, groups=ch)
     mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2

@@ -46,6 +46,13 @@ SIGNATURES = {
     't2o_op_candidates_multi_l1': (_I, [c_i, c_i, _I, _P, _I, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P]),
     't2o_ssim_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     't2o_ssim_fwd': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
+    't2o_ssim_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    't2o_comm_available': (_I, []),
+    't2o_comm_unique_id': (_I, [_P]),
+    't2o_comm_init_rank': (_I, [_P, _I, _P, _I]),
+    't2o_comm_destroy': (_I, [_P]),
+    't2o_allreduce': (_I, [_P, _Z, _P, _P]),
+    't2o_allreduce_mean': (_I, [_P, _Z, _P, _P]),
     't2o_choose_op': (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P]),
     't2o_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     't2o_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -1096,6 +1096,140 @@ T2O_HD float ssim_phase_cols(const SsimArgs& s, int tile, int tid, const float* 
   return sum;
 }
 
+// --------------------------------------------------------------------- SSIM backward
+// The reference has no SSIM backward of its own (utils/ssim/__init__.py:20-40 under autograd); this is the closed form.
+// With W the (symmetric, zero-padded) Gaussian window, mu1 = W*x, mu2 = W*y, e11 = W*(x x), e22 = W*(y y), e12 = W*(x y),
+//   A1 = 2 mu1 mu2 + C1,  A2 = 2 (e12 - mu1 mu2) + C2,  B1 = mu1^2 + mu2^2 + C1,  B2 = e11 - mu1^2 + e22 - mu2^2 + C2,
+//   S = A1 A2 / (B1 B2);  out[b] = mean_{c,h,w} S;  gS = gout[b] / (C H W) at every in-image position q, and
+//   d_e   = dS/de11 = dS/de22 = -S / B2
+//   d_e12 = 2 A1 / (B1 B2)
+//   d_mu1 = 2 mu2 (A2 - A1) / (B1 B2) - 2 mu1 S (1 / B1 - 1 / B2)       (d_mu2: mu1 <-> mu2)
+//   dL/dx = W*(gS d_mu1) + 2 x W*(gS d_e) + y W*(gS d_e12),   dL/dy = W*(gS d_mu2) + 2 y W*(gS d_e) + x W*(gS d_e12).
+// One workgroup = one 32 x 32 tile of one plane: it needs the four derivative maps on the 42 x 42 positions around the tile,
+// hence the statistics there, hence a 52 x 52 input window; everything stays in LDS (the four maps never reach HBM).
+constexpr int kSsimBIn = kSsimTile + 4 * kSsimPad;      // 52 x 52 input window
+constexpr int kSsimBMid = kSsimTile + 2 * kSsimPad;     // 42 x 42 positions whose SSIM value reaches the tile
+constexpr int kSsimBInStride = kSsimBIn + 1, kSsimBMidStride = kSsimBMid + 1, kSsimBOutStride = kSsimTile + 1;
+constexpr int kSsimBX = 0;                                               // x window, then y window
+constexpr int kSsimBH = 2 * kSsimBIn * kSsimBInStride;                   // 5 row-filtered maps (52 rows x 42); later 4 x (42 rows x 32)
+constexpr int kSsimBD = kSsimBH + 5 * kSsimBIn * kSsimBMidStride;        // 4 derivative maps (42 x 42)
+T2O_HD int ssim_bwd_lds_floats() { return kSsimBD + 4 * kSsimBMid * kSsimBMidStride; }
+
+struct SsimBwdArgs {
+  const float* a;        // (B,C,H,W)
+  const float* b;
+  const float* gout;     // (B): gradient w.r.t. out[b] of t2o_ssim_fwd
+  float* ga;             // (B,C,H,W) or null
+  float* gb;             // (B,C,H,W) or null
+  float g[kSsimWin];
+  int B, C, H, W, tiles_x, tiles;
+  float inv_n;           // 1 / (C H W)
+};
+
+// phase 1: the two 52 x 52 input windows (zero outside the image)
+T2O_HD void ssim_bwd_phase_load(const SsimBwdArgs& s, int plane, int tile, int tid, float* lds) {
+  const int y0 = (tile / s.tiles_x) * kSsimTile - 2 * kSsimPad, x0 = (tile % s.tiles_x) * kSsimTile - 2 * kSsimPad;
+  const size_t base = (size_t)plane * s.H * s.W;
+  for (int i = tid; i < kSsimBIn * kSsimBIn; i += kThreads) {
+    const int r = i / kSsimBIn, c = i % kSsimBIn, gy = y0 + r, gx = x0 + c;
+    const bool in = gy >= 0 && gy < s.H && gx >= 0 && gx < s.W;
+    lds[kSsimBX + r * kSsimBInStride + c] = in ? s.a[base + (size_t)gy * s.W + gx] : 0.0f;
+    lds[kSsimBX + kSsimBIn * kSsimBInStride + r * kSsimBInStride + c] = in ? s.b[base + (size_t)gy * s.W + gx] : 0.0f;
+  }
+}
+
+// phase 2: horizontal pass -> 5 maps of 52 rows x 42 columns
+T2O_HD void ssim_bwd_phase_rows(const SsimBwdArgs& s, int tid, float* lds) {
+  const float* A = lds + kSsimBX;
+  const float* Bm = A + kSsimBIn * kSsimBInStride;
+  float* Hm = lds + kSsimBH;
+  for (int i = tid; i < kSsimBIn * kSsimBMid; i += kThreads) {
+    const int r = i / kSsimBMid, c = i % kSsimBMid;
+    float m1 = 0.0f, m2 = 0.0f, e11 = 0.0f, e22 = 0.0f, e12 = 0.0f;
+    for (int k = 0; k < kSsimWin; ++k) {
+      const float x = A[r * kSsimBInStride + c + k], y = Bm[r * kSsimBInStride + c + k], w = s.g[k];
+      m1 += w * x; m2 += w * y; e11 += w * (x * x); e22 += w * (y * y); e12 += w * (x * y);
+    }
+    float* o = Hm + r * kSsimBMidStride + c;
+    constexpr int kMap = kSsimBIn * kSsimBMidStride;
+    o[0] = m1; o[kMap] = m2; o[2 * kMap] = e11; o[3 * kMap] = e22; o[4 * kMap] = e12;
+  }
+}
+
+// phase 3: vertical pass -> the statistics at the 42 x 42 positions -> the four derivative maps times gS (zero outside the image)
+T2O_HD void ssim_bwd_phase_deriv(const SsimBwdArgs& s, int plane, int tile, int tid, float* lds) {
+  const float* Hm = lds + kSsimBH;
+  float* D = lds + kSsimBD;
+  constexpr int kMap = kSsimBIn * kSsimBMidStride, kDMap = kSsimBMid * kSsimBMidStride;
+  const int y0 = (tile / s.tiles_x) * kSsimTile - kSsimPad, x0 = (tile % s.tiles_x) * kSsimTile - kSsimPad;
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  const float gs = s.gout[plane / s.C] * s.inv_n;
+  for (int i = tid; i < kSsimBMid * kSsimBMid; i += kThreads) {
+    const int r = i / kSsimBMid, c = i % kSsimBMid;
+    float d1 = 0.0f, d2 = 0.0f, de = 0.0f, d12 = 0.0f;
+    if (y0 + r >= 0 && y0 + r < s.H && x0 + c >= 0 && x0 + c < s.W) {
+      float v[5];
+      for (int m = 0; m < 5; ++m) {
+        float acc = 0.0f;
+        for (int k = 0; k < kSsimWin; ++k) acc += s.g[k] * Hm[m * kMap + (r + k) * kSsimBMidStride + c];
+        v[m] = acc;
+      }
+      const float mu1 = v[0], mu2 = v[1];
+      const float A1 = 2.0f * mu1 * mu2 + C1, A2 = 2.0f * (v[4] - mu1 * mu2) + C2;
+      const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = (v[2] - mu1 * mu1) + (v[3] - mu2 * mu2) + C2;
+      const float rB1 = 1.0f / B1, rB2 = 1.0f / B2;
+      const float S = A1 * A2 * rB1 * rB2;
+      const float common = 2.0f * (A2 - A1) * rB1 * rB2, diff = 2.0f * S * (rB1 - rB2);
+      d1 = gs * (mu2 * common - mu1 * diff);
+      d2 = gs * (mu1 * common - mu2 * diff);
+      de = -gs * S * rB2;
+      d12 = gs * 2.0f * A1 * rB1 * rB2;
+    }
+    float* o = D + r * kSsimBMidStride + c;
+    o[0] = d1; o[kDMap] = d2; o[2 * kDMap] = de; o[3 * kDMap] = d12;
+  }
+}
+
+// phase 4: horizontal pass over the derivative maps -> 4 maps of 42 rows x 32 columns (over the row-filtered statistics, no longer needed)
+T2O_HD void ssim_bwd_phase_drows(const SsimBwdArgs& s, int tid, float* lds) {
+  const float* D = lds + kSsimBD;
+  float* Hd = lds + kSsimBH;
+  constexpr int kDMap = kSsimBMid * kSsimBMidStride, kHMap = kSsimBMid * kSsimBOutStride;
+  for (int i = tid; i < kSsimBMid * kSsimTile; i += kThreads) {
+    const int r = i / kSsimTile, c = i % kSsimTile;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < kSsimWin; ++k) {
+      const float w = s.g[k];
+      for (int m = 0; m < 4; ++m) acc[m] += w * D[m * kDMap + r * kSsimBMidStride + c + k];
+    }
+    for (int m = 0; m < 4; ++m) Hd[m * kHMap + r * kSsimBOutStride + c] = acc[m];
+  }
+}
+
+// phase 5: vertical pass + the chain rule through x x, y y, x y -> the two image gradients of the tile
+T2O_HD void ssim_bwd_phase_out(const SsimBwdArgs& s, int plane, int tile, int tid, const float* lds) {
+  const float* Hd = lds + kSsimBH;
+  const float* A = lds + kSsimBX;
+  const float* Bm = A + kSsimBIn * kSsimBInStride;
+  constexpr int kHMap = kSsimBMid * kSsimBOutStride;
+  const int y0 = (tile / s.tiles_x) * kSsimTile, x0 = (tile % s.tiles_x) * kSsimTile;
+  const size_t base = (size_t)plane * s.H * s.W;
+  for (int i = tid; i < kSsimTile * kSsimTile; i += kThreads) {
+    const int r = i / kSsimTile, c = i % kSsimTile;
+    if (y0 + r >= s.H || x0 + c >= s.W) continue;
+    float G[4];
+    for (int m = 0; m < 4; ++m) {
+      float acc = 0.0f;
+      for (int k = 0; k < kSsimWin; ++k) acc += s.g[k] * Hd[m * kHMap + (r + k) * kSsimBOutStride + c];
+      G[m] = acc;
+    }
+    const float x = A[(r + 2 * kSsimPad) * kSsimBInStride + c + 2 * kSsimPad], y = Bm[(r + 2 * kSsimPad) * kSsimBInStride + c + 2 * kSsimPad];
+    const size_t o = base + (size_t)(y0 + r) * s.W + x0 + c;
+    if (s.ga) s.ga[o] = G[0] + 2.0f * x * G[2] + y * G[3];
+    if (s.gb) s.gb[o] = G[1] + 2.0f * y * G[2] + x * G[3];
+  }
+}
+
 // ===================================================================== planner: candidate sweep
 // Operation planning (utils/beam_search.py:65-91) fits one operator's parameter by minimising
 // dist(execute(img, op, param), target) with one executor call + one `.item()` per evaluation.

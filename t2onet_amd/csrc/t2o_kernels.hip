@@ -613,6 +613,22 @@ __global__ __launch_bounds__(kThreads) void k_ssim_finalize(const float* partial
   if (threadIdx.x == 0) out[blockIdx.x] = out1 * inv;
 }
 
+// ------------------------------------------------------------------ SSIM backward (both image gradients, one launch)
+__global__ __launch_bounds__(kThreads) void k_ssim_bwd(SsimBwdArgs s) {
+  __shared__ __attribute__((aligned(16))) float lds[kSsimBD + 4 * kSsimBMid * kSsimBMidStride];      // 95.7 KB of the CU's 160
+  int plane, tile;
+  wg_coords(s.tiles, plane, tile);
+  ssim_bwd_phase_load(s, plane, tile, threadIdx.x, lds);
+  __syncthreads();
+  ssim_bwd_phase_rows(s, threadIdx.x, lds);
+  __syncthreads();
+  ssim_bwd_phase_deriv(s, plane, tile, threadIdx.x, lds);
+  __syncthreads();
+  ssim_bwd_phase_drows(s, threadIdx.x, lds);
+  __syncthreads();
+  ssim_bwd_phase_out(s, plane, tile, threadIdx.x, lds);
+}
+
 // ------------------------------------------------------------------ planner: candidate sweep
 // grid = nblk pixel chunks x ceil(C / kCandPerBlock) candidate groups
 __global__ __launch_bounds__(kThreads) void k_candidates_l1(CandArgs a) {
@@ -1686,6 +1702,24 @@ int t2o_ssim_fwd(const float* img1, const float* img2, float* out, void* workspa
   k_ssim_fwd<<<(unsigned)(B * C * s.tiles), kThreads, sizeof(float) * ssim_lds_floats(), st>>>(s);
   k_ssim_finalize<<<B, kThreads, 0, st>>>(s.partials, C * s.tiles, 1.0f / ((float)C * (float)H * (float)W), out);
   return check_launch("ssim forward");
+}
+
+int t2o_ssim_bwd(const float* img1, const float* img2, const float* gout, float* g1, float* g2, int B, int C, int H, int W,
+                 void* stream) {
+  if (!img1 || !img2 || !gout || (!g1 && !g2)) return fail(T2O_EINVAL, "ssim_bwd: null pointer (one of g1 / g2 may be null, not both)");
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(T2O_EINVAL, "B, C, H, W must be positive");
+  SsimBwdArgs s;
+  memset(&s, 0, sizeof(s));
+  s.a = img1; s.b = img2; s.gout = gout; s.ga = g1; s.gb = g2;
+  ssim_window(s.g);
+  s.B = B; s.C = C; s.H = H; s.W = W;
+  s.tiles_x = (W + kSsimTile - 1) / kSsimTile;
+  s.tiles = s.tiles_x * ((H + kSsimTile - 1) / kSsimTile);
+  s.inv_n = 1.0f / ((float)C * (float)H * (float)W);
+  const long long grid = (long long)B * C * s.tiles;
+  if (grid >= ((long long)1 << 31)) return fail(T2O_EUNSUPPORTED, "ssim_bwd: too many tiles");
+  k_ssim_bwd<<<(unsigned)grid, kThreads, 0, (hipStream_t)stream>>>(s);
+  return check_launch("ssim backward");
 }
 
 int t2o_choose_op(const float* logp, float* op_mask, const float* u, float explore_prob, long long* pred_op, int* exec_op,

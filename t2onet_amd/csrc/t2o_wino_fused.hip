@@ -414,8 +414,10 @@ __global__ __launch_bounds__(256) void k_wino_u_chunked(const float* __restrict_
 }
 
 bool wf_supported(int N, int H, int W, int Ci, int Co) {
-  return N > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0 && Ci >= 8 && Ci % 8 == 0 && Co >= 64 && Co % 64 == 0 &&
-         (size_t)N * H * W * (size_t)(Ci > Co ? Ci : Co) < ((size_t)1 << 40);
+  // Ci <= 1024: the padding source `zeros` is read Ci * 4 + 32 bytes deep (the kernel advances it 32 bytes per chunk); the
+  // documented requirement is a zero block of >= 4 KiB + 32 bytes (t2onet_hip.h)
+  return N > 0 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0 && Ci >= 8 && Ci % 8 == 0 && Ci <= 1024 && Co >= 64 && Co % 64 == 0 &&
+         Co <= 1024 && (size_t)N * H * W * (size_t)(Ci > Co ? Ci : Co) < ((size_t)1 << 40);
 }
 
 }  // namespace

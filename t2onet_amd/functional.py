@@ -974,20 +974,44 @@ def candidates_multi_l1(ops, img_index, imgs, target, params):
     return loss
 
 
+class _SsimFn(torch.autograd.Function):
+    """out (B) = per-sample mean of the SSIM map; backward = t2o_ssim_bwd (closed form, one launch)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        B, C, H, W = img1.shape
+        lib = _lib.load()
+        out = torch.empty(B, dtype=torch.float32, device=img1.device)
+        ws = torch.empty(max(lib.t2o_ssim_workspace_bytes(B, C, H, W), 4), dtype=torch.uint8, device=img1.device)
+        rc = lib.t2o_ssim_fwd(_ptr(img1), _ptr(img2), _ptr(out), _ptr(ws), ws.numel(), B, C, H, W, _stream(img1.device))
+        _lib.check(rc, 't2o_ssim_fwd')
+        ctx.save_for_backward(img1, img2)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        img1, img2 = ctx.saved_tensors
+        B, C, H, W = img1.shape
+        g1 = torch.empty_like(img1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(img2) if ctx.needs_input_grad[1] else None
+        if g1 is None and g2 is None:
+            return None, None
+        gout = gout.contiguous().float()
+        rc = _lib.load().t2o_ssim_bwd(_ptr(img1), _ptr(img2), _ptr(gout), _ptr(g1), _ptr(g2), B, C, H, W, _stream(img1.device))
+        _lib.check(rc, 't2o_ssim_bwd')
+        return g1, g2
+
+
 def ssim(img1, img2, size_average=True):
-    """SSIM of utils/ssim/__init__.py (11x11 Gaussian, sigma 1.5), forward only (evaluation metric).
-    Returns a scalar (size_average) or one value per sample."""
+    """SSIM of utils/ssim/__init__.py (11x11 Gaussian, sigma 1.5).  Returns a scalar (size_average) or one value per sample.
+    Differentiable w.r.t. both images (t2o_ssim_bwd): `1 - ssim(pred, target)` is usable as a loss, as the reference's SSIM
+    module is under autograd (utils/ssim/__init__.py:43-66)."""
     _need_gpu(img1, img2)
     if img1.shape != img2.shape or img1.dim() != 4:
         raise ValueError('ssim expects two (B,C,H,W) tensors of the same shape')
-    img1, img2 = img1.contiguous(), img2.contiguous()
-    B, C, H, W = img1.shape
-    lib = _lib.load()
-    out = torch.empty(B, dtype=torch.float32, device=img1.device)
-    ws = torch.empty(max(lib.t2o_ssim_workspace_bytes(B, C, H, W), 4), dtype=torch.uint8, device=img1.device)
-    with torch.no_grad():
-        rc = lib.t2o_ssim_fwd(_ptr(img1), _ptr(img2), _ptr(out), _ptr(ws), ws.numel(), B, C, H, W, _stream(img1.device))
-    _lib.check(rc, 't2o_ssim_fwd')
+    if img1.dtype != torch.float32 or img2.dtype != torch.float32:
+        raise ValueError('ssim expects fp32 images')
+    out = _SsimFn.apply(img1.contiguous(), img2.contiguous())
     return out.mean() if size_average else out
 
 

@@ -64,10 +64,75 @@ class FlatGradients:
         self.flat.zero_()
 
     def all_reduce_mean(self):
-        """One collective for the whole model (88.7 MB for the actor)."""
+        """One collective for the whole model (88.7 MB for the actor): torch.distributed's (RCCL under backend "nccl", gloo in
+        the CPU tests), or -- `use_own_communicator()` / T2O_OWN_COMM=1 -- the C ABI's t2o_allreduce_mean on a communicator this
+        object owns, launched on torch's current stream like every other kernel of the step."""
+        comm = self.__dict__.get('_comm')
+        if comm is None and os.environ.get('T2O_OWN_COMM', '0') != '0' and self.flat.is_cuda and dist.is_available() and dist.is_initialized():
+            comm = self.use_own_communicator()
+        if comm is not None:
+            from . import _lib
+            rc = _lib.load().t2o_allreduce_mean(self.flat.data_ptr(), self.flat.numel(), comm.handle, T._stream(self.flat.device))
+            _lib.check(rc, 't2o_allreduce_mean')
+            return
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
+
+    def use_own_communicator(self, nranks=None, rank=None, exchange=None):
+        """Build an RCCL communicator through the C ABI (t2o_comm_unique_id / t2o_comm_init_rank) and use it for the gradient
+        all-reduce.  Rank 0's 128-byte id reaches the others through `exchange(id_bytes_or_None) -> id_bytes` (default: a
+        torch.distributed object broadcast on whatever process group is up).  Collective: every rank must call it."""
+        comm = Communicator(self.flat.device, nranks, rank, exchange)
+        self._comm = comm
+        return comm
+
+
+class Communicator:
+    """An ncclComm_t owned through the C ABI (t2o_comm_*): one per process, on the process's GPU."""
+
+    def __init__(self, device, nranks=None, rank=None, exchange=None):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        if not lib.t2o_comm_available():
+            lib.t2o_comm_unique_id(None)                      # (sets the error text)
+            raise RuntimeError('t2o_comm: ' + lib.t2o_last_error().decode('utf-8', 'replace'))
+        if nranks is None:
+            up = dist.is_available() and dist.is_initialized()
+            nranks, rank = (dist.get_world_size(), dist.get_rank()) if up else (1, 0)
+        ident = None
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(lib.t2o_comm_unique_id(buf), 't2o_comm_unique_id')
+            ident = buf.raw
+        if exchange is not None:
+            ident = exchange(ident)
+        elif nranks > 1:
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            ident = box[0]
+        self.nranks, self.rank = int(nranks), int(rank)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.t2o_comm_init_rank(ctypes.byref(handle), self.nranks, ident, self.rank), 't2o_comm_init_rank')
+        self.handle = handle
+
+    def all_reduce_(self, t, mean=False):
+        """In-place sum (mean) of a dense fp32 GPU tensor over the communicator, on torch's current stream."""
+        from . import _lib
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError('Communicator.all_reduce_: a dense fp32 GPU tensor')
+        lib = _lib.load()
+        fn = lib.t2o_allreduce_mean if mean else lib.t2o_allreduce
+        _lib.check(fn(t.data_ptr(), t.numel(), self.handle, T._stream(t.device)), 't2o_allreduce')
+        return t
+
+    def close(self):
+        if self.handle:
+            from . import _lib
+            _lib.load().t2o_comm_destroy(self.handle)
+            self.handle = None
 
 
 def _view_like(seg, p):

@@ -88,3 +88,12 @@ def ssim(a, b):
     out = np.zeros(B, np.float32)
     assert lib().emul_ssim(_p(a), _p(b), _p(out), B, C, H, W) == 0
     return out
+
+
+def ssim_bwd(a, b, gout):
+    """Both image gradients of the per-sample SSIM means for the output gradient gout (B)."""
+    a, b, gout = _f(a), _f(b), _f(gout)
+    B, C, H, W = a.shape
+    ga, gb = np.full_like(a, np.nan), np.full_like(b, np.nan)
+    assert lib().emul_ssim_bwd(_p(a), _p(b), _p(gout), _p(ga), _p(gb), B, C, H, W) == 0
+    return ga, gb

@@ -261,6 +261,28 @@ int emul_ssim(const float* a, const float* b, float* out, int B, int C, int H, i
   return 0;
 }
 
+int emul_ssim_bwd(const float* a, const float* b, const float* gout, float* ga, float* gb, int B, int C, int H, int W) {
+  SsimBwdArgs s;
+  memset(&s, 0, sizeof(s));
+  s.a = a; s.b = b; s.gout = gout; s.ga = ga; s.gb = gb;
+  ssim_window(s.g);
+  s.B = B; s.C = C; s.H = H; s.W = W;
+  s.tiles_x = (W + kSsimTile - 1) / kSsimTile;
+  s.tiles = s.tiles_x * ((H + kSsimTile - 1) / kSsimTile);
+  s.inv_n = 1.0f / ((float)C * (float)H * (float)W);
+  std::vector<float> lds(ssim_bwd_lds_floats());
+  for (int plane = 0; plane < B * C; ++plane)
+    for (int tile = 0; tile < s.tiles; ++tile) {
+      for (size_t i = 0; i < lds.size(); ++i) lds[i] = NAN;       // (a phase reading what no phase wrote shows up)
+      for (int tid = 0; tid < kThreads; ++tid) ssim_bwd_phase_load(s, plane, tile, tid, lds.data());
+      for (int tid = 0; tid < kThreads; ++tid) ssim_bwd_phase_rows(s, tid, lds.data());
+      for (int tid = 0; tid < kThreads; ++tid) ssim_bwd_phase_deriv(s, plane, tile, tid, lds.data());
+      for (int tid = 0; tid < kThreads; ++tid) ssim_bwd_phase_drows(s, tid, lds.data());
+      for (int tid = 0; tid < kThreads; ++tid) ssim_bwd_phase_out(s, plane, tile, tid, lds.data());
+    }
+  return 0;
+}
+
 int emul_fused_buffers(const int* ops, int K) {
   Segment seg[64];
   const int ns = plan_segments(ops, K, seg, 64);

@@ -259,6 +259,23 @@ def test_ssim_block_program(shape, golden_dir):
         assert abs(float(emul.ssim(a.numpy(), b.numpy())[0]) - float(g['ssim'])) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(1, 3, 48, 40), (2, 3, 33, 70), (1, 1, 5, 7), (1, 2, 64, 37)])
+def test_ssim_backward_block_program(shape):
+    """The five phases of k_ssim_bwd (closed-form gradient of utils/ssim/__init__.py:20-40) thread by thread on the host against
+    fp64 autograd of the oracle's SSIM, for both images and a non-uniform output gradient; tiles with every kind of border."""
+    B, C, H, W = shape
+    a = synth.uniform(shape, 51)
+    b = (a + synth.uniform(shape, 52, -0.1, 0.1)).clamp(0, 1)
+    gout = synth.uniform((B,), 53, 0.5, 1.5)
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    (cpu_ref.ssim(a64, b64, size_average=False) * gout.double()).sum().backward()
+    ga, gb = emul.ssim_bwd(a.numpy(), b.numpy(), gout.numpy())
+    for got, ref in ((ga, a64.grad), (gb, b64.grad)):
+        scale = float(ref.abs().max())
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, ref.numpy(), rtol=0, atol=2e-5 * scale)
+
+
 def quantized_image(B=2, H=24, W=32, levels=16, seed=95):
     """8-bit-photo-like image on a coarse lattice: most pixels have two or three equal channels,
     many sit on curve knots or at 0 / 1."""

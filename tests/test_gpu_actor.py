@@ -264,6 +264,47 @@ def test_one_rank_nccl_group_gives_the_ungrouped_run(tmp_path):
     assert grouped == plain, (grouped, plain)
 
 
+def test_c_abi_allreduce_on_an_own_one_rank_communicator():
+    """SURVEY 8(b)'s t2o_allreduce(float*, size_t, ncclComm_t, hipStream_t): a communicator built through the C ABI
+    (t2o_comm_unique_id / t2o_comm_init_rank, RCCL resolved at run time), one rank -- all a 1-GPU box can run.  Sum and
+    mean of one rank are the identity, bit for bit, stream-ordered with neighbouring kernels; the Trainer's flat gradient
+    buffer goes through it (`use_own_communicator`) and the step equals the step without any communicator."""
+    import copy
+    import t2onet_amd
+    from t2onet_amd import _lib
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Communicator, Trainer
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    assert lib.t2o_comm_available() == 1
+    comm = Communicator(dev)
+    assert comm.nranks == 1 and comm.rank == 0 and comm.handle
+    t = synth.uniform((22165917,), 5, -1.0, 1.0).to(dev)
+    ref = t.clone()
+    u = t * 2.0                                              # (a producer on the same stream right before ...)
+    comm.all_reduce_(u)
+    comm.all_reduce_(u, mean=True)
+    v = u * 0.5                                              # (... and a consumer right after: stream order must hold)
+    assert torch.equal(v, ref)
+    assert lib.t2o_allreduce(None, 4, comm.handle, None) != 0 and lib.t2o_allreduce(t.data_ptr(), 4, None, None) != 0
+    opt = t2onet_amd.default_options(input_dropout_p=0.0, dropout_p=0.0)
+    torch.manual_seed(51)
+    base = Actor(opt).to(dev).train()
+    base.use_channels_last()
+    Bn = 4
+    img, tgt = synth.images(Bn, 64, 64, 111).to(dev), synth.images(Bn, 64, 64, 112).to(dev)
+    x = synth.requests(Bn, 17, 113).to(dev)
+    lengths = (x != 0).sum(1).cpu()
+
+    def run(own):
+        tr = Trainer(copy.deepcopy(base), opt)
+        if own:
+            tr.grads._comm = comm
+        return [float(tr.episode_step(x, img, tgt, reinforce_sample=0, lengths=lengths)) for _ in range(3)]
+    assert run(True) == run(False)
+    comm.close()
+
+
 def test_episode_with_local_edit_masks():
     """mask_dict path (actor.py:78-98, :238-239): samples with a mask for the chosen operator are
     edited only inside it; others globally.  Checked against the unmasked run and the blend identity."""

@@ -545,6 +545,44 @@ def test_ssim_kernel(dev, golden_dir, shape):
         assert abs(out[0].item() - float(g['ssim'])) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(1, 3, 48, 40), (2, 3, 33, 70), (1, 1, 5, 7), (1, 3, 397, 600), (4, 3, 256, 256)])
+def test_ssim_backward_kernel(dev, shape):
+    """t2o_ssim_bwd (closed-form gradient of utils/ssim/__init__.py:20-40; the reference leaves it to autograd) against fp64
+    autograd of the oracle's SSIM: both image gradients, per-sample output gradients, through torch.autograd on the device
+    (`1 - ssim` as a loss).  1e-4 of the largest gradient entry: the statistics are differences of fp32 window sums."""
+    import t2onet_amd.functional as T
+    B = shape[0]
+    a = synth.uniform(shape, 51)
+    b = (a + synth.uniform(shape, 52, -0.1, 0.1)).clamp(0, 1)
+    gout = synth.uniform((B,), 53, 0.5, 1.5)
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    (cpu_ref.ssim(a64, b64, size_average=False) * gout.double()).sum().backward()
+    x, y = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    (T.ssim(x, y, size_average=False) * gout.to(dev)).sum().backward()
+    for got, ref in ((x.grad, a64.grad), (y.grad, b64.grad)):
+        scale = float(ref.abs().max())
+        assert torch.isfinite(got).all()
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4 * scale)
+    # one-sided: only the prediction needs a gradient (the loss form); bitwise the same values, and run-to-run reproducible
+    x2 = a.to(dev).requires_grad_(True)
+    (1.0 - T.ssim(x2, b.to(dev))).backward()
+    x3 = a.to(dev).requires_grad_(True)
+    (1.0 - T.ssim(x3, b.to(dev))).backward()
+    assert torch.equal(x2.grad, x3.grad)
+    a64b = a.double().requires_grad_(True)
+    (1.0 - cpu_ref.ssim(a64b, b.double())).backward()
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), a64b.grad.numpy(), rtol=0, atol=1e-4 * float(a64b.grad.abs().max()))
+
+
+def test_ssim_backward_refuses_bad_arguments(dev):
+    from t2onet_amd import _lib
+    lib = _lib.load()
+    a = torch.rand(1, 3, 8, 8, device=dev)
+    g = torch.ones(1, device=dev)
+    assert lib.t2o_ssim_bwd(a.data_ptr(), a.data_ptr(), g.data_ptr(), None, None, 1, 3, 8, 8, None) != 0
+    assert lib.t2o_ssim_bwd(a.data_ptr(), a.data_ptr(), g.data_ptr(), a.data_ptr(), None, 1, 0, 8, 8, None) != 0
+
+
 def test_config5_shape_fused_equals_materialised(executor, dev):
     """BASELINE config 5 per-GPU shape: 16 images 512x512, 8 operators (curve-heavy, repeats allowed)."""
     B, H, W = 16, 512, 512
