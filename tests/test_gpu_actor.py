@@ -1,15 +1,21 @@
-"""The actor on the GPU (HIP executor + attention kernels, MIOpen/hipBLASLt for conv/LSTM/GEMM)
-against outputs of the reference itself (tests/golden/actor.npz from tools/gen_golden.py).
+"""The actor on the GPU -- every layer on this library's own fp32 kernels (encoder trunk, request-encoder LSTM, decoder step,
+attention, parameter heads, operators) -- against outputs of the reference itself (tests/golden/actor.npz from
+tools/gen_golden.py: the reference's CPU run).
 
-Images are compared at 5e-4: the predicted operator parameters already differ from the
-reference's CPU run by up to ~1e-4 (they come out of the library ResNet/LSTM), and e.g.
-sharpness multiplies a parameter difference by up to 4 on a pixel; the hand-written kernels
-themselves are pinned at 1e-5 in test_gpu_operators.py.  Backward is only checked in train mode:
-MIOpen (like cuDNN) refuses an RNN backward in eval mode.
+Operator indices must be identical (argmax mode).  Floating-point tolerances are set at ~3x the distances measured with
+tools/measure_parity.py (round 5, profiles/r05_parity_distances.txt), per mode:
 
-Operator indices must be identical (argmax mode); floating-point outputs within 1e-4 of the
-reference's CPU run here: they pass through a 21-conv ResNet and two LSTMs whose library
-kernels (MIOpen vs oneDNN) round differently, before reaching the hand-written kernels."""
+                      evaluation mode            training mode (batch statistics over B = 4)
+  pred_params         3.4e-8 .. 2.4e-7           5.7e-6 / 4.8e-7        (episode / teacher-forced)
+  image crops         4.1e-6 / 5.0e-6            6.5e-5 / 1.3e-5
+  log-probabilities   1.2e-6                     1.5e-5
+  losses              <= 2.4e-7                  <= 1.4e-6
+  gradient norms      --                         9.2e-5 / 1.7e-5 relative
+
+Training mode is looser than evaluation mode for a structural reason, not a library one: BatchNorm over 4 samples (and
+BatchNorm1d over 4 VALUES per feature) divides by a standard deviation formed from a handful of numbers, which amplifies the
+last-bit differences of the convolutions in front of it.  The hand-written kernels themselves are pinned at 1e-5 .. 1e-6 in
+test_gpu_operators.py / test_gpu_conv.py / test_gpu_decoder.py."""
 import os
 
 import numpy as np
@@ -50,12 +56,13 @@ def test_episode_l1_step_matches_reference(gold, mode):
     tgt = synth.images(B, H, W, 43).to(dev)
     state, pred_imgs, pred_ops, pred_params = model.episode_forward(x, img, None, reinforce_sample=0)
     np.testing.assert_array_equal(pred_ops.cpu().numpy(), gold[p + 'pred_ops'])             # bit-exact indices
-    np.testing.assert_allclose(torch.stack(pred_params, 0).detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=5e-4)
-    np.testing.assert_allclose(pred_imgs.detach().double().mean((2, 3, 4)).cpu().numpy(), gold[p + 'imgs_mean'], rtol=0, atol=1e-4)
+    tol = {'params': 1e-6, 'crop': 1.5e-5, 'mean': 1.5e-6} if mode == 'eval' else {'params': 2e-5, 'crop': 2e-4, 'mean': 1e-5}
+    np.testing.assert_allclose(torch.stack(pred_params, 0).detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-5, atol=tol['params'])
+    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=tol['crop'])
+    np.testing.assert_allclose(pred_imgs.detach().double().mean((2, 3, 4)).cpu().numpy(), gold[p + 'imgs_mean'], rtol=0, atol=tol['mean'])
     assert state['imgs'].shape == pred_imgs.shape and len(state['hidden']) == 6 and state['masks'] is None
     loss = T.l1_loss(select_end_images(pred_imgs, pred_ops, opt.end_id), tgt)
-    assert abs(loss.item() - float(gold[p + 'loss'])) < 1e-5                                    # L1 deviation <= 1e-5
+    assert abs(loss.item() - float(gold[p + 'loss'])) < 1e-6                                    # L1 deviation (north star: <= 1e-5)
     if mode == 'eval':
         return
     loss.backward()
@@ -64,7 +71,7 @@ def test_episode_l1_step_matches_reference(gold, mode):
     gn = np.array([0.0 if params[n].grad is None else params[n].grad.double().norm().item() for n in names])
     ref = gold[p + 'grad_norm']
     big = ref > 1e-3 * ref.max()
-    np.testing.assert_allclose(gn[big], ref[big], rtol=2e-2)
+    np.testing.assert_allclose(gn[big], ref[big], rtol=3e-4)                                      # (measured 9.2e-5)
     # heads of unused operators get zeros here (gather over all heads) where the reference has None
     none_ref = gold[p + 'grad_none']
     assert np.all(gn[none_ref] == 0.0)
@@ -87,12 +94,14 @@ def test_supervised_step_matches_reference(gold, mode):
             gt_params[b, k, nparam[int(y[b, k + 1])]:] = 0
     y, gt_params = y.to(dev), gt_params.to(dev)
     pred_imgs, pred_params, logp = model.supervised_forward(x, y, img, img_y, gt_params, None)
-    np.testing.assert_allclose(pred_params.detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(logp.detach().cpu().numpy(), gold[p + 'logprobs'], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=5e-4)
+    tol = ({'params': 1e-6, 'logp': 5e-6, 'crop': 1.5e-5, 'loss': 1e-6} if mode == 'eval'
+           else {'params': 2e-6, 'logp': 5e-5, 'crop': 4e-5, 'loss': 5e-6})
+    np.testing.assert_allclose(pred_params.detach().cpu().numpy(), gold[p + 'pred_params'], rtol=1e-5, atol=tol['params'])
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), gold[p + 'logprobs'], rtol=1e-5, atol=tol['logp'])
+    np.testing.assert_allclose(pred_imgs[:, :, :, 8:24, 8:24].detach().cpu().numpy(), gold[p + 'imgs_crop'], rtol=0, atol=tol['crop'])
     op_loss, param_loss = cpu_ref.supervised_loss(pred_params, logp, y, gt_params, opt)
-    assert abs(op_loss.item() - float(gold[p + 'op_loss'])) < 1e-4
-    assert abs(param_loss.item() - float(gold[p + 'param_loss'])) < 1e-4
+    assert abs(op_loss.item() - float(gold[p + 'op_loss'])) < tol['loss']
+    assert abs(param_loss.item() - float(gold[p + 'param_loss'])) < tol['loss']
     if mode == 'eval':
         return
     (op_loss + param_loss).backward()
@@ -101,7 +110,7 @@ def test_supervised_step_matches_reference(gold, mode):
     gn = np.array([0.0 if params[n].grad is None else params[n].grad.double().norm().item() for n in names])
     ref = gold[p + 'grad_norm']
     big = ref > 1e-3 * ref.max()
-    np.testing.assert_allclose(gn[big], ref[big], rtol=2e-2)
+    np.testing.assert_allclose(gn[big], ref[big], rtol=1e-4)                                      # (measured 1.7e-5)
 
 
 def test_trainer_alternates_and_learns():

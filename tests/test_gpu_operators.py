@@ -4,8 +4,10 @@ reference-shaped Executor/Operator API, against
   (b) the oracle on seeded inputs at sizes it finishes in seconds,
   (c) size-independent properties at BASELINE.json's full sizes.
 
-Tolerance (north_star: <= 1e-5 relative fp32): forward atol 1e-5 (observed ~1e-7: the kernels
-follow the reference's operation order with -ffp-contract=off); gradients are closed forms, so
+Tolerance (north_star: <= 1e-5 relative fp32): forward rtol 1e-5 + atol 2e-6 -- a RELATIVE bound with a floor of two fp32
+ulps of 1.0 for values at zero (measured with tools/measure_parity.py, round 5: every output of every operator is within
+1e-5 relative of the reference / the oracle, no absolute floor needed; the kernels follow the reference's operation order
+with -ffp-contract=off), so a regression on dark pixels cannot hide; gradients are closed forms, so
 they are compared with the oracle's fp64 autograd at 1e-5 and with the reference's fp32
 autograd at 2e-5 + 1e-4 rel (its HSV round trip is itself that noisy: SURVEY.md section 7)."""
 import os
@@ -72,7 +74,7 @@ def test_golden_reference_outputs(executor, gold, dev, op):
             out, par = executor.execute(x, op, None if mask is None else mask.to(dev), specified_param=p)
             assert par is p
             out.backward(gout)
-            np.testing.assert_allclose(out.detach().cpu().numpy(), gold[key + '_out'], rtol=0, atol=1e-5, err_msg=key)
+            np.testing.assert_allclose(out.detach().cpu().numpy(), gold[key + '_out'], rtol=1e-5, atol=2e-6, err_msg=key)
             np.testing.assert_allclose(x.grad.cpu().numpy(), gold[key + '_gimg'], rtol=1e-4,
                                        atol=2e-5 if op in (0, 2) else 5e-6, err_msg=key)
             scale = max(1.0, float(np.abs(gold[key + '_gparam']).max()))
@@ -129,7 +131,7 @@ def test_vs_oracle_ragged_sizes(executor, dev, op, shape):
         pp = p.to(dev).requires_grad_(True)
         out, _ = executor.execute(x, op, None if mask is None else mask.to(dev), specified_param=pp)
         out.backward(gout.to(dev))
-        np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), o_ref.numpy(), rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(x.grad.cpu().numpy(), gi64.numpy(), rtol=1e-5, atol=5e-6)
         scale = max(1.0, float(gp64.abs().max()))
         np.testing.assert_allclose(pp.grad.cpu().numpy(), gp64.numpy(), rtol=2e-4, atol=1e-4 * scale)
