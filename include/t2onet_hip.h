@@ -622,6 +622,18 @@ int t2o_graph_memsets_to_kernels(void* graph, int* replaced);
 int t2o_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                   float beta2, float eps, int step, void* stream);
 
+/* ---- WEIGHT GRADIENT of the same layers in the Winograd domain with both transforms on chip (t2o_wino_wgrad.hip;
+ * models/actor_resnet.py:24-44 under autograd in the reference): dw (Co,3,3,Ci) (+)= d loss / d w of y = conv2d(x, w, None, 1, 1)
+ * for x (n_img,H,W,Ci), dy (n_img,H,W,Co) NHWC, H and W multiples of 16, Ci and Co multiples of 64 (<= 512), fewer than 2^31
+ * pixels.  n_img may span several encoder passes laid side by side (encoder.WgradArena).  16 of the direct kernel's 36
+ * multiplies; V = B^T d B and A dY A^T live in LDS only.  Deterministic: per-workgroup partial sums in the workspace
+ * (t2o_wino_fused_wgrad_workspace_bytes), added in a fixed order, then G^T dU G (t2o_wino_dw_transform).  zeros: >= 17 * Ci * 4 +
+ * 256 bytes of zeros, 16-byte aligned (t2o_conv_set_zero_region's block serves). */
+int t2o_wino_fused_wgrad_supported(int n_img, int H, int W, int Ci, int Co);
+size_t t2o_wino_fused_wgrad_workspace_bytes(int n_img, int H, int W, int Ci, int Co);
+int t2o_wino_fused_wgrad_nhwc(const float* x, const float* dy, float* dw, const float* zeros, void* workspace, size_t workspace_bytes,
+                              int n_img, int H, int W, int Ci, int Co, int accumulate, void* stream);
+
 /* ---- the train step's one collective (the reference runs one process: train_seq2seqL1.py:74-88 has no
  * counterpart).  t2o_allreduce: in-place SUM all-reduce of n fp32 values over the caller's communicator (an ncclComm_t, passed
  * as void*), stream-ordered on `stream`, no host synchronisation; t2o_allreduce_mean: the same followed by x 1/nranks (the

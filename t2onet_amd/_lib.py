@@ -47,6 +47,9 @@ SIGNATURES = {
     't2o_ssim_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     't2o_ssim_fwd': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _P]),
     't2o_ssim_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    't2o_wino_fused_wgrad_supported': (_I, [_I, _I, _I, _I, _I]),
+    't2o_wino_fused_wgrad_workspace_bytes': (_Z, [_I, _I, _I, _I, _I]),
+    't2o_wino_fused_wgrad_nhwc': (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     't2o_comm_available': (_I, []),
     't2o_comm_unique_id': (_I, [_P]),
     't2o_comm_init_rank': (_I, [_P, _I, _P, _I]),

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, _zero_block, wino_conv_nhwc, wino_fused_conv_nhwc, wino_wgrad_nhwc, wino_input,
-                         wino_backward_nhwc, wino_dw_from)
+                         wino_backward_nhwc, wino_dw_from, wino_fused_wgrad_nhwc)
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
 _WINOGRAD = os.environ.get('T2O_WINOGRAD', '1') != '0'
@@ -35,6 +35,9 @@ _DUAL_BN = True      # a shortcut block's two batch norms in one pass each way (
 # T2O_WINOGRAD_FUSED=0: the direct kernels there (A/B)
 _WINO_FUSED = os.environ.get('T2O_WINOGRAD_FUSED', '1') != '0'
 _BN_SUMS_EPILOGUE = True     # bn1's backward sums from the epilogue of conv2's data gradient (direct kernels); switch for the tests
+# the weight gradient of the on-chip Winograd layers in the Winograd domain too, both transforms on chip (t2o_wino_wgrad.hip);
+# T2O_WINOGRAD_WGRAD=0: the direct weight-gradient kernel there (A/B)
+_WINO_WGRAD = os.environ.get('T2O_WINOGRAD_WGRAD', '1') != '0'
 
 
 def _fast_direct(stride, Hi, Wi, Wo):
@@ -321,6 +324,8 @@ class WgradArena:
                 x = self.x[xkey][first * N:(first + count) * N]
                 dy = self.dy[id(conv)][first * N:(first + count) * N]
                 n = count * N
+                if kind == '3x3' and _WINO_WGRAD and plan.fused_wino(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, w.grad, n, Hn, Wn, True):
+                    continue                                   # Winograd domain, both transforms on chip: 16 of 36 multiplies
                 if kind == '3x3':
                     s = conv.stride[0]
                     need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(n, Hn, Wn, Ci, Co)
@@ -521,6 +526,8 @@ class _TrunkFn(torch.autograd.Function):
             if plan.wino(conv, Hi, Wi):
                 V = ctx.kept_v.pop(id(conv), None)
                 wino_wgrad_nhwc(V if V is not None else wino_input(x, N, Hi, Wi), dy, g(w), N, Hi, Wi, acc)
+                return
+            if _WINO_WGRAD and plan.fused_wino(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, g(w), N, Hi, Wi, bool(acc)):
                 return
             if Wn % 4 == 0 and (s == 1 or (Hi % 2 == 0 and Wi % 2 == 0)):
                 need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)

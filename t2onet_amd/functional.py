@@ -1588,6 +1588,27 @@ def wino_fused_conv_nhwc(x, Uc, N, H, W, addend=None, want_stats=False, out=None
     return y, stats
 
 
+def wino_fused_wgrad_nhwc(x, dy, dw, n_img, H, W, accumulate):
+    """dw (Co,3,3,Ci) (+)= weight gradient of the stride-1 3x3 convolution for x (n_img,H,W,Ci), dy (n_img,H,W,Co) NHWC buffers, in
+    the Winograd domain with both transforms on chip (t2o_wino_fused_wgrad_nhwc).  False when the shape is not taken (H, W
+    multiples of 16, channel counts multiples of 64 up to 512)."""
+    lib = _lib.load()
+    dev = x.device
+    Ci, Co = x.shape[-1], dy.shape[-1]
+    if not lib.t2o_wino_fused_wgrad_supported(n_img, H, W, Ci, Co):
+        return False
+    if not (x.is_contiguous() and x.numel() == n_img * H * W * Ci and dy.is_contiguous() and dy.numel() == n_img * H * W * Co):
+        raise ValueError('wino_fused_wgrad_nhwc: x and dy must be dense (n_img,H,W,C) buffers')
+    if not (dw.numel() == Co * 9 * Ci and (dw.is_contiguous() or (dw.dim() == 4 and dw.is_contiguous(memory_format=torch.channels_last)))):
+        raise ValueError('wino_fused_wgrad_nhwc: dw must be a dense (Co,3,3,Ci) buffer (a channels-last convolution weight)')
+    need = lib.t2o_wino_fused_wgrad_workspace_bytes(n_img, H, W, Ci, Co)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    rc = lib.t2o_wino_fused_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), _ptr(_zero_block(dev)), _ptr(ws), need, n_img, H, W, Ci, Co,
+                                       1 if accumulate else 0, _stream(dev))
+    _lib.check(rc, 't2o_wino_fused_wgrad_nhwc')
+    return True
+
+
 def conv3x3_winograd(x, weight, addend=None):
     """conv2d(x, weight, None, 1, 1) (+ addend) through the Winograd pipeline; x (N,Ci,H,W) any layout, returns channels_last."""
     _need_gpu(x, weight)

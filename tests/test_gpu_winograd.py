@@ -268,3 +268,83 @@ def test_on_chip_winograd_matches_conv2d_fp64(shape, with_addend):
     assert float((s - want).abs().max()) <= 1e-5 * float(want.abs().max())
     y2, stats2 = T.wino_fused_conv_nhwc(xh, Uc, N, H, W, ah, want_stats=True)
     assert torch.equal(y, y2) and torch.equal(stats, stats2)
+
+
+# (n_img, Ci, Co, H, W): the stage shapes at small batch, several (co, ci) tiles, Ci != Co, wide / tall maps, one step per split
+WGW_SHAPES = [(2, 64, 64, 16, 16), (3, 64, 64, 32, 48), (2, 128, 128, 32, 32), (1, 64, 128, 16, 32), (2, 128, 64, 48, 16), (5, 64, 64, 64, 64),
+              (1, 192, 64, 16, 16)]
+
+
+@pytest.mark.parametrize('shape', WGW_SHAPES)
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_on_chip_winograd_weight_gradient_matches_fp64(shape, accumulate):
+    """t2o_wino_fused_wgrad_nhwc (B^T d B and A dY A^T formed on chip, dU accumulated in the matrix-core registers over a range
+    of the tile index, fixed-order sum of the ranges, G^T dU G) against the fp64 weight gradient of conv2d; a repeat is
+    bit-identical."""
+    import t2onet_amd.functional as T
+    N, Ci, Co, H, W = shape
+    x = synth.uniform((N, Ci, H, W), 1831, -1.0, 1.0)
+    dy = synth.uniform((N, Co, H, W), 1832, -1.0, 1.0)
+    w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(x.double(), w64, None, 1, 1) * dy.double()).sum().backward()
+    ref = w64.grad
+    dev = torch.device('cuda:0')
+    xh, dyh = x.to(dev).permute(0, 2, 3, 1).contiguous(), dy.to(dev).permute(0, 2, 3, 1).contiguous()
+    start = synth.uniform((Co, 3, 3, Ci), 1833, -1.0, 1.0).to(dev)
+    dw = start.clone()
+    assert T.wino_fused_wgrad_nhwc(xh, dyh, dw, N, H, W, accumulate)
+    got = (dw - start if accumulate else dw).permute(0, 3, 1, 2).cpu().numpy()
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got, ref.float().numpy(), rtol=1e-5, atol=(3e-5 if accumulate else 1e-5) * scale)
+    dw2 = start.clone()
+    assert T.wino_fused_wgrad_nhwc(xh, dyh, dw2, N, H, W, accumulate)
+    assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize('shape', [(320, 64, 64, 64, 64), (320, 128, 128, 32, 32)])
+def test_on_chip_winograd_weight_gradient_at_the_train_step_size(shape):
+    """The shapes of one train step (bs = 64, five encoder passes side by side in encoder.WgradArena): against the direct
+    weight-gradient kernel (itself held to fp64 in test_gpu_conv.py) over all 320 images, against fp64 on the first 16,
+    and bitwise run-to-run reproducible."""
+    import t2onet_amd.functional as T
+    from t2onet_amd import _lib
+    N, Ci, Co, H, W = shape
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(1841)
+    xh = (torch.rand(N, H, W, Ci, generator=g) - 0.5).to(dev)
+    dyh = (torch.rand(N, H, W, Co, generator=g) - 0.5).to(dev)
+    dw = torch.zeros(Co, 3, 3, Ci, device=dev)
+    assert T.wino_fused_wgrad_nhwc(xh, dyh, dw, N, H, W, False)
+    dw2 = torch.full_like(dw, 7.0)
+    assert T.wino_fused_wgrad_nhwc(xh, dyh, dw2, N, H, W, False)
+    assert torch.equal(dw, dw2)
+    lib = _lib.load()
+    need = lib.t2o_conv3x3_wgrad_workspace_bytes(N, H, W, Ci, Co)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ref = torch.zeros_like(dw)
+    _lib.check(lib.t2o_conv3x3_wgrad_acc_nhwc(xh.data_ptr(), dyh.data_ptr(), ref.data_ptr(), ws.data_ptr(), need, N, H, W, Ci, Co, 1, 0,
+                                              torch.cuda.current_stream().cuda_stream), 'direct wgrad')
+    scale = float(ref.abs().max())
+    assert float((dw - ref).abs().max()) <= 2e-5 * scale
+    n = 16
+    dwn = torch.zeros_like(dw)
+    assert T.wino_fused_wgrad_nhwc(xh[:n].contiguous(), dyh[:n].contiguous(), dwn, n, H, W, False)
+    w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    (torch.nn.functional.conv2d(xh[:n].cpu().permute(0, 3, 1, 2).double(), w64, None, 1, 1) * dyh[:n].cpu().permute(0, 3, 1, 2).double()).sum().backward()
+    r64 = w64.grad.permute(0, 2, 3, 1)
+    assert float((dwn.cpu().double() - r64).abs().max()) <= 1e-5 * float(r64.abs().max())
+
+
+def test_on_chip_winograd_weight_gradient_refuses_what_it_does_not_take():
+    import t2onet_amd.functional as T
+    from t2onet_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    assert not lib.t2o_wino_fused_wgrad_supported(2, 24, 16, 64, 64) and not lib.t2o_wino_fused_wgrad_supported(2, 16, 16, 32, 64)
+    assert not lib.t2o_wino_fused_wgrad_supported(2, 16, 16, 64, 576) and lib.t2o_wino_fused_wgrad_workspace_bytes(2, 8, 8, 64, 64) == 0
+    x = torch.zeros(2, 16, 16, 64, device=dev)
+    assert T.wino_fused_wgrad_nhwc(torch.zeros(2, 8, 8, 64, device=dev), torch.zeros(2, 8, 8, 64, device=dev), torch.zeros(64, 3, 3, 64, device=dev), 2, 8, 8, False) is False
+    ws = torch.empty(16, dtype=torch.uint8, device=dev)
+    assert lib.t2o_wino_fused_wgrad_nhwc(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), ws.data_ptr(), 16, 2, 16, 16, 64, 64, 0, None) != 0
+    assert b'workspace' in lib.t2o_last_error()
