@@ -18,8 +18,8 @@
 //       (2 x 32 KiB, double-buffered: 128 KiB);
 //     * the MFMA operands are plain ds_read_b32 of those rows (a lane = one channel of one of the k-step's two tiles -- the
 //       operand order of the instruction, as in k_gemm_tn), 4 MFMAs per plane and step, 64 per wave and step.
-//   The vector instructions of the transforms sit BETWEEN the wave's own MFMAs (measured on the forward kernel: everything
-//   issued outside them is added time).  The workgroup's 16 x 64 x 64 partial sums go to `part[split]`; a fixed-order two-level
+//   The vector instructions of a step's transforms sit in ONE gap between the wave's own MFMAs, its loads and stores one or two
+//   per gap behind them (k_wino_wgrad's step comment has the measurements): a step takes ~4,990 cycles for the 4,096 of its MFMAs.  The workgroup's 16 x 64 x 64 partial sums go to `part[split]`; a fixed-order two-level
 //   sum over the splits (k_wgw_reduce) and the existing G^T dU G kernel finish: deterministic, no atomics.
 //
 //   Algorithmic work per layer and encoder pass at bs = 64: 8.6 GFLOP (the direct kernel: 19.3).
@@ -50,6 +50,7 @@ struct WgwArgs {
   int n_img, H, W, Ci, Co;
   int steps_total;       // n_img * (H / 2) * (W / 16)
   int splits, combos, tiles_ci;
+  unsigned long long* stamps;   // diagnostic builds only (tools/diag/wgw_clock.hip)
 };
 
 __device__ __forceinline__ void mfma_asm(f32x16& c, float a, float b) {
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
     if (p.sx == SEG) { p.sx = 0; p.ty += 1; if (p.ty == TH) { p.ty = 0; p.img += 1; } }
   };
 
-  v2f d[4][4], dyv[2][2];
+  v2f dd[1][4][4], dyd[1][2][2];                            // the loaded patch / block (one step ahead of its transform)
+  float mLs[1] = {1.0f}, mRs[1] = {1.0f};                   // ... and its edge-column masks
   const gptr xbase = (gptr)a.x + (size_t)ci0 * 4;
   const gptr ybase = (gptr)a.dy + (size_t)co0 * 4;
   const gptr zbase = (gptr)a.zero;
@@ -118,64 +120,76 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
   unsigned xo1v = xo1, xo2v = xo1 + xpix, yo0v = yo, yo1v = yo + ypix;
   const size_t xrow = (size_t)a.W * xpix, yrow = (size_t)a.W * ypix;
 
-  // the 20 loads of step position p into d / dyv (+ the masks of ITS edge columns).  Pixel indices fit 32 bits (wgw_supported).
-  auto issue_loads = [&](const Pos& p, float& oL, float& oR) {
+  // the 20 loads of a step, in two parts: the step's addresses (scalar row bases, the two edge-column offsets and masks) ...
+  struct LoadCtx { gptr xr[4]; gptr yr[2]; unsigned o0, o3; float mL, mR; };
+  auto load_ctx = [&](const Pos& p) {
+    LoadCtx c;
     const bool edgeL = p.sx == 0, edgeR = p.sx == SEG - 1;
     asm volatile("" : "+v"(xo1v), "+v"(xo2v), "+v"(yo0v), "+v"(yo1v));
-    const unsigned o0 = (edgeL && is_first) ? xo1v : xo0;                // outside columns: a valid address, value masked to 0
-    const unsigned o3 = (edgeR && is_last) ? xo2v : xo3;
-    oL = (edgeL && is_first) ? 0.0f : 1.0f;
-    oR = (edgeR && is_last) ? 0.0f : 1.0f;
-    // row 2 ty of the image at column 16 sx; the x base stands one pixel LEFT of it (the lane offsets above are all >= 0)
+    c.o0 = (edgeL && is_first) ? xo1v : xo0;                             // outside columns: a valid address, value masked to 0
+    c.o3 = (edgeR && is_last) ? xo2v : xo3;
+    c.mL = (edgeL && is_first) ? 0.0f : 1.0f;
+    c.mR = (edgeR && is_last) ? 0.0f : 1.0f;
+    // row 2 ty of the image at column 16 sx; the x bases stand one pixel LEFT of it (the lane offsets are all >= 0).  Pixel
+    // indices fit 32 bits (wgw_supported).
     const unsigned pix = (unsigned)((p.img * a.H + 2 * p.ty) * a.W + 16 * p.sx);
-    const gptr xr1 = xbase + (size_t)pix * xpix - xpix;                  // patch row 1 = image row 2 ty
-    const gptr xr0 = p.ty == 0 ? zbase : xr1 - xrow;
-    const gptr xr2 = xr1 + xrow;
-    const gptr xr3 = p.ty == TH - 1 ? zbase : xr2 + xrow;
-    d[0][0] = ld2(xr0, o0); d[0][1] = ld2(xr0, xo1v); d[0][2] = ld2(xr0, xo2v); d[0][3] = ld2(xr0, o3);
-    d[1][0] = ld2(xr1, o0); d[1][1] = ld2(xr1, xo1v); d[1][2] = ld2(xr1, xo2v); d[1][3] = ld2(xr1, o3);
-    d[2][0] = ld2(xr2, o0); d[2][1] = ld2(xr2, xo1v); d[2][2] = ld2(xr2, xo2v); d[2][3] = ld2(xr2, o3);
-    d[3][0] = ld2(xr3, o0); d[3][1] = ld2(xr3, xo1v); d[3][2] = ld2(xr3, xo2v); d[3][3] = ld2(xr3, o3);
-    const gptr yr0 = ybase + (size_t)pix * ypix, yr1 = yr0 + yrow;
-    dyv[0][0] = ld2(yr0, yo0v); dyv[0][1] = ld2(yr0, yo1v);
-    dyv[1][0] = ld2(yr1, yo0v); dyv[1][1] = ld2(yr1, yo1v);
+    c.xr[1] = xbase + (size_t)pix * xpix - xpix;                         // patch row 1 = image row 2 ty
+    c.xr[0] = p.ty == 0 ? zbase : c.xr[1] - xrow;
+    c.xr[2] = c.xr[1] + xrow;
+    c.xr[3] = p.ty == TH - 1 ? zbase : c.xr[2] + xrow;
+    c.yr[0] = ybase + (size_t)pix * ypix;
+    c.yr[1] = c.yr[0] + yrow;
+    return c;
+  };
+  // ... and the loads one by one (k = 4 i + j: patch element (i, j); 16 .. 19: the 2 x 2 output-gradient block), so that the loop
+  // can deal them out one per MFMA gap: issued in one batch, the 4 waves' 80 loads queued up in front of the CU's one
+  // texture-address unit and the issuing plane took 1,370 cycles instead of 256 (tools/diag/wgw_clock.hip)
+  auto load_one = [&](auto kc, auto setc, const LoadCtx& c) {
+    constexpr int k = decltype(kc)::value, set = decltype(setc)::value;
+    if constexpr (k < 16) {
+      constexpr int i = k >> 2, j = k & 3;
+      dd[set][i][j] = ld2(c.xr[i], j == 0 ? c.o0 : j == 1 ? xo1v : j == 2 ? xo2v : c.o3);
+    } else {
+      constexpr int r = (k - 16) >> 1, q = (k - 16) & 1;
+      dyd[set][r][q] = ld2(c.yr[r], q == 0 ? yo0v : yo1v);
+    }
   };
 
   // ---- transforms, statement by statement (dealt out between MFMAs in the loop)
-  v2f tr[4][4], tv[4][4], ar[4][2], av[4][4];
-  auto t_row = [&](auto kc) {                             // k = 4 j + r: B^T d, rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-    constexpr int k = decltype(kc)::value, j = k >> 2, r = k & 3;
+  v2f tr[4][4], tv[4][4], ar[2][2], av[4][4];
+  auto t_row = [&](auto kc, auto setc) {                  // k = 4 j + r: B^T d, rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+    constexpr int k = decltype(kc)::value, j = k >> 2, r = k & 3, set = decltype(setc)::value;
     constexpr int p = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1, q = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3;
-    if constexpr (r == 1) tr[r][j] = d[p][j] + d[q][j];
-    else tr[r][j] = d[p][j] - d[q][j];
-    asm volatile("" : "+v"(tr[r][j]));
+    if constexpr (r == 1) tr[r][j] = dd[set][p][j] + dd[set][q][j];
+    else tr[r][j] = dd[set][p][j] - dd[set][q][j];
   };
-  auto t_mask = [&](auto kc, float cL, float cR) {        // k = 0..7: the image's outside columns are zeros
-    constexpr int k = decltype(kc)::value, r = k & 3;
-    if constexpr (k < 4) tr[r][0] = tr[r][0] * cL;
-    else tr[r][3] = tr[r][3] * cR;
-    asm volatile("" : "+v"(tr[r][k < 4 ? 0 : 3]));
-  };
-  auto t_col = [&](auto kc) {                             // k = 4 i + c: the same along the columns
+  // the same along the columns, k = 4 i + c.  The patch's outside columns (0 at the image's left edge, 3 at its right edge) were
+  // loaded from a valid neighbour and count as zeros: their 0 / 1 mask rides in the column step as a fused multiply-add -- the
+  // product with 0 or 1 is exact, so the result is that of masking first (8 vector instructions per step less)
+  auto t_col = [&](auto kc, float cL, float cR) {
     constexpr int k = decltype(kc)::value, i = k >> 2, c = k & 3;
-    constexpr int p = c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 2 : 1, q = c == 0 ? 2 : c == 1 ? 2 : c == 2 ? 1 : 3;
-    if constexpr (c == 1) tv[i][c] = tr[i][p] + tr[i][q];
-    else tv[i][c] = tr[i][p] - tr[i][q];
-    asm volatile("" : "+v"(tv[i][c]));
+    if constexpr (c == 0) tv[i][0] = __builtin_elementwise_fma(tr[i][0], (v2f){cL, cL}, -tr[i][2]);
+    else if constexpr (c == 1) tv[i][1] = tr[i][1] + tr[i][2];
+    else if constexpr (c == 2) tv[i][2] = tr[i][2] - tr[i][1];
+    else tv[i][3] = __builtin_elementwise_fma(-tr[i][3], (v2f){cR, cR}, tr[i][1]);
   };
-  const v2f zero2 = {0.0f, 0.0f};
-  auto a_row = [&](auto kc) {                             // k = 0..3: A dY: rows (d0, d0 + d1, d0 - d1, -d1) of the 2 x 2 block
-    constexpr int k = decltype(kc)::value, c = k & 1;
-    if constexpr (k < 2) { ar[0][c] = dyv[0][c]; ar[1][c] = dyv[0][c] + dyv[1][c]; asm volatile("" : "+v"(ar[1][c])); }
-    else { ar[2][c] = dyv[0][c] - dyv[1][c]; ar[3][c] = zero2 - dyv[1][c]; asm volatile("" : "+v"(ar[2][c]), "+v"(ar[3][c])); }
+  // A dY A^T of the 2 x 2 block WITHOUT its sign flips: rows (d0, d0 + d1, d0 - d1, d1), then per row (r0, r0 + r1, r0 - r1, r1).
+  // k_wino_dy's planes 3, 7, 11 (-r1 of rows 0..2) and 12, 13, 14 (row 3 = -d1; plane 15 = -(-d1's r1) is positive) are the
+  // negatives of these; a product with a negated operand is the negated product exactly, so k_wgw_reduce flips the sign of those
+  // planes' sums instead (6 vector instructions per step less).
+  auto a_row = [&](auto kc, auto setc) {                  // k = 0, 1: column c of the block
+    constexpr int c = decltype(kc)::value, set = decltype(setc)::value;
+    ar[0][c] = dyd[set][0][c] + dyd[set][1][c];
+    ar[1][c] = dyd[set][0][c] - dyd[set][1][c];
   };
-  auto a_col = [&](auto kc) {                             // k = row i: (r0, r0 + r1, r0 - r1, -r1)
-    constexpr int i = decltype(kc)::value;
-    av[i][0] = ar[i][0];
-    av[i][1] = ar[i][0] + ar[i][1];
-    av[i][2] = ar[i][0] - ar[i][1];
-    av[i][3] = zero2 - ar[i][1];
-    asm volatile("" : "+v"(av[i][1]), "+v"(av[i][2]), "+v"(av[i][3]));
+  auto a_col = [&](auto kc, auto setc) {                  // k = row i of A dY: (d0, d0 + d1, d0 - d1, d1)
+    constexpr int i = decltype(kc)::value, set = decltype(setc)::value;
+    const v2f r0 = i == 0 ? dyd[set][0][0] : i == 1 ? ar[0][0] : i == 2 ? ar[1][0] : dyd[set][1][0];
+    const v2f r1 = i == 0 ? dyd[set][0][1] : i == 1 ? ar[0][1] : i == 2 ? ar[1][1] : dyd[set][1][1];
+    av[i][0] = r0;
+    av[i][1] = r0 + r1;
+    av[i][2] = r0 - r1;
+    av[i][3] = r1;
   };
   auto v_store = [&](auto kc, int buf) {
     constexpr int k = decltype(kc)::value;
@@ -184,6 +198,22 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
   auto a_store = [&](auto kc, int buf) {
     constexpr int k = decltype(kc)::value;
     *reinterpret_cast<v2f*>(&As[buf][0] + k * kPlaneBytes + wr_off) = av[k >> 2][k & 3];
+  };
+  // the transform of a step as ONE list of 38 statements: 0-15 the patch's row steps | 16-17 the block's row steps | 18-21 its
+  // column steps (d and dyv are dead behind statement 21) | 22-37 the patch's column steps
+#ifndef T2O_WGW_VPG
+#define T2O_WGW_VPG 38
+#endif
+  constexpr int kVpg = T2O_WGW_VPG, kWork = 38;
+  constexpr int kLoadGap = (22 + kVpg - 1) / kVpg, kStoreGap = (kWork + kVpg - 1) / kVpg;
+  static_assert(kLoadGap + 20 <= 60 && kStoreGap + 16 <= 60, "the step's loads and stores end in front of its barrier");
+  using RS = std::integral_constant<int, 0>;
+  auto work = [&](auto wc) {
+    constexpr int w = decltype(wc)::value;
+    if constexpr (w < 16) t_row(std::integral_constant<int, w>{}, RS{});
+    else if constexpr (w < 18) a_row(std::integral_constant<int, w - 16>{}, RS{});
+    else if constexpr (w < 22) a_col(std::integral_constant<int, w - 18>{}, RS{});
+    else t_col(std::integral_constant<int, w - 22>{}, mLs[0], mRs[0]);
   };
 
   // ---- MFMA operands: k-step e of plane xi covers tiles 2 e, 2 e + 1; lane (ln, lh) = channel ln of tile 2 e + lh
@@ -205,28 +235,54 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-  // ---- prologue: step s_begin transformed into buffer 0, the loads of step s_begin + 1 in flight
-  Pos pl = pos_of(s_begin);
-  float cL, cR;                                            // masks of the data in d[] (set by the loads that filled it)
-  issue_loads(pl, cL, cR);
-  static_for<0, 16>([&](auto kc) { t_row(kc); });
-  static_for<0, 8>([&](auto kc) { t_mask(kc, cL, cR); });
-  static_for<0, 4>([&](auto kc) { a_row(kc); });
-  static_for<0, 16>([&](auto kc) { t_col(kc); });
-  static_for<0, 4>([&](auto kc) { a_col(kc); });
+  // ---- prologue: step s_begin transformed into buffer 0; the loads of step s_begin + 1 in flight.  Positions past the range's
+  // end are clamped to its last step (loaded and transformed again, into a buffer nobody reads).
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  Pos pl = pos_of(s_begin);                                // position of the newest loads
+  int sl = s_begin;                                        // ... and its step number
+  auto next_ctx = [&]() {                                  // advance (clamped) and form the addresses
+#ifndef T2O_WGW_SAMEROWS
+    if (sl + 1 < s_end) { advance(pl); sl += 1; }
+#endif
+    return load_ctx(pl);
+  };
+  {
+    const LoadCtx c0 = load_ctx(pl);
+    static_for<0, 20>([&](auto kc) { load_one(kc, RS{}, c0); });
+    mLs[0] = c0.mL; mRs[0] = c0.mR;
+  }
+  static_for<0, kWork>([&](auto wc) { work(wc); });
   static_for<0, 16>([&](auto kc) { v_store(kc, 0); a_store(kc, 0); });
-  if (s_begin + 1 < s_end) advance(pl);
-  issue_loads(pl, cL, cR);                                 // (a one-step range: the same step again, transformed into a buffer nobody reads)
+  {
+    const LoadCtx c1 = next_ctx();
+    static_for<0, 20>([&](auto kc) { load_one(kc, RS{}, c1); });
+    mLs[0] = c1.mL; mRs[0] = c1.mR;
+  }
   __syncthreads();
-  frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+  frag_read(I0{}, I0{}, 0);
 
-  // ---- one step: the MFMAs of step s from buffer `buf`; the transform of step s + 1 (in d / dyv since the last step) into
-  // buffer buf ^ 1; the loads of step s + 2.  Past the end the last step is loaded and transformed again, into a buffer nobody reads.
-  for (int s = s_begin; s < s_end; ++s) {
-    const int buf = (s - s_begin) & 1;
-    Pos pn = pl;                                           // position of the loads to issue: step s + 2 (clamped to the last)
-    if (s + 2 < s_end) advance(pn);
-    float nL = 1.0f, nR = 1.0f;
+  // ---- one step (bufc = step parity, a compile-time constant: the LDS addresses are immediates): the MFMAs of step s from LDS
+  // buffer buf; the transform of step s + 1 (loaded during step s - 1) into buffer buf ^ 1; then the loads of step s + 2.
+  // Gaps (one behind each of the 64 MFMAs), measured with tools/diag/wgw_clock.hip (cycles per step; the 64 MFMAs alone: 4,096):
+  //   * the 38 transform statements ALL in gap 0: a gap that holds vector instructions costs ~20 cycles whatever their number
+  //     plus 7-10 per instruction (two per gap over 19 gaps: 5,597; four: 5,366; eight: 5,238; nineteen: 5,163; all: 5,122);
+  //   * the 20 loads ONE per gap from gap 1 on (in one batch the 4 waves' 80 loads queued up in front of the CU's one
+  //     texture-address unit: 1,370 cycles for that plane instead of 256);
+  //   * the 32 stores two per gap behind them (inside gap 0, right behind their producers: 5,544 against 4,985);
+  //   * a second register set for the loads (consumed a whole step later) changed nothing (4,984): what the loads cost -- 230 of
+  //     the step's ~890 cycles beside its MFMAs, by the same loop reading one row over and over -- is queueing in the memory
+  //     system, not the latency of a single load.
+#ifdef T2O_WGW_DIAG
+  unsigned ph[16] = {};
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+  auto step_body = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#ifdef T2O_WGW_DIAG
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+    const LoadCtx cn = next_ctx();
     static_for<0, 16>([&](auto pc) {
       constexpr int p = decltype(pc)::value;               // plane
       if constexpr (p == 15) {
@@ -234,7 +290,7 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
         // plane 15's MFMAs (operands in registers) cover their latency
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, buf ^ 1);
+        frag_read(I0{}, I0{}, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       static_for<0, 4>([&](auto ec) {
@@ -244,22 +300,38 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
         constexpr int g = 4 * p + e;                       // gap number 0 .. 63
         // fragments of the next plane: behind this plane's first MFMA, into the other slot
         if constexpr (e == 0 && p + 1 < 15) frag_read(std::integral_constant<int, p + 1>{}, std::integral_constant<int, (p + 1) & 1>{}, buf);
-        if constexpr (e == 0 && p == 14) frag_read(std::integral_constant<int, 15>{}, std::integral_constant<int, 1>{}, buf);
-        // transform of step s + 1: rows (gaps 0-7), masks (8-11), A dY rows (12-13), then d / dyv are dead: loads of step
-        // s + 2 (gap 16), columns (20-27), A dY A^T columns (28-31), stores (32-47)
-        if constexpr (g < 8) { t_row(std::integral_constant<int, 2 * g>{}); t_row(std::integral_constant<int, 2 * g + 1>{}); }
-        else if constexpr (g < 12) { t_mask(std::integral_constant<int, 2 * (g - 8)>{}, cL, cR); t_mask(std::integral_constant<int, 2 * (g - 8) + 1>{}, cL, cR); }
-        else if constexpr (g < 14) { a_row(std::integral_constant<int, 2 * (g - 12)>{}); a_row(std::integral_constant<int, 2 * (g - 12) + 1>{}); }
-        else if constexpr (g == 16) { issue_loads(pn, nL, nR); }
-        else if constexpr (g >= 20 && g < 28) { t_col(std::integral_constant<int, 2 * (g - 20)>{}); t_col(std::integral_constant<int, 2 * (g - 20) + 1>{}); }
-        else if constexpr (g >= 28 && g < 32) { a_col(std::integral_constant<int, g - 28>{}); }
-        else if constexpr (g >= 32 && g < 48) { v_store(std::integral_constant<int, g - 32>{}, buf ^ 1); a_store(std::integral_constant<int, g - 32>{}, buf ^ 1); }
+        if constexpr (e == 0 && p == 14) frag_read(std::integral_constant<int, 15>{}, I1{}, buf);
+#ifndef T2O_WGW_NO_XFORM
+        static_for<kVpg * g, (kVpg * (g + 1) < kWork ? kVpg * (g + 1) : kWork)>([&](auto wc) { work(wc); });
+        if constexpr (g >= kLoadGap && g < kLoadGap + 20) { load_one(std::integral_constant<int, g - kLoadGap>{}, RS{}, cn); }
+        if constexpr (g >= kStoreGap && g < kStoreGap + 16) {
+          v_store(std::integral_constant<int, g - kStoreGap>{}, buf ^ 1);
+          a_store(std::integral_constant<int, g - kStoreGap>{}, buf ^ 1);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
+#ifdef T2O_WGW_DIAG
+      { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[p] += (unsigned)(tn - tprev); tprev = tn; }
+#endif
     });
-    cL = nL; cR = nR;
-    pl = pn;
+    mLs[0] = cn.mL; mRs[0] = cn.mR;
+  };
+  // (pairs, then the odd step: a conditional second step INSIDE the loop made the compiler shuffle the 256 accumulators through
+  // vector registers at the merge -- 284 v_accvgpr moves per step)
+  int s = s_begin;
+  for (; s + 1 < s_end; s += 2) {
+    step_body(I0{});
+    step_body(I1{});
   }
+  if (s < s_end) step_body(I0{});
+#ifdef T2O_WGW_DIAG
+  if (a.stamps && lane == 0) {          // per wave: [loop cycles, steps, planes 0..15]
+    unsigned long long* q = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 32;
+    q[0] = __builtin_amdgcn_s_memtime() - t_loop; q[1] = (unsigned long long)(s_end - s_begin);
+    for (int i = 0; i < 16; ++i) q[2 + i] = ph[i];
+  }
+#endif
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // (the last MFMA's 16 passes, before any accumulator is read)
 
   // ---- partial sums out: acc[xi][r] = dU[xi][co0 + 32 wm + (r & 3) + 8 (r >> 2) + 4 lh][ci0 + 32 wn + ln]
@@ -274,7 +346,8 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
 // part (S, E) -> sum (E), E = 16 * Co * Ci floats: a thread sums a group of S / kGroups consecutive splits of one float4 in
 // order, the groups meet in LDS and are added in order: fixed order whatever the launch geometry.
 constexpr int kRedGroups = 8, kRedQuads = 32;
-__global__ __launch_bounds__(256) void k_wgw_reduce(const float* __restrict__ part, float* __restrict__ sum, int S, size_t E4) {
+// Planes 3, 7, 11, 12, 13, 14 were accumulated with A dY A^T's sign flips left out (k_wino_wgrad: a_col): their sums change sign here.
+__global__ __launch_bounds__(256) void k_wgw_reduce(const float* __restrict__ part, float* __restrict__ sum, int S, size_t E4, size_t plane4) {
   __shared__ float4 sm[kRedGroups][kRedQuads];
   const int q = threadIdx.x % kRedQuads, g = threadIdx.x / kRedQuads;
   const size_t idx = (size_t)blockIdx.x * kRedQuads + q;
@@ -293,6 +366,8 @@ __global__ __launch_bounds__(256) void k_wgw_reduce(const float* __restrict__ pa
     float4 r = sm[0][q];
 #pragma unroll
     for (int k = 1; k < kRedGroups; ++k) { const float4 t = sm[k][q]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    const int xi = (int)(idx / plane4);
+    if ((0x7888 >> xi) & 1) { r.x = -r.x; r.y = -r.y; r.z = -r.z; r.w = -r.w; }       // bits 3, 7, 11, 12, 13, 14
     reinterpret_cast<float4*>(sum)[idx] = r;
   }
 }
@@ -347,7 +422,7 @@ int t2o_wino_fused_wgrad_nhwc(const float* x, const float* dy, float* dw, const 
   if (hipGetLastError() != hipSuccess) return set_error(T2O_ELAUNCH, "wino_fused_wgrad launch failed");
   const size_t E = (size_t)16 * Co * Ci, E4 = E / 4;
   float* sum = a.part + (size_t)a.splits * E;
-  k_wgw_reduce<<<(unsigned)((E4 + kRedQuads - 1) / kRedQuads), 256, 0, st>>>(a.part, sum, a.splits, E4);
+  k_wgw_reduce<<<(unsigned)((E4 + kRedQuads - 1) / kRedQuads), 256, 0, st>>>(a.part, sum, a.splits, E4, (size_t)Co * Ci / 4);
   if (hipGetLastError() != hipSuccess) return set_error(T2O_ELAUNCH, "wino_fused_wgrad reduce launch failed");
   return t2o_wino_dw_transform(sum, dw, Co, Ci, 1, accumulate, stream);
 }

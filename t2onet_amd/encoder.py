@@ -109,6 +109,15 @@ class TrunkPlan:
         return (_WINO_FUSED and _WINOGRAD and conv.stride[0] == 1 and not self.wino(conv, H, W) and w.shape[0] in (64, 128)
                 and w.shape[1] in (64, 128) and H % 16 == 0 and W % 16 == 0)
 
+    def onchip_wgrad(self, conv, H, W):
+        """The weight gradient of this layer in the Winograd domain with both transforms on chip (t2o_wino_wgrad.hip)?  Every
+        stride-1 layer the on-chip forward kernel runs (64 / 128 channels: fused_wino; 256 channels on maps that are multiples of
+        16: wino + the chunk-major filters) -- there the forward then forms no V and the backward no A dY A^T at all."""
+        w = conv.weight
+        return (_WINO_WGRAD and _WINO_FUSED and _WINOGRAD and conv.stride[0] == 1 and (self.fused_wino(conv, H, W) or self.wino(conv, H, W))
+                and bool(_lib.load().t2o_wino_fused_wgrad_supported(1, H, W, w.shape[1], w.shape[0]))
+                and bool(_lib.load().t2o_wino_fused_supported(1, H, W, w.shape[1], w.shape[0])))
+
     def fused_convs(self):
         return [c for b in self.blocks for c in (b.conv1, b.conv2)
                 if c.stride[0] == 1 and c.weight.shape[0] in (64, 128, 256, 512) and c.weight.shape[1] in (64, 128, 256, 512)] if (_WINO_FUSED and _WINOGRAD) else []
@@ -241,7 +250,7 @@ class WgradArena:
             dims[(i, 'a1')] = dims[(i, 'out')] = (Hn, Wn, Co)
             for conv, xkey, hi, wi in ((b.conv1, prev, Hc, Wc), (b.conv2, (i, 'a1'), Hn, Wn)):
                 st = conv.stride[0]
-                if plan.wino(conv, hi, wi):
+                if plan.wino(conv, hi, wi) and not plan.onchip_wgrad(conv, hi, wi):
                     # Winograd layer: the passes' transformed inputs V and output gradients A dY A^T side by side, one
                     # batch of 16 GEMMs over all their tiles + one back-transform per train step
                     Tpad = _lib.load().t2o_wino_padded_tiles(N, hi, wi)
@@ -324,7 +333,7 @@ class WgradArena:
                 x = self.x[xkey][first * N:(first + count) * N]
                 dy = self.dy[id(conv)][first * N:(first + count) * N]
                 n = count * N
-                if kind == '3x3' and _WINO_WGRAD and plan.fused_wino(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, w.grad, n, Hn, Wn, True):
+                if kind == '3x3' and plan.onchip_wgrad(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, w.grad, n, Hn, Wn, True):
                     continue                                   # Winograd domain, both transforms on chip: 16 of 36 multiplies
                 if kind == '3x3':
                     s = conv.stride[0]
@@ -403,6 +412,8 @@ class _TrunkFn(torch.autograd.Function):
             s = conv.stride[0]
             Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
             if plan.wino(conv, Hi, Wi):
+                if plan.onchip_wgrad(conv, Hi, Wi):            # forward, data and weight gradient all on chip: V is never formed
+                    return wino_fused_conv_nhwc(x, uf[('c', id(conv))], Nn, Hi, Wi, None, True)
                 keep = []
                 y, stats = wino_conv_nhwc(x, uf[id(conv)], Nn, Hi, Wi, None, True, keep_v=keep,
                                           v_out=arena.wino_slot('V', conv, apass) if apass is not None else None,
@@ -523,11 +534,11 @@ class _TrunkFn(torch.autograd.Function):
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             s = conv.stride[0]
+            if plan.onchip_wgrad(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, g(w), N, Hi, Wi, bool(acc)):
+                return
             if plan.wino(conv, Hi, Wi):
                 V = ctx.kept_v.pop(id(conv), None)
                 wino_wgrad_nhwc(V if V is not None else wino_input(x, N, Hi, Wi), dy, g(w), N, Hi, Wi, acc)
-                return
-            if _WINO_WGRAD and plan.fused_wino(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, g(w), N, Hi, Wi, bool(acc)):
                 return
             if Wn % 4 == 0 and (s == 1 or (Hi % 2 == 0 and Wi % 2 == 0)):
                 need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)
@@ -605,11 +616,11 @@ class _TrunkFn(torch.autograd.Function):
                 dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co, slot2)
             da1 = torch.empty_like(rec['a1'])
             rows1 = None                                   # bn1's backward sums, when conv2's data gradient leaves them
-            if plan.wino(b.conv2, Hn, Wn):
+            if plan.wino(b.conv2, Hn, Wn) and not plan.onchip_wgrad(b.conv2, Hn, Wn):
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
             else:
                 C2o, C2i = b.conv2.weight.shape[0], b.conv2.weight.shape[1]
-                fused2 = plan.fused_wino(b.conv2, Hn, Wn)
+                fused2 = plan.fused_wino(b.conv2, Hn, Wn) or plan.onchip_wgrad(b.conv2, Hn, Wn)
                 n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and _fast_direct(1, Hn, Wn, Wn) and not fused2) else 0
                 if fused2 and _BN_SUMS_EPILOGUE:
                     # the on-chip Winograd data gradient with bn1's backward sums in its epilogue
@@ -642,7 +653,7 @@ class _TrunkFn(torch.autograd.Function):
                 dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co, slot1)
             del da1
             dx = torch.empty_like(rec['x'])
-            if plan.wino(b.conv1, Hc, Wc) and not len(b.shortcut):
+            if plan.wino(b.conv1, Hc, Wc) and not len(b.shortcut) and not plan.onchip_wgrad(b.conv1, Hc, Wc):
                 wino_bwd(b.conv1, rec['x'], dy1, dx, dsc, Hc, Wc)
                 d = dx
                 continue
