@@ -241,8 +241,8 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   // chunks again, into buffers nobody reads any more.  Measured (tools/diag/wf_clock.hip): a wave's 64 MFMAs take their 4,096
   // pipe cycles whatever else happens, and everything issued OUTSIDE them is added time (first version: 877 cycles of DMA issue
   // and loads + 551 of transform per chunk) -- so every other instruction sits BETWEEN two MFMAs of this wave, pinned there:
-  //   behind the barrier (before pair 7): the NEXT transform's 16 loads; pair 1: this one's 16 row steps; pair 2: its 16 column
-  //   steps; pair 3: its 16 stores;
+  //   behind the barrier (before pair 7): the NEXT transform's 16 loads; pair 1's first two gaps: this one's 16 row and 16 column
+  //   steps (bunched: see below); pair 3: its 16 stores;
   //   pairs 0, 5, 6: the 11 DMA pieces, one per second gap; every pair's fragments are requested one pair ahead.
   auto chunk_body = [&](int kBuf, int c) {              // (kBuf as a run-time value: unrolled by two with constant buffers the
                                                         // register allocation spilled 86 values)
@@ -274,12 +274,20 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
           dma_u_piece(mc, uoff, ulds);
         } else if constexpr (k == 4 && (m & 1) == 0 && m < 6) {
           x_piece(std::integral_constant<int, m / 2>{}, kBuf, adv);
-        } else if constexpr (k == 1) {
-          t_row(std::integral_constant<int, 2 * m>{});
-          t_row(std::integral_constant<int, 2 * m + 1>{});
-        } else if constexpr (k == 2) {
-          t_col(std::integral_constant<int, 2 * m>{});
-          t_col(std::integral_constant<int, 2 * m + 1>{});
+#ifndef T2O_WF_VPG
+#define T2O_WF_VPG 16
+#endif
+        } else if constexpr (k == 1 || k == 2) {
+          // the 32 transform statements T2O_WF_VPG per gap from pair 1's first gap on: a gap that holds vector instructions costs
+          // ~20 cycles whatever their number plus 7-10 per instruction (measured on k_wino_wgrad, tools/diag/wgw_clock.hip).  Cycles
+          // per chunk at 64 / 128 channels (tools/diag/wf_variants.sh): two per gap 5,570 / 5,415; four 5,438 / 5,290; eight 5,381 /
+          // 5,218; sixteen 5,363 / 5,198; all in one 5,361 / 5,202
+          constexpr int g = 8 * (k - 1) + m, lo = T2O_WF_VPG * g, hi = T2O_WF_VPG * (g + 1) < 32 ? T2O_WF_VPG * (g + 1) : 32;
+          static_for<lo, hi>([&](auto wc) {
+            constexpr int w = decltype(wc)::value;
+            if constexpr (w < 16) t_row(std::integral_constant<int, w>{});
+            else t_col(std::integral_constant<int, w - 16>{});
+          });
         } else if constexpr (k == 3) {
           t_store(std::integral_constant<int, 2 * m>{}, kBuf ^ 1);
           t_store(std::integral_constant<int, 2 * m + 1>{}, kBuf ^ 1);
