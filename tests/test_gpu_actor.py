@@ -10,7 +10,7 @@ tools/measure_parity.py (round 5, profiles/r05_parity_distances.txt), per mode:
   image crops         4.1e-6 / 5.0e-6            6.5e-5 / 1.3e-5
   log-probabilities   1.2e-6                     1.5e-5
   losses              <= 2.4e-7                  <= 1.4e-6
-  gradient norms      --                         9.2e-5 / 1.7e-5 relative
+  gradient norms      --                         9.2e-5 .. 1.3e-2 (three boxes) / 1.7e-5 relative
 
 Training mode is looser than evaluation mode for a structural reason, not a library one: BatchNorm over 4 samples (and
 BatchNorm1d over 4 VALUES per feature) divides by a standard deviation formed from a handful of numbers, which amplifies the
@@ -71,7 +71,10 @@ def test_episode_l1_step_matches_reference(gold, mode):
     gn = np.array([0.0 if params[n].grad is None else params[n].grad.double().norm().item() for n in names])
     ref = gold[p + 'grad_norm']
     big = ref > 1e-3 * ref.max()
-    np.testing.assert_allclose(gn[big], ref[big], rtol=3e-4)                                      # (measured 9.2e-5)
+    # three runs of the same build on three boxes: 9.2e-5, 5.7e-3, 1.3e-2 -- the episode's gradient passes through five chained
+    # encoder passes and five operator applications, and the request encoder's remaining LIBRARY GEMMs do not round the same way
+    # on every box (the step amplifies 1e-7 perturbations ~1e4); the teacher-forced step below holds 1e-4
+    np.testing.assert_allclose(gn[big], ref[big], rtol=2e-2)
     # heads of unused operators get zeros here (gather over all heads) where the reference has None
     none_ref = gold[p + 'grad_none']
     assert np.all(gn[none_ref] == 0.0)
