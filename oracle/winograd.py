@@ -77,3 +77,67 @@ def direct_conv(x, w):
         for kw in range(3):
             y += np.einsum('nhwc,oc->nhwo', xp[:, kh:kh + H, kw:kw + W], w[:, kh, kw].astype(np.float64))
     return y
+
+
+# planes of A dY A^T that carry a minus sign (k_wino_dy: -r1 of rows 0..2; row 3 = -d1 except its own -r1): k_wino_wgrad accumulates
+# them un-negated and k_wgw_reduce flips the sign of their sums
+NEGATED_PLANES = (3, 7, 11, 12, 13, 14)
+
+
+def weight_gradient_onchip_form(x, dy, splits=3):
+    """dw (Co,3,3,Ci) the way t2onet_amd/csrc/t2o_wino_wgrad.hip forms it (fp64; the structure, not the rounding):
+      * the tile index is walked in STEPS of 8 tiles -- (image, tile row ty, segment sx of 8 tiles = 16 pixels) -- cut into `splits`
+        contiguous ranges whose partial sums are added in order;
+      * patch rows outside the image are zero rows; patch COLUMNS outside it (column 0 of the first tile at the left edge, column 3
+        of the last tile at the right edge) are read from the neighbouring valid column and enter the column step multiplied by 0:
+        tv[i][0] = tr[i][0] * mL - tr[i][2], tv[i][3] = tr[i][1] - tr[i][3] * mR;
+      * A dY A^T is formed WITHOUT its sign flips -- rows (d0, d0 + d1, d0 - d1, d1), per row (r0, r0 + r1, r0 - r1, r1) -- and the
+        sums of the planes in NEGATED_PLANES change sign at the end;
+      * G^T dU G closes.
+    x (N,H,W,Ci), dy (N,H,W,Co), H and W multiples of 16."""
+    x, dy = x.astype(np.float64), dy.astype(np.float64)
+    N, H, W, Ci = x.shape
+    Co = dy.shape[3]
+    assert H % 16 == 0 and W % 16 == 0
+    TH, SEG = H // 2, W // 16
+    steps = [(n, ty, sx) for n in range(N) for ty in range(TH) for sx in range(SEG)]
+    parts = []
+    for sp in range(splits):
+        dU = np.zeros((16, Co, Ci))
+        for (n, ty, sx) in steps[len(steps) * sp // splits:len(steps) * (sp + 1) // splits]:
+            for tx in range(8):
+                w0 = 16 * sx + 2 * tx - 1                      # column of patch column 0
+                d = np.zeros((4, 4, Ci))
+                edge_l, edge_r = (sx == 0 and tx == 0), (sx == SEG - 1 and tx == 7)
+                for i in range(4):
+                    h = 2 * ty - 1 + i
+                    if not 0 <= h < H:
+                        continue                                # (the zero block)
+                    for j in range(4):
+                        w = w0 + j
+                        if j == 0 and edge_l:
+                            w = w0 + 1                          # clamped: a valid neighbour, masked below
+                        if j == 3 and edge_r:
+                            w = w0 + 2
+                        d[i, j] = x[n, h, w]
+                m_l, m_r = (0.0 if edge_l else 1.0), (0.0 if edge_r else 1.0)
+                tr = np.stack([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]])            # rows of B^T d: tr[r][j]
+                tv = np.empty((4, 4, Ci))
+                for i in range(4):
+                    tv[i, 0] = tr[i, 0] * m_l - tr[i, 2]
+                    tv[i, 1] = tr[i, 1] + tr[i, 2]
+                    tv[i, 2] = tr[i, 2] - tr[i, 1]
+                    tv[i, 3] = tr[i, 1] - tr[i, 3] * m_r
+                g = dy[n, 2 * ty:2 * ty + 2, 16 * sx + 2 * tx:16 * sx + 2 * tx + 2]            # (2, 2, Co)
+                rows = [g[0], g[0] + g[1], g[0] - g[1], g[1]]                                  # each (2, Co): columns 0, 1
+                av = np.empty((4, 4, Co))
+                for i in range(4):
+                    av[i, 0], av[i, 1], av[i, 2], av[i, 3] = rows[i][0], rows[i][0] + rows[i][1], rows[i][0] - rows[i][1], rows[i][1]
+                dU += np.einsum('xo,xc->xoc', av.reshape(16, Co), tv.reshape(16, Ci))
+        parts.append(dU)
+    total = parts[0].copy()
+    for p in parts[1:]:
+        total += p
+    for xi in NEGATED_PLANES:
+        total[xi] = -total[xi]
+    return np.einsum('ai,aboc,bj->oijc', G, total.reshape(4, 4, Co, Ci), G)

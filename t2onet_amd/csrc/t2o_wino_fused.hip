@@ -305,6 +305,8 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   };
 
   // ---- pipeline: DMA x(c + 2), U(c + 1) | transform(c + 1) | MFMA(c), one barrier per chunk
+  // (chunk 1 is requested BEHIND the first barrier, under the transform of chunk 0: requested together with chunk 0 -- one round
+  // trip in front of the loop instead of two -- the prologue took 5,890 cycles instead of 5,200: three DMA batches in one queue)
   dma_chunk(0, chunks > 1 ? 32 : 0);
   dma_u(0, 0);
   vm_wait0();

@@ -38,3 +38,27 @@ def test_weight_gradient_in_the_transformed_domain():
     (torch.nn.functional.conv2d(torch.from_numpy(xn).double().permute(0, 3, 1, 2), w, None, 1, 1) * torch.from_numpy(dy).double().permute(0, 3, 1, 2)).sum().backward()
     dw = winograd.weight_gradient(xn, dy)
     np.testing.assert_allclose(dw, w.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('shape', [(1, 16, 16, 3, 2), (2, 16, 32, 2, 3), (1, 32, 16, 2, 2)])
+def test_weight_gradient_the_way_the_on_chip_kernel_forms_it(shape):
+    """t2o_wino_wgrad.hip's formulation restated in numpy (steps of 8 tiles, zero rows, clamped + masked edge columns inside the
+    column step's multiply-add, A dY A^T without its sign flips and the six planes' sums negated at the end, split ranges added
+    in order) against the plain transformed-domain weight gradient and the direct one: the algebra of the kernel's shortcuts is
+    exact."""
+    N, H, W, Ci, Co = shape
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (N, H, W, Ci))
+    dy = rng.uniform(-1, 1, (N, H, W, Co))
+    wg = winograd
+    ref = wg.weight_gradient(x, dy)
+    for splits in (1, 3):
+        got = wg.weight_gradient_onchip_form(x, dy, splits)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    # and the reference form itself is the gradient of the direct convolution (finite difference on one weight)
+    w = rng.uniform(-1, 1, (Co, 3, 3, Ci))
+    e = np.zeros_like(w)
+    e[1, 2, 0, 1] = 1.0
+    fd = ((wg.direct_conv(x, w + 1e-6 * e) - wg.direct_conv(x, w - 1e-6 * e)) * dy).sum() / 2e-6
+    assert abs(fd - ref[1, 2, 0, 1]) < 1e-6 * max(1.0, abs(fd))
+    assert wg.NEGATED_PLANES == (3, 7, 11, 12, 13, 14)
