@@ -513,7 +513,9 @@ def test_trainer_with_graphed_encoder_matches_eager():
         # the episode samples operators: same seed, same draws (encoder graphs consume no random numbers)
         assert abs(e0 - e1) < 1e-5
         # (3e-3: with encoder graphs the feature head runs as fc + BatchNorm1d modules, eagerly as the fused kernel -- two fp32
-        # roundings of the same values, amplified through five chained encoder passes: measured 1.5e-3 on 5 of 22 M entries)
+        # roundings of the same values, amplified through five chained encoder passes: measured 1.5e-3 on 5 of 22 M entries.
+        # This end-to-end bound is not the feature head's only guard: tests/test_gpu_decoder.py::test_feature_head_matches_fp64
+        # holds the fused kernel to 3e-6 (values) / 3e-5 (gradients) of the fc + bn1 + relu MODULES in fp64 -- ADVICE r4)
         np.testing.assert_allclose(ge1.cpu().numpy(), ge0.cpu().numpy(), rtol=0, atol=3e-3 * float(ge0.abs().max()))
 
 
