@@ -270,10 +270,16 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
         mfma_one(std::integral_constant<int, 2 * k>{}, std::integral_constant<int, k & 1>{}, mc);
         __builtin_amdgcn_sched_barrier(0);
         // the 11 DMA pieces one per second MFMA gap (back to back they cost ~50 cycles each beyond the MFMA they hide behind)
+#ifndef T2O_WF_XPAIR
+#define T2O_WF_XPAIR 1
+#endif
+        // the 3 x pieces of chunk c + 2 (into Xs[kBuf], free since the barrier of chunk c - 1) in gaps 2, 4, 6 of pair T2O_WF_XPAIR:
+        // the barrier in front of pair 7 waits for them -- requested in pair 4 they had ~1,600 cycles to arrive
+        if constexpr (k == T2O_WF_XPAIR && (m & 1) == 0 && m >= 2) {
+          x_piece(std::integral_constant<int, (m - 2) / 2>{}, kBuf, adv);
+        }
         if constexpr (k == 0) {
           dma_u_piece(mc, uoff, ulds);
-        } else if constexpr (k == 4 && (m & 1) == 0 && m < 6) {
-          x_piece(std::integral_constant<int, m / 2>{}, kBuf, adv);
 #ifndef T2O_WF_VPG
 #define T2O_WF_VPG 16
 #endif
