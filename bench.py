@@ -843,6 +843,38 @@ def conv_kernel_table(B, H, W, device, reps=40):
                 'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2), 'effective': True,
                 'executed_GFLOP': round(flop * 16.0 / 36.0 / 1e9, 3), 'executed_TFLOPs': round(flop * 16.0 / 36.0 / ms / 1e9, 2),
                 'kernel': 'k_wino_fused'}
+    # the weight gradient of the same layers: Winograd domain, both transforms on chip (round 5), over the five encoder passes of a
+    # train step side by side (encoder.WgradArena) -- against the direct kernel it replaced, same operands
+    P5 = 5
+    for C, div in ((64, 4), (128, 8), (256, 16)):
+        h, w = H // div, W // div
+        if not lib.t2o_wino_fused_wgrad_supported(P5 * B, h, w, C, C):
+            continue
+        x = torch.rand(P5 * B, h, w, C, generator=g).to(device) - 0.5
+        dy = torch.rand(P5 * B, h, w, C, generator=g).to(device) - 0.5
+        dw = torch.zeros(C, 3, 3, C, device=device)
+        flop = 2.0 * 9 * C * C * P5 * B * h * w
+        need = lib.t2o_conv3x3_wgrad_workspace_bytes(P5 * B, h, w, C, C)
+        wsd = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+        cands = [('onchip_wino_wgrad', lambda: T.wino_fused_wgrad_nhwc(x, dy, dw, P5 * B, h, w, True), 'k_wino_wgrad + k_wgw_reduce + k_wino_dw', 16.0 / 36.0)]
+        if need > 0:
+            cands.append(('direct_wgrad', lambda: _lib.check(lib.t2o_conv3x3_wgrad_acc_nhwc(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), wsd.data_ptr(), need,
+                                                                                           P5 * B, h, w, C, C, 1, 1, st), 'direct wgrad'),
+                          'k_conv3x3_wgrad + k_conv_wgrad_reduce', 1.0))
+        for name, fn, kern, frac_exec in cands:
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(6):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 6
+            rows['%s_c%d_%dx%d_x%dpasses' % (name, C, h, w, P5)] = {
+                'ms': round(ms, 5), 'GFLOP': round(flop / 1e9, 3), 'TFLOPs': round(flop / ms / 1e9, 2), 'effective': frac_exec < 1.0,
+                'executed_GFLOP': round(flop * frac_exec / 1e9, 3), 'executed_TFLOPs': round(flop * frac_exec / ms / 1e9, 2), 'kernel': kern}
+        del x, dy, dw, wsd
     dom = [v for k, v in rows.items() if v['kernel'] == 'k_wino_fused' and '_addend' not in k]
     if not dom:                                             # (an image size the on-chip kernel does not take: the direct kernel runs)
         dom = [v for k, v in rows.items() if v['kernel'] == 'k_conv3x3_fwd<2,1>' and ('_c64_' in k or '_c128_' in k)]

@@ -21,7 +21,7 @@ if r and 'kernel' in r:
 elif r:
     print('roofline:', r)
 for k, v in (d.get('conv_kernels') or {}).items():
-    print('      %-22s %8.2f us  %6.1f TF/s  %s' % (k, v['ms'] * 1e3, v['TFLOPs'], v['kernel']))
+    print('      %-40s %8.2f us  %6.1f TF/s  %s' % (k, v['ms'] * 1e3, v['TFLOPs'], v['kernel']))
 r = d.get('executor_roofline')
 if r:
     print('executor_roofline: %s %.0f GB/s moved, frac %.3f (credited %.3f) traffic %s' % (r['kernel'], r['achieved'], r['frac'], r['credited_frac'], r['traffic']))
