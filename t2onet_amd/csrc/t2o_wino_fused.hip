@@ -83,6 +83,10 @@ __device__ __forceinline__ void vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void mfma_asm(f32x16& c, float a, float b) {
   asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// ... the first product of an accumulator block: C = 0 as an inline constant instead of 256 v_accvgpr_write per workgroup
+__device__ __forceinline__ void mfma_asm_first(f32x16& c, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
 template <int kFirst, int kLast, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (kFirst < kLast) {
@@ -205,11 +209,7 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   };
   auto dma_u = [&](int cc, int buf) { static_for<0, 8>([&](auto jc) { dma_u_piece(jc, (size_t)cc * uchunk, lds_u_wave + (unsigned)(buf * kUBuf)); }); };
 
-  f32x16 acc[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+  f32x16 acc[16];                                         // (not cleared: chunk 0's first product of every block writes C = 0)
 
   float4 fa[2][2], fb[2][2];                              // fragments of a plane pair, double-buffered across pairs
 #ifdef T2O_WF_DIAG
@@ -224,11 +224,12 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     fb[slot][1] = *reinterpret_cast<const float4*>(&Us[buf][0] + (p + 1) * 2048 + boff);
   };
   // MFMA m (0..7) of a plane pair: component m >> 1 of the fragments, plane p + (m & 1)
-  auto mfma_one = [&](auto pc, auto slotc, auto mc) {
+  auto mfma_one = [&](auto pc, auto slotc, auto mc, auto firstc) {
     constexpr int p = decltype(pc)::value, slot = decltype(slotc)::value, m = decltype(mc)::value, w = m & 1, e = m >> 1;
     const float av = e == 0 ? fa[slot][w].x : e == 1 ? fa[slot][w].y : e == 2 ? fa[slot][w].z : fa[slot][w].w;
     const float bv = e == 0 ? fb[slot][w].x : e == 1 ? fb[slot][w].y : e == 2 ? fb[slot][w].z : fb[slot][w].w;
-    mfma_asm(acc[p + w], av, bv);
+    if constexpr (decltype(firstc)::value && e == 0) mfma_asm_first(acc[p + w], av, bv);     // (chunk 0: the block's first product)
+    else mfma_asm(acc[p + w], av, bv);
   };
   auto x_piece = [&](auto kc, int buf, int adv) {
     constexpr int k = decltype(kc)::value;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   //   behind the barrier (before pair 7): the NEXT transform's 16 loads; pair 1's first two gaps: this one's 16 row and 16 column
   //   steps (bunched: see below); pair 3: its 16 stores;
   //   pairs 0, 5, 6: the 11 DMA pieces, one per second gap; every pair's fragments are requested one pair ahead.
-  auto chunk_body = [&](int kBuf, int c) {              // (kBuf as a run-time value: unrolled by two with constant buffers the
+  auto chunk_body = [&](int kBuf, int c, auto firstc) {  // (kBuf as a run-time value: unrolled by two with constant buffers the
                                                         // register allocation spilled 86 values)
 #ifdef T2O_WF_DIAG
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
       }
       static_for<0, 8>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        mfma_one(std::integral_constant<int, 2 * k>{}, std::integral_constant<int, k & 1>{}, mc);
+        mfma_one(std::integral_constant<int, 2 * k>{}, std::integral_constant<int, k & 1>{}, mc, firstc);
         __builtin_amdgcn_sched_barrier(0);
         // the 11 DMA pieces one per second MFMA gap (back to back they cost ~50 cycles each beyond the MFMA they hide behind)
 #ifndef T2O_WF_XPAIR
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     const int t = 32 * th + (r & 3) + 8 * (r >> 2) + 4 * lh;
     return (((size_t)n * a.H + by * 16 + 2 * (t >> 3)) * a.W + bx * 16 + 2 * (t & 7)) * a.Co + co0 + 32 * ch + ln;
   };
-  for (int c = 0; c < chunks; ++c) chunk_body(c & 1, c);
+  chunk_body(0, 0, std::true_type{});
+  for (int c = 1; c < chunks; ++c) chunk_body(c & 1, c, std::false_type{});
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // (the last MFMA's 16 passes, before any accumulator is read)
 #ifdef T2O_WF_DIAG
   const unsigned long long t_end = __builtin_amdgcn_s_memtime();

@@ -5,6 +5,7 @@
 #   test[:<pytest args>]  pytest -m gpu (default: all of tests/)        smoke        __graft_entry__.smoke()
 #   bench                 default bench.py (+ bench_detail.json)         benchprof    rocprofv3 --kernel-trace --stats of the same command
 #   step[:<graph 0|1>]    rocprofv3 kernel stats + trace gaps of the train step alone (tools/step_only.py)
+#   seq                   ordered kernel list of one train step (tools/step_sequence.py)
 #   hip                   rocprofv3 --hip-trace --stats of the eager step
 #   ab:"ENV=a|ENV=b"      un-profiled A/B of the train step under the given environments ('|' separated, '' = defaults)
 #   egraph                eager vs whole-step hipGraph, alternating
@@ -47,6 +48,13 @@ for stage in "$@"; do
       python tools/trace_gaps.py $f 0.4 > $OUT/step_trace_gaps_$mode.txt 2>&1
       find $OUT/prof$mode -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $OUT/step_kernel_stats_$mode.csv
       rm -rf $OUT/prof$mode; tail -n 1 $OUT/step_only_$mode.log; head -n 24 $OUT/step_kernel_stats_$mode.csv | cut -c1-160 ;;
+    seq)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/profseq -- python $ROOT/tools/step_only.py 6 0 0 > $ROOT/$OUT/step_only_seq.log 2>&1; echo "rc=$?"
+      cd $ROOT
+      f=$(find $OUT/profseq -name "*kernel_trace.csv" | head -1)
+      python tools/step_sequence.py $f > $OUT/step_sequence.txt 2>&1
+      rm -rf $OUT/profseq; wc -l $OUT/step_sequence.txt ;;
     hip)
       cd /tmp
       timeout 600 rocprofv3 --hip-trace --stats --output-format csv -d $ROOT/$OUT/hip -- python $ROOT/tools/step_only.py 10 0 0 > $ROOT/$OUT/step_only_hip.log 2>&1
