@@ -87,6 +87,11 @@ __device__ __forceinline__ void mfma_asm(f32x16& c, float a, float b) {
 __device__ __forceinline__ void mfma_asm_first(f32x16& c, float a, float b) {
   asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b) {           // a - b on both halves, one instruction
+  v2f d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 template <int kFirst, int kLast, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (kFirst < kLast) {
@@ -328,27 +333,34 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
 #ifdef T2O_WF_DIAG
   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
-  // offset of output pixel (2 ty, 2 tx) of register r's tile, channel of this lane
-  auto out_off = [&](int r) {
-    const int t = 32 * th + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    return (((size_t)n * a.H + by * 16 + 2 * (t >> 3)) * a.W + bx * 16 + 2 * (t & 7)) * a.Co + co0 + 32 * ch + ln;
-  };
   chunk_body(0, 0, std::true_type{});
   for (int c = 1; c < chunks; ++c) chunk_body(c & 1, c, std::false_type{});
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // (the last MFMA's 16 passes, before any accumulator is read)
 #ifdef T2O_WF_DIAG
   const unsigned long long t_end = __builtin_amdgcn_s_memtime();
 #endif
+  // Output addressing: everything but the lane's own (tile column half, channel) is uniform -- a scalar byte offset per (r, i, j)
+  // plus ONE 32-bit lane offset, i.e. scalar-base loads / stores (as 64-bit per-lane offsets the 64 stores and 64 epilogue loads
+  // cost 134 + 134 vector instructions of address arithmetic per workgroup)
+  typedef __attribute__((address_space(1))) char* gbytes;
+  typedef __attribute__((address_space(1))) const char* gcbytes;
+  const unsigned lane_off = (unsigned)(lh * 32 * a.Co + ln * 4);        // tile columns 4 lh .. (8 pixels), channel ln
+  const size_t rowb = (size_t)a.W * a.Co * 4, colb = (size_t)a.Co * 4;
+  auto sbyte = [&](int r) {                               // pixel (2 ty, 2 tx) of register r's tile for lh = 0, channel co0 + 32 ch
+    return ((((size_t)n * a.H + by * 16 + 8 * th + 2 * (r >> 2)) * a.W + bx * 16 + 2 * (r & 3)) * a.Co + co0 + 32 * ch) * 4;
+  };
   // the epilogue operand: all 64 loads of the lane at once (one round trip; fetched under the last chunk's MFMAs they would
   // not fit -- the loop leaves ~50 of the 256 non-accumulator registers free, 64 more spilled 130 values)
   float pre[kEpi ? 16 : 1][4];
   if constexpr (kEpi != 0) {
-    const float* __restrict__ src = kAdd ? a.addend : a.bn_x;
-    const size_t rowstep = (size_t)a.W * a.Co;
+    const gcbytes src = (gcbytes)(kAdd ? a.addend : a.bn_x);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const size_t off = out_off(r);
-      pre[r][0] = src[off]; pre[r][1] = src[off + a.Co]; pre[r][2] = src[off + rowstep]; pre[r][3] = src[off + rowstep + a.Co];
+      const gcbytes sb = src + sbyte(r);
+      pre[r][0] = *reinterpret_cast<__attribute__((address_space(1))) const float*>(sb + lane_off);
+      pre[r][1] = *reinterpret_cast<__attribute__((address_space(1))) const float*>(sb + colb + lane_off);
+      pre[r][2] = *reinterpret_cast<__attribute__((address_space(1))) const float*>(sb + rowb + lane_off);
+      pre[r][3] = *reinterpret_cast<__attribute__((address_space(1))) const float*>(sb + rowb + colb + lane_off);
     }
     __builtin_amdgcn_sched_barrier(0);                    // (all requested before the first is waited for)
   }
@@ -362,36 +374,48 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     bmean = a.bn_mean[co]; binv = a.bn_invstd[co];
     bsc = a.bn_w[co] * binv; bsh = a.bn_b[co] - bmean * bsc;
   }
+  // (registers r, r + 1 side by side: the transform's 24 additions per register are v_pk_add_f32 on the pair -- the same
+  // arithmetic element by element; stores and statistics stay in the order r, i)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float m[4][4];
+  for (int r2 = 0; r2 < 8; ++r2) {
+    v2f m[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) m[i][j] = acc[4 * i + j][r];
-    float q[2][4];
+      for (int j = 0; j < 4; ++j) m[i][j] = (v2f){acc[4 * i + j][2 * r2], acc[4 * i + j][2 * r2 + 1]};
+    v2f q[2][4], o0p[2], o1p[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       q[0][j] = (m[0][j] + m[1][j]) + m[2][j];
-      q[1][j] = (m[1][j] - m[2][j]) - m[3][j];
+      // (the subtractions as explicit v_pk_add_f32 with a negated source: written as vector a - b, a + (-b) or fma(b, -1, a)
+      // the compiler split them into scalar v_sub_f32 again)
+      q[1][j] = pk_sub(pk_sub(m[1][j], m[2][j]), m[3][j]);
     }
-    const size_t off0 = out_off(r);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      float o0 = (q[i][0] + q[i][1]) + q[i][2];
-      float o1 = (q[i][1] - q[i][2]) - q[i][3];
-      const size_t off = off0 + (size_t)i * a.W * a.Co;
-      if constexpr (kAdd) { o0 += pre[r][2 * i]; o1 += pre[r][2 * i + 1]; }
-      a.y[off] = o0;
-      a.y[off + a.Co] = o1;
-      if constexpr (kBnb) {
-        const float x0 = pre[r][2 * i], x1 = pre[r][2 * i + 1];
-        const float g0 = (x0 * bsc + bsh > 0.0f) ? o0 : 0.0f, g1 = (x1 * bsc + bsh > 0.0f) ? o1 : 0.0f;
-        s1 += g0 + g1;
-        s2 += g0 * ((x0 - bmean) * binv) + g1 * ((x1 - bmean) * binv);
-      } else {
-        s1 += o0 + o1;
-        s2 += o0 * o0 + o1 * o1;
+      o0p[i] = (q[i][0] + q[i][1]) + q[i][2];
+      o1p[i] = pk_sub(pk_sub(q[i][1], q[i][2]), q[i][3]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * r2 + rr;
+      const gbytes yb = (gbytes)a.y + sbyte(r);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float o0 = rr == 0 ? o0p[i].x : o0p[i].y;
+        float o1 = rr == 0 ? o1p[i].x : o1p[i].y;
+        if constexpr (kAdd) { o0 += pre[r][2 * i]; o1 += pre[r][2 * i + 1]; }
+        *reinterpret_cast<__attribute__((address_space(1))) float*>(yb + (size_t)i * rowb + lane_off) = o0;
+        *reinterpret_cast<__attribute__((address_space(1))) float*>(yb + (size_t)i * rowb + colb + lane_off) = o1;
+        if constexpr (kBnb) {
+          const float x0 = pre[r][2 * i], x1 = pre[r][2 * i + 1];
+          const float g0 = (x0 * bsc + bsh > 0.0f) ? o0 : 0.0f, g1 = (x1 * bsc + bsh > 0.0f) ? o1 : 0.0f;
+          s1 += g0 + g1;
+          s2 += g0 * ((x0 - bmean) * binv) + g1 * ((x1 - bmean) * binv);
+        } else {
+          s1 += o0 + o1;
+          s2 += o0 * o0 + o1 * o1;
+        }
       }
     }
   }
