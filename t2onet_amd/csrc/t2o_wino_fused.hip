@@ -111,6 +111,9 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   __shared__ __attribute__((aligned(16))) char Us[2][kUBuf];
 
   // workgroup -> (pixel block, channel tile): the channel tiles of one block are neighbours inside an XCD
+#ifdef T2O_WF_DIAG
+  const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int b = blockIdx.x;
   const int xcd = b % 8, k8 = b / 8;
   const int blk = (k8 / a.tiles_n) * 8 + xcd, ct = k8 % a.tiles_n;
@@ -317,13 +320,15 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   };
 
   // ---- pipeline: DMA x(c + 2), U(c + 1) | transform(c + 1) | MFMA(c), one barrier per chunk
-  // (chunk 1 is requested BEHIND the first barrier, under the transform of chunk 0: requested together with chunk 0 -- one round
-  // trip in front of the loop instead of two -- the prologue took 5,890 cycles instead of 5,200: three DMA batches in one queue)
+  // x chunk 0, U chunk 0 and x chunk 1 are requested together, but the first barrier waits only for the first two (a wave's DMA
+  // pieces complete in order: all but the 3 newest): chunk 1 travels under the transform of chunk 0 AND has a round trip's head
+  // start.  (Requested together and all waited for at once the prologue took 5,890 cycles instead of 5,200; requested behind the
+  // first barrier -- the round-4 form -- it is waited for a second full round trip.)
   dma_chunk(0, chunks > 1 ? 32 : 0);
   dma_u(0, 0);
-  vm_wait0();
-  __syncthreads();
   dma_chunk(1, chunks > 2 ? 32 : 0);                      // (a one-chunk layer: the same chunk again, never used)
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   transform_all(0, 0);
   vm_wait0();
   __syncthreads();
@@ -331,13 +336,13 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   frag_read(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, 0);
   static_for<0, 16>([&](auto jc) { t_load(jc, 1); });
 #ifdef T2O_WF_DIAG
-  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime(), r_loop = __builtin_amdgcn_s_memrealtime();
 #endif
   chunk_body(0, 0, std::true_type{});
   for (int c = 1; c < chunks; ++c) chunk_body(c & 1, c, std::false_type{});
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // (the last MFMA's 16 passes, before any accumulator is read)
 #ifdef T2O_WF_DIAG
-  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
 #endif
   // Output addressing: everything but the lane's own (tile column half, channel) is uniform -- a scalar byte offset per (r, i, j)
   // plus ONE 32-bit lane offset, i.e. scalar-base loads / stores (as 64-bit per-lane offsets the 64 stores and 64 epilogue loads
@@ -437,6 +442,8 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
     unsigned long long* q = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
     q[0] = t_loop - t_start; q[1] = t_end - t_loop; q[2] = __builtin_amdgcn_s_memtime() - t_end;
     for (int i = 0; i < 9; ++i) q[3 + i] = ph[i];
+    q[12] = r_entry; q[13] = __builtin_amdgcn_s_memrealtime();     // (100 MHz, one counter for the chip)
+    q[14] = r_loop; q[15] = r_end;
   }
 #endif
 }

@@ -48,5 +48,19 @@ int main(int argc, char** argv) {
   const char* what[8] = {"8 U pieces", "transform rows", "transform columns", "transform stores", "3 x pieces", "-", "-", "barrier, reads"};
   for (int k = 0; k < 8; ++k) printf("  plane pair %d (8 MFMAs = 512 cycles) + %-18s %6.0f cycles per chunk\n", k, what[k], med(v[3 + k]) / chunks);
   printf("  wait for the DMA + barrier %6.0f cycles per chunk\n", med(v[11]) / chunks);
+  {   // workgroup lifetimes on the chip-wide 100 MHz clock: entry of its first instruction .. its last stamp; and the whole launch
+    std::vector<double> life, mhz, pre; unsigned long long lo = ~0ull, hi = 0;
+    for (size_t i = 0; i < (size_t)grid * 4; ++i) {
+      if (!s[i * 16 + 1] || !s[i * 16 + 13]) continue;
+      life.push_back((double)(s[i * 16 + 13] - s[i * 16 + 12]) * 0.01);
+      if (s[i * 16 + 15] > s[i * 16 + 14]) mhz.push_back((double)s[i * 16 + 1] / ((double)(s[i * 16 + 15] - s[i * 16 + 14]) * 0.01));
+      pre.push_back((double)(s[i * 16 + 14] - s[i * 16 + 12]) * 0.01);
+      lo = std::min(lo, s[i * 16 + 12]); hi = std::max(hi, s[i * 16 + 13]);
+    }
+    const double rounds = (double)grid / 256.0;
+    printf("  shader clock over the loop: %.0f MHz; entry .. loop start %.2f us\n", med(mhz), med(pre));
+    printf("  wave lifetime (entry .. last stamp): median %.2f us; first entry .. last exit %.1f us = %.2f us per round of 256 workgroups\n",
+           med(life), (double)(hi - lo) * 0.01, (double)(hi - lo) * 0.01 / rounds);
+  }
   return 0;
 }
