@@ -44,7 +44,7 @@ js = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools
       'kernels': {a: ks for a, ks in alias.items() if ks}}
 per_launch = {}
 for k, d in full.items():
-    if k.startswith('k_conv3x3') or k.startswith('k_wino_fused'):
+    if k.startswith('k_conv3x3') or k.startswith('k_wino_fused') or k.startswith('k_wino_wgrad'):
         fe = sum(d.get('FETCH_SIZE', [0])) / max(len(d.get('FETCH_SIZE', [0])), 1) * 1024 * 2
         wr = sum(d.get('WRITE_SIZE', [0])) / max(len(d.get('WRITE_SIZE', [0])), 1) * 1024
         per_launch[k] = round(fe + wr)
