@@ -110,8 +110,8 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
     if (p.sx == SEG) { p.sx = 0; p.ty += 1; if (p.ty == TH) { p.ty = 0; p.img += 1; } }
   };
 
-  v2f dd[1][4][4], dyd[1][2][2];                            // the loaded patch / block (one step ahead of its transform)
-  float mLs[1] = {1.0f}, mRs[1] = {1.0f};                   // ... and its edge-column masks
+  v2f d[4][4], dyv[2][2];                                   // the loaded patch / block (one step ahead of its transform)
+  float mL = 1.0f, mR = 1.0f;                               // ... and its edge-column masks
   const gptr xbase = (gptr)a.x + (size_t)ci0 * 4;
   const gptr ybase = (gptr)a.dy + (size_t)co0 * 4;
   const gptr zbase = (gptr)a.zero;
@@ -144,24 +144,24 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
   // ... and the loads one by one (k = 4 i + j: patch element (i, j); 16 .. 19: the 2 x 2 output-gradient block), so that the loop
   // can deal them out one per MFMA gap: issued in one batch, the 4 waves' 80 loads queued up in front of the CU's one
   // texture-address unit and the issuing plane took 1,370 cycles instead of 256 (tools/diag/wgw_clock.hip)
-  auto load_one = [&](auto kc, auto setc, const LoadCtx& c) {
-    constexpr int k = decltype(kc)::value, set = decltype(setc)::value;
+  auto load_one = [&](auto kc, const LoadCtx& c) {
+    constexpr int k = decltype(kc)::value;
     if constexpr (k < 16) {
       constexpr int i = k >> 2, j = k & 3;
-      dd[set][i][j] = ld2(c.xr[i], j == 0 ? c.o0 : j == 1 ? xo1v : j == 2 ? xo2v : c.o3);
+      d[i][j] = ld2(c.xr[i], j == 0 ? c.o0 : j == 1 ? xo1v : j == 2 ? xo2v : c.o3);
     } else {
       constexpr int r = (k - 16) >> 1, q = (k - 16) & 1;
-      dyd[set][r][q] = ld2(c.yr[r], q == 0 ? yo0v : yo1v);
+      dyv[r][q] = ld2(c.yr[r], q == 0 ? yo0v : yo1v);
     }
   };
 
   // ---- transforms, statement by statement (dealt out between MFMAs in the loop)
   v2f tr[4][4], tv[4][4], ar[2][2], av[4][4];
-  auto t_row = [&](auto kc, auto setc) {                  // k = 4 j + r: B^T d, rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-    constexpr int k = decltype(kc)::value, j = k >> 2, r = k & 3, set = decltype(setc)::value;
+  auto t_row = [&](auto kc) {                             // k = 4 j + r: B^T d, rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+    constexpr int k = decltype(kc)::value, j = k >> 2, r = k & 3;
     constexpr int p = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1, q = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3;
-    if constexpr (r == 1) tr[r][j] = dd[set][p][j] + dd[set][q][j];
-    else tr[r][j] = dd[set][p][j] - dd[set][q][j];
+    if constexpr (r == 1) tr[r][j] = d[p][j] + d[q][j];
+    else tr[r][j] = d[p][j] - d[q][j];
   };
   // the same along the columns, k = 4 i + c.  The patch's outside columns (0 at the image's left edge, 3 at its right edge) were
   // loaded from a valid neighbour and count as zeros: their 0 / 1 mask rides in the column step as a fused multiply-add -- the
@@ -177,15 +177,15 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
   // k_wino_dy's planes 3, 7, 11 (-r1 of rows 0..2) and 12, 13, 14 (row 3 = -d1; plane 15 = -(-d1's r1) is positive) are the
   // negatives of these; a product with a negated operand is the negated product exactly, so k_wgw_reduce flips the sign of those
   // planes' sums instead (6 vector instructions per step less).
-  auto a_row = [&](auto kc, auto setc) {                  // k = 0, 1: column c of the block
-    constexpr int c = decltype(kc)::value, set = decltype(setc)::value;
-    ar[0][c] = dyd[set][0][c] + dyd[set][1][c];
-    ar[1][c] = dyd[set][0][c] - dyd[set][1][c];
+  auto a_row = [&](auto kc) {                             // k = 0, 1: column c of the block
+    constexpr int c = decltype(kc)::value;
+    ar[0][c] = dyv[0][c] + dyv[1][c];
+    ar[1][c] = dyv[0][c] - dyv[1][c];
   };
-  auto a_col = [&](auto kc, auto setc) {                  // k = row i of A dY: (d0, d0 + d1, d0 - d1, d1)
-    constexpr int i = decltype(kc)::value, set = decltype(setc)::value;
-    const v2f r0 = i == 0 ? dyd[set][0][0] : i == 1 ? ar[0][0] : i == 2 ? ar[1][0] : dyd[set][1][0];
-    const v2f r1 = i == 0 ? dyd[set][0][1] : i == 1 ? ar[0][1] : i == 2 ? ar[1][1] : dyd[set][1][1];
+  auto a_col = [&](auto kc) {                             // k = row i of A dY: (d0, d0 + d1, d0 - d1, d1)
+    constexpr int i = decltype(kc)::value;
+    const v2f r0 = i == 0 ? dyv[0][0] : i == 1 ? ar[0][0] : i == 2 ? ar[1][0] : dyv[1][0];
+    const v2f r1 = i == 0 ? dyv[0][1] : i == 1 ? ar[0][1] : i == 2 ? ar[1][1] : dyv[1][1];
     av[i][0] = r0;
     av[i][1] = r0 + r1;
     av[i][2] = r0 - r1;
@@ -207,13 +207,12 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
   constexpr int kVpg = T2O_WGW_VPG, kWork = 38;
   constexpr int kLoadGap = (22 + kVpg - 1) / kVpg, kStoreGap = (kWork + kVpg - 1) / kVpg;
   static_assert(kLoadGap + 20 <= 60 && kStoreGap + 16 <= 60, "the step's loads and stores end in front of its barrier");
-  using RS = std::integral_constant<int, 0>;
   auto work = [&](auto wc) {
     constexpr int w = decltype(wc)::value;
-    if constexpr (w < 16) t_row(std::integral_constant<int, w>{}, RS{});
-    else if constexpr (w < 18) a_row(std::integral_constant<int, w - 16>{}, RS{});
-    else if constexpr (w < 22) a_col(std::integral_constant<int, w - 18>{}, RS{});
-    else t_col(std::integral_constant<int, w - 22>{}, mLs[0], mRs[0]);
+    if constexpr (w < 16) t_row(std::integral_constant<int, w>{});
+    else if constexpr (w < 18) a_row(std::integral_constant<int, w - 16>{});
+    else if constexpr (w < 22) a_col(std::integral_constant<int, w - 18>{});
+    else t_col(std::integral_constant<int, w - 22>{}, mL, mR);
   };
 
   // ---- MFMA operands: k-step e of plane xi covers tiles 2 e, 2 e + 1; lane (ln, lh) = channel ln of tile 2 e + lh
@@ -249,15 +248,15 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
   };
   {
     const LoadCtx c0 = load_ctx(pl);
-    static_for<0, 20>([&](auto kc) { load_one(kc, RS{}, c0); });
-    mLs[0] = c0.mL; mRs[0] = c0.mR;
+    static_for<0, 20>([&](auto kc) { load_one(kc, c0); });
+    mL = c0.mL; mR = c0.mR;
   }
   static_for<0, kWork>([&](auto wc) { work(wc); });
   static_for<0, 16>([&](auto kc) { v_store(kc, 0); a_store(kc, 0); });
   {
     const LoadCtx c1 = next_ctx();
-    static_for<0, 20>([&](auto kc) { load_one(kc, RS{}, c1); });
-    mLs[0] = c1.mL; mRs[0] = c1.mR;
+    static_for<0, 20>([&](auto kc) { load_one(kc, c1); });
+    mL = c1.mL; mR = c1.mR;
   }
   __syncthreads();
   frag_read(I0{}, I0{}, 0);
@@ -303,7 +302,7 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
         if constexpr (e == 0 && p == 14) frag_read(std::integral_constant<int, 15>{}, I1{}, buf);
 #ifndef T2O_WGW_NO_XFORM
         static_for<kVpg * g, (kVpg * (g + 1) < kWork ? kVpg * (g + 1) : kWork)>([&](auto wc) { work(wc); });
-        if constexpr (g >= kLoadGap && g < kLoadGap + 20) { load_one(std::integral_constant<int, g - kLoadGap>{}, RS{}, cn); }
+        if constexpr (g >= kLoadGap && g < kLoadGap + 20) { load_one(std::integral_constant<int, g - kLoadGap>{}, cn); }
         if constexpr (g >= kStoreGap && g < kStoreGap + 16) {
           v_store(std::integral_constant<int, g - kStoreGap>{}, buf ^ 1);
           a_store(std::integral_constant<int, g - kStoreGap>{}, buf ^ 1);
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(kWgThreads, 1) void k_wino_wgrad(WgwArgs a) {
       { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[p] += (unsigned)(tn - tprev); tprev = tn; }
 #endif
     });
-    mLs[0] = cn.mL; mRs[0] = cn.mR;
+    mL = cn.mL; mR = cn.mR;
   };
   // (pairs, then the odd step: a conditional second step INSIDE the loop made the compiler shuffle the 256 accumulators through
   // vector registers at the merge -- 284 v_accvgpr moves per step)
