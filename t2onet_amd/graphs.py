@@ -117,14 +117,14 @@ class GraphedEncoder:
             s.needs_gin = k > 0                        # call 0 sees the input image: no gradient needed
             s.static_in = sample_img.detach().clone().requires_grad_(True)
             s.fwd = torch.cuda.CUDAGraph(keep_graph=True)
-            with torch.cuda.graph(s.fwd, pool=pool, capture_error_mode='thread_local'):
+            with _no_gc(), torch.cuda.graph(s.fwd, pool=pool, capture_error_mode='thread_local'):
                 s.static_out = module(s.static_in)
             self.memsets_replaced += _harden(s.fwd)
             slots.append(s)
         for s in reversed(slots):
             s.static_gout = torch.zeros_like(s.static_out)
             s.bwd = torch.cuda.CUDAGraph(keep_graph=True)
-            with torch.cuda.graph(s.bwd, pool=pool, capture_error_mode='thread_local'):
+            with _no_gc(), torch.cuda.graph(s.bwd, pool=pool, capture_error_mode='thread_local'):
                 wrt = ([s.static_in] if s.needs_gin else []) + params
                 g = torch.autograd.grad((s.static_out,), wrt, (s.static_gout,), allow_unused=True)
                 if s.needs_gin:
@@ -156,6 +156,26 @@ class GraphedEncoder:
                 raise RuntimeError('GraphedEncoder: a parameter .grad tensor was replaced after capture (use '
                                    'zero_grad(set_to_none=False) / the Trainer\'s flat buffer)')
         return _Replay.apply(img, self.anchor, self.slots[call])
+
+
+class _no_gc:
+    """No cyclic garbage collection while a stream is capturing.  The collector may run on ANY thread that allocates -- the autograd
+    worker in the middle of a captured backward -- and finalise whatever garbage is around: an earlier Trainer with its own
+    hipGraphs, side streams and pool memory.  Seen once in seven full test runs (round 5): `Fatal Python error: Aborted` inside
+    a capture, the collector on the stack.  Collect first, then keep the collector off until the capture has ended."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
 
 
 class GraphedEpisodeStep:
@@ -192,7 +212,7 @@ class GraphedEpisodeStep:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph(keep_graph=True)
-            with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
+            with _no_gc(), torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'):
                 self.loss = self._body()
             self.memsets_replaced = _harden(self.graph)
         finally:
@@ -200,6 +220,8 @@ class GraphedEpisodeStep:
                 for t, keep in zip(buffers, saved):
                     t.copy_(keep)
             trainer.grads.zero()
+            self.trainer = None                                # (used by _body only: no Trainer <-> graph reference cycle, so a finished
+                                                               # Trainer and its graphs are freed at once, not by a later collection)
 
     def _body(self):
         from .train import end_l1_loss
