@@ -507,6 +507,52 @@ def _host_info():
     return {'cpu_model': model, 'logical_cpus': os.cpu_count(), 'physical_cores': phys}
 
 
+def _cpu_train_step(B3, H, W):
+    """The oracle's episode/L1 train step (train_seq2seqL1.py:74-88) on B3 synthetic images: a closure that runs one step."""
+    import torch
+    from oracle import cpu_ref, synth
+    opt = cpu_ref.default_opt()
+    sd = cpu_ref.make_leaf_params(synth.fill_state_dict(cpu_ref.actor_state_skeleton(opt)))
+    leaves = [v for v in sd.values() if v.requires_grad]
+    adam = torch.optim.Adam(leaves, lr=1e-3)
+    ximg, xtgt = synth.images(B3, H, W, 21), synth.images(B3, H, W, 22)
+    req = synth.requests(B3, 17, 23)
+    gen = torch.Generator().manual_seed(10)
+
+    def train_once():
+        adam.zero_grad(set_to_none=True)
+        r = cpu_ref.episode_forward(sd, req, ximg, opt, reinforce_sample=1, training=True, generator=gen)
+        pred = cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], opt.end_id)
+        cpu_ref.l1_loss(pred, xtgt).backward()
+        adam.step()
+    return train_once
+
+
+def cpu_probe_main(spec):
+    """--cpu-probe THREADS:IMAGES:H:W (child process of cpu_baselines): one warm-up + one timed oracle train step, one JSON line."""
+    import torch
+    threads, images, H, W = (int(v) for v in spec.split(':'))
+    torch.set_num_threads(threads)
+    fn = _cpu_train_step(images, H, W)
+    fn()
+    t0 = time.perf_counter()
+    fn()
+    dt = time.perf_counter() - t0
+    print(json.dumps({'threads': threads, 'images': images, 'seconds': round(dt, 3), 'value': round(images / dt, 3)}), flush=True)
+    return 0
+
+
+def _cpu_probe_child(threads, images, H, W, limit_s):
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-probe', '%d:%d:%d:%d' % (threads, images, H, W)],
+                           capture_output=True, text=True, timeout=limit_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=''))
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'error': '%d threads: not finished within %d s' % (threads, limit_s)}
+    except Exception as e:                     # noqa: BLE001
+        return {'value': None, 'error': '%s: %s' % (type(e).__name__, e)}
+
+
 def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
     """BASELINE.md section 3 through oracle/cpu_ref.py -- the eager-PyTorch restatement of the reference, validated against
     it by the committed goldens -- on this node's host cores.  The object's own value is configs[2], the headline's
@@ -546,19 +592,7 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
            'logical_cpus': host['logical_cpus'], 'kind': 'port', 'config': 'configs[2]', 'sample': None, 'host': host}
     try:
         B3 = sample_cfg3
-        sd = cpu_ref.make_leaf_params(synth.fill_state_dict(cpu_ref.actor_state_skeleton(opt)))
-        leaves = [v for v in sd.values() if v.requires_grad]
-        adam = torch.optim.Adam(leaves, lr=1e-3)
-        ximg, xtgt = synth.images(B3, H, W, 21), synth.images(B3, H, W, 22)
-        req = synth.requests(B3, 17, 23)
-        gen = torch.Generator().manual_seed(10)
-
-        def train_once():
-            adam.zero_grad(set_to_none=True)
-            r = cpu_ref.episode_forward(sd, req, ximg, opt, reinforce_sample=1, training=True, generator=gen)
-            pred = cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], opt.end_id)
-            cpu_ref.l1_loss(pred, xtgt).backward()
-            adam.step()
+        train_once = _cpu_train_step(B3, H, W)
         med3, n3 = _median_time(train_once, 3, 1e9)
         res['value'] = round(B3 / med3, 3)
         res['reps'] = n3
@@ -567,6 +601,21 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
                          '%s physical cores' % (B3, H, W, n3, med3, threads, host['physical_cores']))
     except Exception as e:                     # noqa: BLE001
         res['error'] = '%s: %s' % (type(e).__name__, e)
+    # BASELINE.md section 3 says torch.set_num_threads(os.cpu_count()): that figure too, beside the fixed-thread one --
+    # the same step on a small sample in CHILD processes with a time limit (all hardware threads have been 50x slower than 32 on
+    # eager ops of this size: the probe must not be able to hold the benchmark up)
+    try:
+        n_probe = 8
+        allc = _cpu_probe_child(os.cpu_count() or 1, n_probe, H, W, 75)
+        fixed = _cpu_probe_child(threads, n_probe, H, W, 75)
+        res['all_cores'] = {'threads': os.cpu_count(), 'images': n_probe, 'value': allc.get('value'), 'unit': 'images/sec',
+                            'same_sample_at_fixed_threads': fixed.get('value'), 'fixed_threads': threads,
+                            'sample': 'the configs[2] step on %d images, 1 warm-up + 1 repetition, in a child process (75 s limit)' % n_probe}
+        for r_ in (allc, fixed):
+            if 'error' in r_:
+                res['all_cores']['error'] = r_['error']
+    except Exception as e:                     # noqa: BLE001
+        res['all_cores'] = {'error': '%s: %s' % (type(e).__name__, e)}
     res['configs_0'] = cfg0
     res['configs_1'] = cfg1
     if with_gpu_parity:
@@ -608,7 +657,7 @@ def synthetic_requests(B, g):
     return x
 
 
-def train_step_bench(ctx, B, H, W, steps, warmup):
+def train_step_bench(ctx, B, H, W, steps, warmup, with_extras=True):
     """BASELINE.json configs[2]/[3]: the episode/L1 train step of train_seq2seqL1.py:74-88, FiveK-shaped
     synthetic batch, random-init weights, fp32; exactly `steps` timed steps."""
     import torch
@@ -672,6 +721,8 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
     # alternating pair, AFTER the timed headline region: extra keys, same model and batch shapes
     extra = {}
     try:
+        if not with_extras:
+            raise StopIteration
         ops_t = torch.stack([torch.randperm(6, generator=g)[:5] for _ in range(B)])
         y = torch.cat([torch.full((B, 1), 1), torch.tensor([3, 4, 5, 6, 8, 9])[ops_t], torch.full((B, 1), 2)], 1).to(device)
         img_y = torch.rand(B, 6, 3, H, W, generator=g).to(device)
@@ -701,27 +752,27 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
                                              'six encoder passes'},
                  'alternating_pair': {'ms_per_pair': round(pair, 3), 'images_per_sec': round(2 * world * B / pair * 1e3, 1),
                                       'what': 'one supervised + one episode step, the reference\'s iteration parity'}}
+    except StopIteration:
+        pass
     except Exception as e:                 # noqa: BLE001
         extra = {'supervised_step': {'error': '%s: %s' % (type(e).__name__, e)}}
     flop = TRAIN_FLOP_PER_IMAGE * (H * W) / (256.0 * 256.0) * B
     tf = flop / (dt / steps) / 1e12                        # per GPU
-    # what the matrix cores really execute: the stride-1 3x3 layers that take the Winograd F(2x2,3x3) path (encoder.py: >= 256
-    # channels, 6 layers x 3 directions x 5 encoder passes) do 16/36 of the direct convolution's multiplies
-    from t2onet_amd import encoder as _enc
-    wino_saved = 0.0
-    if _enc._WINOGRAD and getattr(model.vis_encoder, 'trunk_plan', None) is not None:
-        plan = model.vis_encoder.trunk_plan()
-        hh, ww = H // 2, W // 2                            # after the stem
-        for blk in plan.blocks:
-            s1 = blk.conv1.stride[0]
-            hh, ww = (hh - 1) // s1 + 1, (ww - 1) // s1 + 1
-            for conv in (blk.conv1, blk.conv2):
-                if plan.wino(conv, hh, ww):
-                    wino_saved += 3 * 5 * 2.0 * 9 * conv.weight.shape[0] * conv.weight.shape[1] * B * hh * ww * (1.0 - 16.0 / 36.0)
-                elif conv is not blk.conv1 or s1 == 1:
-                    if plan.fused_wino(conv, hh, ww):      # on-chip Winograd: forward + data gradient only (the weight gradient stays direct)
-                        wino_saved += 2 * 5 * 2.0 * 9 * conv.weight.shape[0] * conv.weight.shape[1] * B * hh * ww * (1.0 - 16.0 / 36.0)
-    executed = flop - wino_saved
+    # what the matrix cores really execute: derived from the plan's OWN per-layer, per-direction kernel choice (encoder.TrunkPlan.
+    # flop_table: the function the trunk's forward / backward schedule asks too) -- Winograd F(2x2,3x3) families do 16 of the direct
+    # convolution's 36 multiplies; x 5 encoder passes of the episode step
+    executed, families = flop, None
+    if getattr(model.vis_encoder, 'trunk_plan', None) is not None:
+        table = model.vis_encoder.trunk_plan().flop_table(B, H, W)
+        passes = 5
+        trunk_algo = passes * sum(r[3] for r in table)
+        executed = flop - trunk_algo + passes * sum(r[4] for r in table)     # (SURVEY's figure also holds the small dense layers)
+        families = {}
+        for _, _, fam, algo, ex in table:
+            f = families.setdefault(fam, [0.0, 0.0])
+            f[0] += passes * algo
+            f[1] += passes * ex
+        families = {k: {'algorithmic_TFLOP': round(v[0] / 1e12, 4), 'executed_TFLOP': round(v[1] / 1e12, 4)} for k, v in families.items()}
     finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())   # (a step that produced inf/nan gradients is no measurement)
     if not finite:
         raise RuntimeError('train leg: non-finite parameters after %d steps' % (warmup + steps))
@@ -736,10 +787,12 @@ def train_step_bench(ctx, B, H, W, steps, warmup):
                          'executed_flop_per_step_per_gpu': executed,
                          'executed_TFLOPs': round(executed / (dt / steps) / 1e12, 2),
                          'executed_frac': round(executed / (dt / steps) / 1e12 / FP32_MATRIX_PEAK_TF, 4),
+                         'by_kernel_family': families,
                          'note': 'whole step against the dense fp32 matrix peak: 5 x ResNet-18 forward+backward = '
                                  '67.8 GFLOP/image at 256x256 (SURVEY 8(d)), the ALGORITHMIC count of the direct convolutions; '
-                                 'per GPU.  executed_*: the same minus what Winograd F(2x2,3x3) removes on the layers that '
-                                 'take it (16 of 36 multiplies) -- the matrix pipe\'s real load'},
+                                 'per GPU.  executed_*: the same with every layer and direction priced by the kernel family the '
+                                 'trunk plan runs it on (TrunkPlan.flop_table; Winograd F(2x2,3x3): 16 of 36 multiplies) -- the '
+                                 'matrix pipe\'s real load'},
             'workload': 'episode/L1 train step (train_seq2seqL1.py:74-88), bs=%d/GPU %dx%d fp32, sampled ops, '
                         'flat-gradient all-reduce (%d ranks) + Adam' % (B, H, W, world), **extra}
 
@@ -957,9 +1010,14 @@ def compact_line(detail, detail_path=None):
         if isinstance(ts.get('alternating_pair'), dict):
             t['alternating_pair_ms'] = ts['alternating_pair'].get('ms_per_pair')
         out['train_step'] = t
+    t128 = detail.get('train_step_128')
+    if t128:
+        out['train_step_128'] = _pick(t128, ('images_per_sec', 'ms_per_step', 'host_enqueue_ms_per_step', 'vs_256', 'executed_frac', 'error'))
     cb = detail.get('cpu_baseline')
     if cb is not None:
-        c = _pick(cb, ('value', 'unit', 'cores', 'kind', 'config', 'physical_cores', 'reps', 'error'))
+        c = _pick(cb, ('value', 'unit', 'cores', 'threads', 'kind', 'config', 'physical_cores', 'logical_cpus', 'reps', 'gpu_over_cpu', 'error'))
+        if isinstance(cb.get('all_cores'), dict):
+            c['all_cores'] = _pick(cb['all_cores'], ('threads', 'value', 'same_sample_at_fixed_threads', 'images', 'error'))
         c['sample'] = _short(cb.get('sample'), 240)
         if isinstance(cb.get('host'), dict):
             c['cpu_model'] = cb['host'].get('cpu_model')
@@ -992,7 +1050,7 @@ def emit_line(detail, extra_keys=()):
     c.update({k: detail[k] for k in extra_keys if k in detail})
     s = json.dumps(c, separators=(',', ':'))
     if len(s) > LINE_LIMIT:               # never a line the driver cannot parse: drop the optional blocks, largest first
-        for k in ('executor', 'train_step', 'parity', 'executor_roofline', 'train_roofline'):
+        for k in ('executor', 'train_step', 'parity', 'train_step_128', 'executor_roofline', 'train_roofline'):
             c.pop(k, None)
             s = json.dumps(c, separators=(',', ':'))
             if len(s) <= LINE_LIMIT:
@@ -1193,12 +1251,27 @@ def worker(args):
         line['error'] = 'train step: %s: %s' % (type(e).__name__, e)
         rc[0] = 1
     watchdog.cancel()
+    # EXTRA key (the headline stays configs[2]): the same step at the size the reference itself trains at -- 128 x 128 crops,
+    # bs = 64 (README.md:91, datasets/FiveKdataset.py:25,68).  A quarter of the pixels: the encoder's maps are 32 x 32 ... 4 x 4.
+    if rc[0] == 0 and not args.quick and (H, W) == (256, 256) and world == 1:
+        try:
+            torch.cuda.empty_cache()
+            t128 = train_step_bench(ctx, B, 128, 128, args.steps, max(args.warmup, 3), with_extras=False)
+            line['train_step_128'] = dict(_pick(t128, ('images_per_sec', 'ms_per_step', 'host_enqueue_ms_per_step', 'steps', 'warmup', 'loss',
+                                                       'workload')),
+                                          vs_256=round(t128['images_per_sec'] / train['images_per_sec'], 3),
+                                          executed_TFLOPs=t128['roofline']['executed_TFLOPs'], executed_frac=t128['roofline']['executed_frac'],
+                                          by_kernel_family=t128['roofline']['by_kernel_family'])
+        except Exception as e:             # noqa: BLE001
+            line['train_step_128'] = {'error': '%s: %s' % (type(e).__name__, e)}
     # the CPU baseline LAST (reported, never the target): run before the train leg, its eager CPU autograd over 64 images left
     # the process in a state in which the supervised / episode alternation read 100-113 ms per pair instead of 83 (the headline
     # and each step on its own were unaffected; not the intra-op thread count -- pinned to 1, the same)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             line['cpu_baseline'] = cpu_baselines(H, W, args.cpu_sample, args.cpu_train_sample)
+            if line.get('value') and line['cpu_baseline'].get('value'):     # (vs_baseline stays null: BASELINE.md publishes no number)
+                line['cpu_baseline']['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)
         except Exception as e:             # noqa: BLE001
             line['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     emit()
@@ -1225,9 +1298,12 @@ def main():
     ap.add_argument('--cpu-train-sample', type=int, default=32, help='images of the configs[2] CPU baseline (a bounded sample of the 64-image batch; 1 warm-up + 3 reps)')
     ap.add_argument('--train-timeout', type=int, default=600, help='seconds before the train-step leg is abandoned')
     ap.add_argument('--launch-timeout', type=int, default=1500, help='launcher: seconds before the ranks are stopped')
+    ap.add_argument('--cpu-probe', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--selftest', action='store_true',
                     help='CPU/gloo stand-in step through the launcher, rendezvous and timing code (tests only)')
     args = ap.parse_args()
+    if args.cpu_probe:
+        return cpu_probe_main(args.cpu_probe)
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
     if args.gpus > 1 and 'RANK' not in os.environ:

@@ -9,8 +9,6 @@ the hot path.  Three ways through it, same arithmetic:
     library (MIOpen) convolutions elsewhere, fused batch-norm kernels;
   * evaluation mode / CPU tensors: plain PyTorch modules.
 Module names follow the reference so its checkpoints load."""
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -18,15 +16,12 @@ import torch.nn.functional as F
 from . import functional as T
 
 
-# ONE kill-switch: T2O_LIBRARY_KERNELS=1 sends the encoder's convolutions (and the request encoder's LSTM,
-# lang_encoder.py) to the framework's library calls -- the comparison the A/B timings of DESIGN.md were made
-# against.  Everything else is frozen at the measured best; the module-level names below exist for the tests, which
-# flip them with monkeypatch.
-_LIBRARY = os.environ.get('T2O_LIBRARY_KERNELS', '0') == '1'
+# Module-level switches for the TESTS, which flip them with monkeypatch to compare the paths with one another (there is no
+# environment knob: the product has ONE path per shape -- a framework-convolution A/B is something tests / tools build themselves).
 _FUSED = True                  # fused training-mode batch norm (+ add + ReLU) kernels (False: PyTorch's batch norm; tests only)
-_OWN_WGRAD = not _LIBRARY      # the hand-written convolution kernels (t2o_conv*.hip), all three directions
+_OWN_WGRAD = True              # the hand-written convolution kernels (t2o_conv*.hip), all three directions
 _CONV_STATS = True             # the forward convolution leaves the batch-norm statistics of its output (from its accumulators)
-_TRUNK = not _LIBRARY          # the one-node trunk (encoder.py); False: the per-layer path everywhere (what the tests compare it with)
+_TRUNK = True                  # the one-node trunk (encoder.py); False: the per-layer path everywhere (what the tests compare it with)
 
 
 def _conv(conv, x, bn=None):

@@ -118,6 +118,68 @@ class TrunkPlan:
                 and bool(_lib.load().t2o_wino_fused_wgrad_supported(1, H, W, w.shape[1], w.shape[0]))
                 and bool(_lib.load().t2o_wino_fused_supported(1, H, W, w.shape[1], w.shape[0])))
 
+    # ---- the ONE place a layer's kernel family is chosen (the forward / backward schedules below and bench.py's executed-FLOP
+    # accounting both ask here)
+    def kernel_for(self, conv, N, Hi, Wi, direction):
+        """Kernel family that runs `direction` ('fwd' | 'dgrad' | 'wgrad') of the 3x3 layer `conv` on an (N, Hi, Wi, Ci) input:
+        'wino_fused' (t2o_wino_fused.hip, forward / data gradient), 'wino_wgrad' (t2o_wino_wgrad.hip), 'wino_sep' (the separate-pass
+        pipeline of t2o_winograd.hip: transforms + 16 GEMMs), 'direct' (t2o_conv.hip, LDS-DMA implicit GEMM), 'generic'
+        (t2o_conv_generic.hip, gathered rows)."""
+        w = conv.weight
+        Co, Ci = w.shape[0], w.shape[1]
+        s = conv.stride[0]
+        Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
+        lib = _lib.load()
+        if direction == 'wgrad':
+            if self.onchip_wgrad(conv, Hi, Wi):
+                return 'wino_wgrad'
+            if self.wino(conv, Hi, Wi):
+                return 'wino_sep'
+            return 'direct' if (Wo % 4 == 0 and (s == 1 or (Hi % 2 == 0 and Wi % 2 == 0))) else 'generic'
+        if self.wino(conv, Hi, Wi):
+            # (forward: Ci -> Co; data gradient: the same kernel with the channel roles swapped)
+            a, b = (Ci, Co) if direction == 'fwd' else (Co, Ci)
+            return 'wino_fused' if (_WINO_FUSED and bool(lib.t2o_wino_fused_supported(N, Hi, Wi, a, b))) else 'wino_sep'
+        if self.fused_wino(conv, Hi, Wi):
+            return 'wino_fused'
+        return 'direct' if _fast_direct(s, Hi, Wi, Wo) else 'generic'
+
+    def flop_table(self, N, H, W):
+        """One encoder pass (forward + backward) over an (N, 3, H, W) batch, row by row: (layer, direction, kernel family,
+        algorithmic FLOP = the direct convolution's 2 * taps * Ci * Co * output pixels, executed FLOP = what the chosen kernel's
+        matrix instructions do: 16 of 36 multiplies per 2 x 2 output tile for the Winograd families, over the PADDED tile count
+        for the separate-pass GEMMs).  bench.py multiplies by the passes of a train step; tests/test_actor_cpu.py pins the sums
+        and tests/test_gpu_encoder.py checks the families against the entry points a real pass calls."""
+        lib = _lib.load()
+        rows = []
+        Hc, Wc = H // 2, W // 2
+        C0 = self.net.conv1.weight.shape[0]
+        f0 = 2.0 * 27 * C0 * N * Hc * Wc
+        for d in ('fwd', 'dgrad', 'wgrad'):
+            rows.append(('stem', d, 'stem', f0, f0))
+        for i, b in enumerate(self.blocks):
+            s = b.conv1.stride[0]
+            Hn, Wn = (Hc - 1) // s + 1, (Wc - 1) // s + 1
+            for name, conv, hi, wi, ho, wo in (('block%d.conv1' % i, b.conv1, Hc, Wc, Hn, Wn), ('block%d.conv2' % i, b.conv2, Hn, Wn, Hn, Wn)):
+                Co, Ci = conv.weight.shape[0], conv.weight.shape[1]
+                algo = 2.0 * 9 * Ci * Co * N * ho * wo
+                for d in ('fwd', 'dgrad', 'wgrad'):
+                    fam = self.kernel_for(conv, N, hi, wi, d)
+                    if fam == 'wino_sep':
+                        ex = 2.0 * 16 * lib.t2o_wino_padded_tiles(N, hi, wi) * Ci * Co
+                    elif fam in ('wino_fused', 'wino_wgrad'):
+                        ex = 2.0 * 16 * (N * (hi // 2) * (wi // 2)) * Ci * Co
+                    else:
+                        ex = algo
+                    rows.append((name, d, fam, algo, ex))
+            if len(b.shortcut):
+                sc = b.shortcut[0]
+                f = 2.0 * sc.weight.shape[0] * sc.weight.shape[1] * N * Hn * Wn
+                for d in ('fwd', 'dgrad', 'wgrad'):
+                    rows.append(('block%d.shortcut' % i, d, 'conv1x1', f, f))
+            Hc, Wc = Hn, Wn
+        return rows
+
     def fused_convs(self):
         return [c for b in self.blocks for c in (b.conv1, b.conv2)
                 if c.stride[0] == 1 and c.weight.shape[0] in (64, 128, 256, 512) and c.weight.shape[1] in (64, 128, 256, 512)] if (_WINO_FUSED and _WINOGRAD) else []
@@ -333,8 +395,10 @@ class WgradArena:
                 x = self.x[xkey][first * N:(first + count) * N]
                 dy = self.dy[id(conv)][first * N:(first + count) * N]
                 n = count * N
-                if kind == '3x3' and plan.onchip_wgrad(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, w.grad, n, Hn, Wn, True):
-                    continue                                   # Winograd domain, both transforms on chip: 16 of 36 multiplies
+                if kind == '3x3' and plan.kernel_for(conv, N, Hi, Wi, 'wgrad') == 'wino_wgrad':
+                    if not wino_fused_wgrad_nhwc(x, dy, w.grad, n, Hn, Wn, True):     # Winograd domain, both transforms on chip: 16 of 36 multiplies
+                        raise RuntimeError('WgradArena: the on-chip Winograd weight gradient refused a layer the plan gave it')
+                    continue
                 if kind == '3x3':
                     s = conv.stride[0]
                     need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(n, Hn, Wn, Ci, Co)
@@ -420,10 +484,11 @@ class _TrunkFn(torch.autograd.Function):
                                           uc=uf.get(('c', id(conv))))      # (the on-chip kernel where the map is a multiple of 16)
                 kept_v[id(conv)] = keep[0]                     # (4x the layer's input: its weight gradient starts from it)
                 return y, stats
-            if plan.fused_wino(conv, Hi, Wi):
+            fam = plan.kernel_for(conv, Nn, Hi, Wi, 'fwd')
+            if fam == 'wino_fused':
                 return wino_fused_conv_nhwc(x, uf[('c', id(conv))], Nn, Hi, Wi, None, True)
             y = _nhwc(Nn, Ho, Wo, Co, dev)
-            if _fast_direct(s, Hi, Wi, Wo):
+            if fam == 'direct':
                 stats = torch.empty((lib.t2o_conv3x3_fwd_stats_rows(Nn, Ho, Wo, Co, s), 2, Co), dtype=torch.float32, device=dev)
                 rc = lib.t2o_conv3x3_fwd_stats_nhwc(_ptr(x), _ptr(w), _ptr(y), _ptr(stats), _ptr(conv_ws), conv_ws.numel(), Nn, Ho, Wo,
                                                     Ci, Co, s, st)
@@ -534,13 +599,16 @@ class _TrunkFn(torch.autograd.Function):
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             s = conv.stride[0]
-            if plan.onchip_wgrad(conv, Hi, Wi) and wino_fused_wgrad_nhwc(x, dy, g(w), N, Hi, Wi, bool(acc)):
+            fam = plan.kernel_for(conv, N, Hi, Wi, 'wgrad')
+            if fam == 'wino_wgrad':
+                if not wino_fused_wgrad_nhwc(x, dy, g(w), N, Hi, Wi, bool(acc)):
+                    raise RuntimeError('trunk: the on-chip Winograd weight gradient refused a layer the plan gave it')
                 return
-            if plan.wino(conv, Hi, Wi):
+            if fam == 'wino_sep':
                 V = ctx.kept_v.pop(id(conv), None)
                 wino_wgrad_nhwc(V if V is not None else wino_input(x, N, Hi, Wi), dy, g(w), N, Hi, Wi, acc)
                 return
-            if Wn % 4 == 0 and (s == 1 or (Hi % 2 == 0 and Wi % 2 == 0)):
+            if fam == 'direct':
                 need = (lib.t2o_conv3x3_wgrad_workspace_bytes if s == 1 else lib.t2o_conv3x3s2_wgrad_workspace_bytes)(N, Hn, Wn, Ci, Co)
                 ws = torch.empty(need, dtype=torch.uint8, device=dev)
                 rc = lib.t2o_conv3x3_wgrad_acc_nhwc(_ptr(x), _ptr(dy), _ptr(g(w)), _ptr(ws), need, N, Hn, Wn, Ci, Co, s, acc, st)
@@ -565,13 +633,14 @@ class _TrunkFn(torch.autograd.Function):
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             s = conv.stride[0]
-            if plan.wino(conv, Hi, Wi):
-                wino_conv_nhwc(dy, wt['wino'][id(conv)], N, Hi, Wi, addend, False, out=dx, uc=wt['wino'].get(('c', id(conv))))
-                return
-            if plan.fused_wino(conv, Hi, Wi):
+            fam = plan.kernel_for(conv, N, Hi, Wi, 'dgrad')
+            if fam == 'wino_fused':
                 wino_fused_conv_nhwc(dy, wt['wino'][('c', id(conv))], N, Hi, Wi, addend, False, out=dx)
                 return
-            if _fast_direct(s, Hi, Wi, Wn):
+            if fam == 'wino_sep':
+                wino_conv_nhwc(dy, wt['wino'][id(conv)], N, Hi, Wi, addend, False, out=dx)
+                return
+            if fam == 'direct':
                 if s == 1:
                     rc = lib.t2o_conv3x3_dgrad_pre_nhwc(_ptr(dy), _ptr(wt[id(conv)]), _ptr(addend), _ptr(dx), _ptr(conv_ws), conv_ws.numel(),
                                                         N, Hi, Wi, Ci, Co, st)
@@ -620,8 +689,9 @@ class _TrunkFn(torch.autograd.Function):
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
             else:
                 C2o, C2i = b.conv2.weight.shape[0], b.conv2.weight.shape[1]
-                fused2 = plan.fused_wino(b.conv2, Hn, Wn) or plan.onchip_wgrad(b.conv2, Hn, Wn)
-                n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and _fast_direct(1, Hn, Wn, Wn) and not fused2) else 0
+                fam2 = plan.kernel_for(b.conv2, N, Hn, Wn, 'dgrad')
+                fused2 = fam2 == 'wino_fused'
+                n_rows = lib.t2o_conv3x3_dgrad_bnsums_rows(N, Hn, Wn, C2i, C2o) if (_BN_SUMS_EPILOGUE and fam2 == 'direct') else 0
                 if fused2 and _BN_SUMS_EPILOGUE:
                     # the on-chip Winograd data gradient with bn1's backward sums in its epilogue
                     rows1 = torch.empty(lib.t2o_wino_fused_stats_rows(N, Hn, Wn) * 2 * C2i, dtype=torch.float32, device=dev)

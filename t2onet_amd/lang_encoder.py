@@ -9,11 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
-
-import os
-
-# T2O_LIBRARY_KERNELS=1 (the one kill-switch, see actor_resnet.py): the library's packed sequence call (MIOpen) on the GPU too
-_OWN_LSTM = os.environ.get('T2O_LIBRARY_KERNELS', '0') != '1'
+_OWN_LSTM = True      # this library's LSTM step kernels on the GPU (module switch for the tests, which compare with nn.LSTM)
 
 
 class Embedding(nn.Embedding):

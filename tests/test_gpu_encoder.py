@@ -405,3 +405,59 @@ def test_on_chip_winograd_stages_against_the_direct_kernels(monkeypatch, bias, s
         assert rel_l2(res[True][1], res[False][1]) < 3e-2
         for n in res[True][2]:
             assert rel_l2(res[True][2][n], res[False][2][n]) < 3e-2, n
+
+
+class _EntryPointRecorder:
+    """Stands in for the ctypes library: every C-ABI call goes through, its name is noted."""
+
+    def __init__(self, lib):
+        self._lib, self.calls = lib, []
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*args):
+            self.calls.append(name)
+            return fn(*args)
+        return call
+
+
+@pytest.mark.parametrize('shape', [(2, 256, 256), (4, 128, 128)])
+def test_flop_table_names_the_kernels_a_pass_really_calls(monkeypatch, shape):
+    """bench.py prices the train step's matrix work from TrunkPlan.flop_table.  Here one forward + backward
+    of the trunk runs with every C-ABI call recorded, and the 3x3 layers' entry points -- counted per kernel family and
+    direction -- must be exactly the table's rows."""
+    from collections import Counter
+    import t2onet_amd._lib as L
+    N, H, W = shape
+    net = _encoder().to(DEV).to(memory_format=torch.channels_last).train()
+    plan = net.trunk_plan()
+    img = synth.images(N, H, W, 31).to(DEV)
+    assert plan.supported(img)
+    want = Counter((r[2], r[1]) for r in plan.flop_table(N, H, W) if r[0].startswith('block') and 'shortcut' not in r[0])
+    rec = _EntryPointRecorder(L.load())
+    monkeypatch.setattr(L, '_lib', rec)
+    _run(net, img, synth.uniform((N, 512), 32, -1.0, 1.0).to(DEV))
+    monkeypatch.undo()
+    family = {'t2o_wino_fused_conv_nhwc': 'wino_fused', 't2o_wino_fused_conv_bnsums_nhwc': 'wino_fused', 't2o_wino_fused_wgrad_nhwc': ('wino_wgrad', 'wgrad'),
+              't2o_gemm_nt_batched': 'wino_sep', 't2o_gemm_tn_batched_ld': ('wino_sep', 'wgrad'),
+              't2o_conv3x3_fwd_stats_nhwc': ('direct', 'fwd'), 't2o_conv3x3_dgrad_pre_nhwc': ('direct', 'dgrad'),
+              't2o_conv3x3s2_dgrad_pre_nhwc': ('direct', 'dgrad'), 't2o_conv3x3_dgrad_pre_bnsums_nhwc': ('direct', 'dgrad'),
+              't2o_conv3x3_wgrad_acc_nhwc': ('direct', 'wgrad'), 't2o_conv3x3_any_fwd_nhwc': ('generic', 'fwd'),
+              't2o_conv3x3_any_dgrad_nhwc': ('generic', 'dgrad'), 't2o_conv3x3_any_wgrad_nhwc': ('generic', 'wgrad')}
+    got = Counter()
+    n_fb = Counter()                                        # forward / data-gradient launches of the two-direction entry points, in call order
+    for name in rec.calls:
+        f = family.get(name)
+        if f is None:
+            continue
+        if isinstance(f, tuple):
+            got[f] += 1
+        else:
+            n_fb[f] += 1
+    # the forward runs first: of a family's two-direction launches the table's forward count are forwards, the rest data gradients
+    for fam, n in n_fb.items():
+        nf = want[(fam, 'fwd')]
+        got[(fam, 'fwd')] += nf
+        got[(fam, 'dgrad')] += n - nf
+    assert +got == +want, (got, want)

@@ -108,3 +108,14 @@ for op in [0, 1, 2, 3, 5, 6, 7]:
             worst[('ragged', op)] = max(worst.get(('ragged', op), 0.0), dev_mixed(out.cpu().numpy(), ref.numpy(), 1e-5))
 for k in sorted(worst):
     print('operator fwd', k, 'needed atol at rtol 1e-5: %.3g' % worst[k])
+
+# ---- the learned-parameter path (Operator.extract_parameters, models/operators.py:73-88): head -> operator
+for op in [0, 1, 2, 3, 5, 6, 7]:
+    Bq, Hq, Wq = 2, 24, 20
+    img = synth.images(Bq, Hq, Wq, 11).to(dev)
+    f = synth.uniform((Bq, 512), 13, -1.0, 1.0).to(dev)
+    out, par = ex.execute(img, op, None, features=f)
+    print('learned op %d: param abs %.3g, needed atol at rtol 1e-5: param %.3g out %.3g' % (
+        op, dev_abs(par.detach().cpu().numpy(), og['op%d_feat_param' % op]),
+        dev_mixed(par.detach().cpu().numpy(), og['op%d_feat_param' % op], 1e-5),
+        dev_mixed(out.detach().cpu().numpy(), og['op%d_feat_out' % op], 1e-5)))

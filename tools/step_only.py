@@ -26,7 +26,8 @@ if os.environ.get('T2O_NO_ARENA'):
     Trainer._arena = lambda self, img, passes: None
 tr = Trainer(model, opt, graph_encoder=(sys.argv[3] != '0') if len(sys.argv) > 3 else True, graph_step=(sys.argv[2] != '0') if len(sys.argv) > 2 else True)
 g = torch.Generator().manual_seed(10)
-B, H, W = 64, 256, 256
+B = int(os.environ.get('T2O_BATCH', '64'))
+H = W = int(os.environ.get('T2O_SIZE', '256'))           # T2O_SIZE=128: the reference's own training size (datasets/FiveKdataset.py:68)
 img = torch.rand(B, 3, H, W, generator=g).to(dev)
 tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
 x = bench.synthetic_requests(B, g)
