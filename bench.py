@@ -606,11 +606,11 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
     # eager ops of this size: the probe must not be able to hold the benchmark up)
     try:
         n_probe = 8
-        allc = _cpu_probe_child(os.cpu_count() or 1, n_probe, H, W, 75)
-        fixed = _cpu_probe_child(threads, n_probe, H, W, 75)
+        allc = _cpu_probe_child(os.cpu_count() or 1, n_probe, H, W, 60)
+        fixed = _cpu_probe_child(threads, n_probe, H, W, 60)
         res['all_cores'] = {'threads': os.cpu_count(), 'images': n_probe, 'value': allc.get('value'), 'unit': 'images/sec',
                             'same_sample_at_fixed_threads': fixed.get('value'), 'fixed_threads': threads,
-                            'sample': 'the configs[2] step on %d images, 1 warm-up + 1 repetition, in a child process (75 s limit)' % n_probe}
+                            'sample': 'the configs[2] step on %d images, 1 warm-up + 1 repetition, in a child process (60 s limit)' % n_probe}
         for r_ in (allc, fixed):
             if 'error' in r_:
                 res['all_cores']['error'] = r_['error']

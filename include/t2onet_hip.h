@@ -649,6 +649,20 @@ int t2o_comm_destroy(void* comm);
 int t2o_allreduce(float* flat, size_t n, void* comm, void* stream);
 int t2o_allreduce_mean(float* flat, size_t n, void* comm, void* stream);
 
+/* ---- the general fp32 matrix-core GEMM (t2o_gemm.hip) behind the dense products no specialised kernel takes: the request
+ * encoder's input projection over all time steps and its weight / input gradients (models/lang_encoder.py:91-102, nn.LSTM's
+ * x W_ih^T and the gradients of W_ih, W_hh), the decoder tape's weight gradients over all decoder steps of a train step
+ * (models/action_decoder.py:52-63: vis_linear, both LSTM cells, attention.linear_out, out_linear) and fc (models/
+ * actor_resnet.py:107).   C (M,N) = [C +] op(A) op(B), row-major, leading dimensions in floats:
+ *   a_kmajor = 1: A is stored (K, M) (a "dy^T x" product sums over the rows of both operands), 0: (M, K);
+ *   b_kmajor = 1: B is stored (K, N), 0: (N, K) (nn.Linear's weight).
+ * Any M, N, K >= 1; operands / C may be column slices of larger matrices.  One workgroup per 64 x 64 tile walks K front to back:
+ * the rounding depends on the shape only (no split-K, no atomics) -- bitwise the same on every run and machine.
+ * t2o_colsum: out[n] = [out[n] +] sum over the rows of X (R, N) (bias gradients), fixed order. */
+int t2o_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor, int b_kmajor,
+             int accumulate, void* stream);
+int t2o_colsum(const float* X, float* out, int R, int N, int ldx, int accumulate, void* stream);
+
 /* ---- Winograd F(2x2,3x3) with V and M kept on chip (t2o_wino_fused.hip): conv2d(x, w, None, 1, 1) on NHWC activations for the
  * stride-1 3x3 layers of the 64- / 128-channel stages (models/actor_resnet.py:24-44), H and W multiples of 16, Ci of 8, Co of
  * 64 -- ONE launch per layer where t2o_wino_input_transform + t2o_gemm_nt_batched + t2o_wino_output_transform move 8x the

@@ -102,6 +102,8 @@ SIGNATURES = {
     't2o_wino_padded_tiles': (_I, [_I, _I, _I]),
     't2o_wino_weight_transform': (_I, [_P, _P, _I, _I, _P]),
     't2o_gemm_nt_batched': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    't2o_gemm': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    't2o_colsum': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     't2o_gemm_tn_splits': (_I, [_I, _I, _I, _I]),
     't2o_gemm_tn_batched': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     't2o_gemm_tn_batched_ld': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

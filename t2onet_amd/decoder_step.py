@@ -20,6 +20,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import functional as T
 from .functional import _need_gpu, _stream
 
 _STEP_KINDS = None
@@ -102,19 +103,18 @@ class DecoderTape:
         D, E = self.D, self.E
         self._clear_missing(n, self.step_done, ('d_lin', 'd_gates1', 'd_gates0', 'd_step_in', 'd_vis'))
         R = self.rows
-        ones = torch.ones(n * self.B, dtype=torch.float32, device=self.flat.device)
         rnn = dec.rnn
 
         def prod(p, dy, x, cols=None):
             if p is None or not p.requires_grad:
                 return
-            sink(p, lambda out, beta: torch.addmm(out if cols is None else out[:, cols[0]:cols[1]], dy.t(), x, beta=beta,
-                                                  out=out if cols is None else out[:, cols[0]:cols[1]]), cols)
+            sink(p, lambda out, beta: T.gemm(dy, x, out=out if cols is None else out[:, cols[0]:cols[1]], a_kmajor=True, b_kmajor=True,
+                                             accumulate=bool(beta)), cols)
 
         def colsum(p, dy):
             if p is None or not p.requires_grad:
                 return
-            sink(p, lambda out, beta: torch.addmv(out, dy.t(), ones, beta=beta, out=out), None)
+            sink(p, lambda out, beta: T.colsum(dy, out=out, accumulate=bool(beta)), None)
 
         dvis, dg0, dg1, dlin = R('d_vis', n), R('d_gates0', n), R('d_gates1', n), R('d_lin', n)
         prod(dec.vis_linear.weight, dvis, R('featc', n))
@@ -149,11 +149,10 @@ class DecoderTape:
             return
         self._clear_missing(n, self.feat_done, ('d_fc', 'd_bn'))
         dfc = self.rows('d_fc', n)
-        ones = torch.ones(n * self.B, dtype=torch.float32, device=self.flat.device)
         if fc.weight.requires_grad:
-            sink(fc.weight, lambda out, beta: torch.addmm(out, dfc.t(), self.rows('pooledc', n), beta=beta, out=out), None)
+            sink(fc.weight, lambda out, beta: T.gemm(dfc, self.rows('pooledc', n), out=out, a_kmajor=True, b_kmajor=True, accumulate=bool(beta)), None)
         if fc.bias is not None and fc.bias.requires_grad:
-            sink(fc.bias, lambda out, beta: torch.addmv(out, dfc.t(), ones, beta=beta, out=out), None)
+            sink(fc.bias, lambda out, beta: T.colsum(dfc, out=out, accumulate=bool(beta)), None)
         dbn = self.a['d_bn'][:n]
         if bn.weight is not None and bn.weight.requires_grad:
             sink(bn.weight, lambda out, beta: out.copy_(dbn[:, 0].sum(0)) if beta == 0 else out.add_(dbn[:, 0].sum(0)), None)

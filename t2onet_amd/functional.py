@@ -1135,6 +1135,52 @@ def stem_planar(x, weight, dy=None, want='fwd', into=None):
     return dw
 
 
+def _ld(t, what):
+    if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1) or t.stride(0) < t.shape[1]:
+        raise ValueError('%s must be a 2-D fp32 matrix with contiguous rows (a column slice of a larger one is fine)' % what)
+    return t.stride(0)
+
+
+def gemm(A, B, out=None, a_kmajor=False, b_kmajor=False, accumulate=False):
+    """out (M,N) [+]= op(A) op(B) on this library's general matrix-core GEMM (t2o_gemm: one fixed reduction order per shape, the
+    same bits on every machine -- the products the framework's BLAS used to pick a kernel for).  A is (M,K), or (K,M) with
+    a_kmajor (a `dy^T x` product sums over the rows of both operands); B is (N,K) -- nn.Linear's weight layout -- or (K,N) with
+    b_kmajor.  Operands and `out` may be column slices of larger matrices."""
+    _need_gpu(A, B)
+    K, M = (A.shape[0], A.shape[1]) if a_kmajor else (A.shape[1], A.shape[0])
+    Kb, N = (B.shape[0], B.shape[1]) if b_kmajor else (B.shape[1], B.shape[0])
+    if K != Kb:
+        raise ValueError('gemm: contraction lengths differ (%d vs %d)' % (K, Kb))
+    if out is None:
+        if accumulate:
+            raise ValueError('gemm: accumulate needs `out`')
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    elif tuple(out.shape) != (M, N):
+        raise ValueError('gemm: out is %s, the product (%d, %d)' % (tuple(out.shape), M, N))
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        return out if accumulate else out.zero_()
+    rc = _lib.load().t2o_gemm(_ptr(A), _ptr(B), _ptr(out), M, N, K, _ld(A, 'gemm: A'), _ld(B, 'gemm: B'), _ld(out, 'gemm: out'),
+                              1 if a_kmajor else 0, 1 if b_kmajor else 0, 1 if accumulate else 0, _stream(A.device))
+    _lib.check(rc, 't2o_gemm')
+    return out
+
+
+def colsum(X, out=None, accumulate=False):
+    """out (N) [+]= the column sums of X (R,N) in a fixed order (t2o_colsum): bias gradients."""
+    _need_gpu(X)
+    R, N = X.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    if R == 0:
+        return out if accumulate else out.zero_()
+    if not (out.dim() == 1 and out.numel() == N and out.is_contiguous() and out.dtype == torch.float32):
+        raise ValueError('colsum: out must be a dense fp32 vector of %d' % N)
+    _lib.check(_lib.load().t2o_colsum(_ptr(X), _ptr(out), R, N, _ld(X, 'colsum: X'), 1 if accumulate else 0, _stream(X.device)), 't2o_colsum')
+    return out
+
+
 class _LstmLayerFn(torch.autograd.Function):
     """One (bi)directional LSTM layer over zero-padded rows with per-sample lengths (t2o_lstm_layer_fwd / _bwd): the
     input GEMM for all steps and directions, the step kernels, and -- backward -- the weight / bias / input gradients as
@@ -1152,7 +1198,7 @@ class _LstmLayerFn(torch.autograd.Function):
         dev = x.device
         x = x.contiguous()
         wih_cat = torch.cat(w_ih, 0) if D > 1 else w_ih[0]                     # (D*4H, E)
-        gi = torch.nn.functional.linear(x, wih_cat)                            # (B, L, D*4H)
+        gi = gemm(x.view(B * L, E), wih_cat).view(B, L, -1)                    # (B, L, D*4H): x W_ih^T for all steps and directions
         whh_t = torch.stack([t.view(4, H, H).permute(2, 1, 0) for t in w_hh], 0).contiguous()     # (D, H(k), H(j), 4 gates)
         b_ih = torch.stack([w[per * d + 2] for d in range(D)], 0).contiguous() if has_bias else None
         b_hh = torch.stack([w[per * d + 3] for d in range(D)], 0).contiguous() if has_bias else None
@@ -1190,29 +1236,33 @@ class _LstmLayerFn(torch.autograd.Function):
                                             _ptr(dgates), _ptr(carry), _ptr(dc), B, L, H, D, _stream(dev))
         _lib.check(rc, 't2o_lstm_layer_bwd')
         dgi = dgates.permute(2, 0, 1, 3).reshape(B * L, D * 4 * H)             # rows (b, t), columns (d, gate): gi's layout
-        dx = (dgi @ wih_cat).view(B, L, E) if ctx.needs_input_grad[0] else None
-        dbias = dgi.sum(0) if has_bias else None
+        dx = gemm(dgi, wih_cat, b_kmajor=True).view(B, L, E) if ctx.needs_input_grad[0] else None
+        dbias = colsum(dgi) if has_bias else None
         per = 4 if has_bias else 2
+
+        def steps_of(d):
+            """(dgates, h_prev) over the steps that have a previous state, as (rows, .) matrices: contiguous per direction"""
+            dg = (dgates[1:, d] if d == 0 else dgates[:-1, d]).reshape((L - 1) * B, 4 * H)
+            hp = (hnew[:-1, d] if d == 0 else hnew[1:, d]).reshape((L - 1) * B, H)
+            return dg, hp
         if ctx.acc and all(_persistent_grad(q) for q in ctx.params):           # parameter gradients added in place by the GEMMs
             p, x2 = ctx.params, x.reshape(B * L, E)
             for d in range(D):
-                p[per * d].grad.addmm_(dgi[:, d * 4 * H:(d + 1) * 4 * H].t(), x2)
+                gemm(dgi[:, d * 4 * H:(d + 1) * 4 * H], x2, out=p[per * d].grad, a_kmajor=True, b_kmajor=True, accumulate=True)
                 if L > 1:
-                    dg = (dgates[1:, d] if d == 0 else dgates[:-1, d]).reshape((L - 1) * B, 4 * H)
-                    hp = (hnew[:-1, d] if d == 0 else hnew[1:, d]).reshape((L - 1) * B, H)
-                    p[per * d + 1].grad.addmm_(dg.t(), hp)
+                    dg, hp = steps_of(d)
+                    gemm(dg, hp, out=p[per * d + 1].grad, a_kmajor=True, b_kmajor=True, accumulate=True)
             if has_bias:
                 torch._foreach_add_([p[per * d + k].grad for d in range(D) for k in (2, 3)],
                                     [dbias[d * 4 * H:(d + 1) * 4 * H] for d in range(D) for _ in (2, 3)])
             return (dx, None, None) + (None,) * len(p)
-        dwih = dgi.t() @ x.reshape(B * L, E)                                   # (D*4H, E)
+        dwih = gemm(dgi, x.reshape(B * L, E), a_kmajor=True, b_kmajor=True)    # (D*4H, E)
         grads = []
         for d in range(D):
             # dW_hh = sum_t dgates[t]^T h_prev(t): h_prev of time t is the state after t-1 (direction 0) / t+1 (direction 1)
             if L > 1:
-                dg = (dgates[1:, d] if d == 0 else dgates[:-1, d]).reshape((L - 1) * B, 4 * H)
-                hp = (hnew[:-1, d] if d == 0 else hnew[1:, d]).reshape((L - 1) * B, H)
-                dwhh = dg.t() @ hp
+                dg, hp = steps_of(d)
+                dwhh = gemm(dg, hp, a_kmajor=True, b_kmajor=True)
             else:
                 dwhh = torch.zeros_like(w_hh[d])
             grads += [dwih[d * 4 * H:(d + 1) * 4 * H], dwhh]
@@ -1356,20 +1406,34 @@ class _LinearAccFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.params = (weight, bias)
         ctx.acc = _persistent_grad(weight) and (bias is None or _persistent_grad(bias))
-        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+        if not x.is_cuda:                                     # (host tensors: the data-parallel logic's gloo tests)
+            return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+        x = x.contiguous()
+        if bias is None:
+            return gemm(x, weight)
+        return gemm(x, weight, out=bias.detach().unsqueeze(0).repeat(x.shape[0], 1), accumulate=True)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         weight, bias = ctx.params
         dy = dy.contiguous()
-        dx = dy @ w if ctx.needs_input_grad[0] else None
+        if not dy.is_cuda:
+            dx = dy @ w if ctx.needs_input_grad[0] else None
+            if ctx.acc and _persistent_grad(weight) and (bias is None or _persistent_grad(bias)):
+                weight.grad.addmm_(dy.t(), x)
+                if bias is not None:
+                    bias.grad.addmv_(dy.t(), _ones(dy.shape[0], dy.device))
+                return dx, None, None
+            return dx, dy.t() @ x, (dy.sum(0) if bias is not None else None)
+        x = x.contiguous()
+        dx = gemm(dy, w, b_kmajor=True) if ctx.needs_input_grad[0] else None
         if ctx.acc and _persistent_grad(weight) and (bias is None or _persistent_grad(bias)):
-            weight.grad.addmm_(dy.t(), x)
+            gemm(dy, x, out=weight.grad, a_kmajor=True, b_kmajor=True, accumulate=True)
             if bias is not None:
-                bias.grad.addmv_(dy.t(), _ones(dy.shape[0], dy.device))
+                colsum(dy, out=bias.grad, accumulate=True)
             return dx, None, None
-        return dx, dy.t() @ x, (dy.sum(0) if bias is not None else None)
+        return dx, gemm(dy, x, a_kmajor=True, b_kmajor=True), (colsum(dy) if bias is not None else None)
 
 
 def linear_acc(x, weight, bias=None):
@@ -1383,7 +1447,7 @@ class _LstmCellAccFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh):
-        ig, hg = x @ w_ih.t(), h @ w_hh.t()
+        ig, hg = (gemm(x.contiguous(), w_ih), gemm(h.contiguous(), w_hh)) if x.is_cuda else (x @ w_ih.t(), h @ w_hh.t())
         hy, cy, ws = torch.ops.aten._thnn_fused_lstm_cell(ig, hg, c, b_ih, b_hh)
         ctx.save_for_backward(x, h, c, cy, ws, w_ih, w_hh)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
@@ -1396,14 +1460,23 @@ class _LstmCellAccFn(torch.autograd.Function):
         p_ih, p_hh, b_ih, b_hh = ctx.params
         has_bias = b_ih is not None
         gg, gcx, gb = torch.ops.aten._thnn_fused_lstm_cell_backward_impl(ghy, gcy, c, cy, ws, has_bias)
-        dx = gg @ w_ih if ctx.needs_input_grad[0] else None
-        dh = gg @ w_hh if ctx.needs_input_grad[1] else None
+        own = gg.is_cuda
+        if own:
+            gg, x, h = gg.contiguous(), x.contiguous(), h.contiguous()
+        dx = (gemm(gg, w_ih, b_kmajor=True) if own else gg @ w_ih) if ctx.needs_input_grad[0] else None
+        dh = (gemm(gg, w_hh, b_kmajor=True) if own else gg @ w_hh) if ctx.needs_input_grad[1] else None
         if ctx.acc and all(_persistent_grad(p) for p in ctx.params if p is not None):
-            p_ih.grad.addmm_(gg.t(), x)
-            p_hh.grad.addmm_(gg.t(), h)
+            if own:
+                gemm(gg, x, out=p_ih.grad, a_kmajor=True, b_kmajor=True, accumulate=True)
+                gemm(gg, h, out=p_hh.grad, a_kmajor=True, b_kmajor=True, accumulate=True)
+            else:
+                p_ih.grad.addmm_(gg.t(), x)
+                p_hh.grad.addmm_(gg.t(), h)
             if has_bias:
                 torch._foreach_add_([b_ih.grad, b_hh.grad], [gb, gb])
             return dx, dh, gcx, None, None, None, None
+        if own:
+            return dx, dh, gcx, gemm(gg, x, a_kmajor=True, b_kmajor=True), gemm(gg, h, a_kmajor=True, b_kmajor=True), (gb if has_bias else None), (gb if has_bias else None)
         return dx, dh, gcx, gg.t() @ x, gg.t() @ h, (gb if has_bias else None), (gb if has_bias else None)
 
 

@@ -88,7 +88,10 @@ def test_golden_learned_parameter_path(executor, gold, dev, op):
     f = synth.uniform((B, 512), 13, -1.0, 1.0).to(dev).requires_grad_(True)
     out, par = executor.execute(img, op, None, features=f)
     np.testing.assert_allclose(par.detach().cpu().numpy(), gold['op%d_feat_param' % op], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), gold['op%d_feat_out' % op], rtol=0, atol=2e-5)
+    # (round 6, tools/measure_parity.py `learned op`: at rtol 1e-5 the outputs need an absolute floor of <= 1.2e-7 for six of the
+    # seven operators and 3.2e-6 for the colour curve -- its 24 knots come from the parameter head's two GEMMs, whose 3.6e-7
+    # rounding differences the curve's normalisation multiplies; twice that is the bound)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), gold['op%d_feat_out' % op], rtol=1e-5, atol=6e-6 if op == 3 else 2e-6)
     if 'op%d_feat_gfeat' % op in gold:
         out.backward(synth.uniform((B, 3, H, W), 12, -1.0, 1.0).to(dev))
         g = gold['op%d_feat_gfeat' % op]
