@@ -675,10 +675,7 @@ def train_step_bench(ctx, B, H, W, steps, warmup, with_extras=True):
             dist.broadcast(t.data, 0)
     want_graph = os.environ.get('T2O_GRAPH_ENCODER', '0') != '0'
     want_step_graph = os.environ.get('T2O_GRAPH_STEP', '0') != '0'
-    # the framework's GEMM autotuner for the remaining library products (request encoder, the tapes' weight gradients): opt-in
-    # since round 4 -- with the decoder step on own kernels it no longer moves the step (42.58 vs 42.61 ms, A/B on one box)
-    tune = os.environ.get('T2O_TUNE_GEMMS', '0') != '0'
-    tr = Trainer(model, opt, graph_encoder=want_graph, graph_step=want_step_graph, tune_gemms=tune)
+    tr = Trainer(model, opt, graph_encoder=want_graph, graph_step=want_step_graph)
     g = torch.Generator().manual_seed(10 + ctx['rank'])
     img = torch.rand(B, 3, H, W, generator=g).to(device)
     tgt = torch.rand(B, 3, H, W, generator=g).to(device)
@@ -780,7 +777,8 @@ def train_step_bench(ctx, B, H, W, steps, warmup, with_extras=True):
             'host_enqueue_ms_per_step': round(t_enq / steps * 1e3, 2),
             'steps': steps, 'warmup': warmup, 'global_batch': world * B, 'loss': float(loss.item()), 'parameters_finite': finite,
             'encoder_hipgraphs': bool(tr.graph_encoder and '_graphed_encoders' in model.__dict__),
-            'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0, 'library_gemms_tuned': bool(tr.gemms_tuned),
+            'step_hipgraphs': len(tr._step_graphs) if tr.graph_step else 0,
+            'own_communicator': bool(tr.grads.__dict__.get('_comm') is not None),      # T2O_OWN_COMM=1: the C ABI's t2o_allreduce_mean
             'ms_per_step_over_ranks': spread, 'allreduce_ms': allreduce_ms, 'allreduce_bytes': tr.grads.flat.numel() * 4,
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_MATRIX_PEAK_TF, 'unit': 'TFLOP/s',
                          'frac': round(tf / FP32_MATRIX_PEAK_TF, 4), 'flop_per_step_per_gpu': flop,
@@ -1004,7 +1002,7 @@ def compact_line(detail, detail_path=None):
     ts = detail.get('train_step')
     if ts:
         t = _pick(ts, ('host_enqueue_ms_per_step', 'global_batch', 'loss', 'step_hipgraphs', 'ms_per_step_over_ranks',
-                       'allreduce_ms', 'allreduce_bytes'))
+                       'allreduce_ms', 'allreduce_bytes', 'own_communicator'))
         if isinstance(ts.get('supervised_step'), dict):
             t['supervised_ms'] = ts['supervised_step'].get('ms_per_step', _short(ts['supervised_step'].get('error'), 120))
         if isinstance(ts.get('alternating_pair'), dict):
@@ -1095,10 +1093,22 @@ def selftest_worker(args):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    spread, allreduce_ms = {'min': round(dt / args.steps * 1e3, 4), 'max': round(dt / args.steps * 1e3, 4)}, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
+        t = torch.tensor([dt, -dt], dtype=torch.float64)    # (the N > 1 keys of the real line, formed the same way: MAX of +-dt)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        spread = {'min': round(-float(t[1]) / args.steps * 1e3, 4), 'max': round(float(t[0]) / args.steps * 1e3, 4)}
+        dt = float(t[0])
+        ts = []
+        for _ in range(5):
+            dist.barrier()
+            a0 = time.perf_counter()
+            dist.all_reduce(buf)
+            ts.append(time.perf_counter() - a0)
+            buf.div_(world)
+        t = torch.tensor([sorted(ts)[len(ts) // 2]], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_ms = round(float(t.item()) * 1e3, 4)
         seen = torch.zeros(world)
         seen[rank] = os.getpid()
         dist.all_reduce(seen)
@@ -1122,6 +1132,8 @@ def selftest_worker(args):
                    'cpu_baseline': {'value': 0.0, 'unit': 'steps/sec', 'cores': 1, 'kind': 'port', 'sample': 'selftest stand-in ' * 40},
                    'executor': {n: dict(leg) for n in ('cfg2_bs64', 'bs256', 'cfg5_16x512', 'cfg2_generic')},
                    'conv_kernels': {'row_%02d' % i: {'ms': 0.1, 'GFLOP': 19.3, 'TFLOPs': 100.0, 'kernel': 'selftest'} for i in range(24)},
+                   'train_step': {'host_enqueue_ms_per_step': 0.0, 'global_batch': world, 'ms_per_step_over_ranks': spread,
+                                  'allreduce_ms': allreduce_ms, 'allreduce_bytes': buf.numel() * 4},
                    'mean_after_allreduce': float(buf[0])}, extra_keys=('selftest', 'mean_after_allreduce'))
     if world > 1:
         dist.barrier()

@@ -40,6 +40,8 @@ constexpr int kWfThreads = 256;
 constexpr int kXRow = 20;                        // slots per patch row (18 used)
 constexpr int kXPieces = 12;                     // 1 KiB DMA pieces per chunk: 18 * 20 slots * 32 B = 11,520 B
 constexpr int kXBuf = kXPieces * 1024;
+constexpr int kXPiecesPerWave = kXPieces / 4;    // the 4 waves' shares: pieces wave, wave + 4, ... (dma_chunk, x_piece)
+static_assert(kXPiecesPerWave * 4 == kXPieces, "every wave issues the same number of x pieces per chunk (the prologue's vmcnt relies on it)");
 constexpr int kVBuf = 16 * 64 * 32;              // 16 planes x 64 tiles x 32 B
 constexpr int kUBuf = 16 * 64 * 32;              // 16 planes x 64 output channels x 32 B
 
@@ -128,9 +130,9 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   const int chunks = a.Ci >> 3;
 
   // ---- DMA: this wave's pieces wave, wave + 4, wave + 8; per lane the global address of its 16 bytes (chunk 0)
-  const char* xaddr[3];
+  const char* xaddr[kXPiecesPerWave];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < kXPiecesPerWave; ++k) {
     const int piece = wave + 4 * k;
     const int slot = (piece * 64 + lane) >> 1, phys = lane & 1;
     const int half = phys ^ ((slot >> 3) & 1);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   const unsigned lds_x = lds_addr(&Xs[0][0]);
   auto dma_chunk = [&](int buf, int advance) {           // the chunk the addresses stand at; advances them
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < kXPiecesPerWave; ++k) {
       glds16v(xaddr[k], lds_x + (unsigned)(buf * kXBuf + (wave + 4 * k) * 1024));
       xaddr[k] += advance;
     }
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
         // the 3 x pieces of chunk c + 2 (into Xs[kBuf], free since the barrier of chunk c - 1) in gaps 2, 4, 6 of pair T2O_WF_XPAIR:
         // the barrier in front of pair 7 waits for them -- requested in pair 4 they had ~1,600 cycles to arrive
         if constexpr (k == T2O_WF_XPAIR && (m & 1) == 0 && m >= 2) {
+          static_assert(kXPiecesPerWave == 3, "the x pieces of a chunk go out in gaps 2, 4, 6 of one plane pair");
           x_piece(std::integral_constant<int, (m - 2) / 2>{}, kBuf, adv);
         }
         if constexpr (k == 0) {
@@ -327,7 +330,8 @@ __global__ __launch_bounds__(kWfThreads, 1) void k_wino_fused(WfArgs a) {
   dma_chunk(0, chunks > 1 ? 32 : 0);
   dma_u(0, 0);
   dma_chunk(1, chunks > 2 ? 32 : 0);                      // (a one-chunk layer: the same chunk again, never used)
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  // (all but the kXPiecesPerWave newest: the count is dma_chunk's own -- ADVICE r5)
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kXPiecesPerWave) : "memory");
   __builtin_amdgcn_s_barrier();
   transform_all(0, 0);
   vm_wait0();

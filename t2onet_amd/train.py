@@ -83,9 +83,18 @@ class FlatGradients:
         """Build an RCCL communicator through the C ABI (t2o_comm_unique_id / t2o_comm_init_rank) and use it for the gradient
         all-reduce.  Rank 0's 128-byte id reaches the others through `exchange(id_bytes_or_None) -> id_bytes` (default: a
         torch.distributed object broadcast on whatever process group is up).  Collective: every rank must call it."""
+        old = self.__dict__.pop('_comm', None)
+        if old is not None:
+            old.close()
         comm = Communicator(self.flat.device, nranks, rank, exchange)
         self._comm = comm
         return comm
+
+    def close(self):
+        """Destroy the communicator this object built (use_own_communicator / T2O_OWN_COMM), if any."""
+        comm = self.__dict__.pop('_comm', None)
+        if comm is not None:
+            comm.close()
 
 
 class Communicator:
@@ -98,9 +107,13 @@ class Communicator:
         if not lib.t2o_comm_available():
             lib.t2o_comm_unique_id(None)                      # (sets the error text)
             raise RuntimeError('t2o_comm: ' + lib.t2o_last_error().decode('utf-8', 'replace'))
+        if (nranks is None) != (rank is None):
+            raise ValueError('Communicator: give nranks and rank together (or neither: the process group\'s, else one rank)')
         if nranks is None:
             up = dist.is_available() and dist.is_initialized()
             nranks, rank = (dist.get_world_size(), dist.get_rank()) if up else (1, 0)
+        if not (0 <= int(rank) < int(nranks)):
+            raise ValueError('Communicator: rank %s outside 0..%s' % (rank, int(nranks) - 1))
         ident = None
         if rank == 0:
             buf = ctypes.create_string_buffer(128)
@@ -129,10 +142,16 @@ class Communicator:
         return t
 
     def close(self):
-        if self.handle:
+        if getattr(self, 'handle', None):
             from . import _lib
             _lib.load().t2o_comm_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                      # noqa: BLE001 -- interpreter shutdown: the library may be gone already
+            pass
 
 
 def _view_like(seg, p):
@@ -223,27 +242,12 @@ class FlatAdam:
 class Trainer:
     """Drives the reference's alternation: odd iterations supervised, even iterations episode/L1."""
 
-    def __init__(self, model, opt, lr=None, graph_encoder=False, graph_step=False, tune_gemms=False):
+    def __init__(self, model, opt, lr=None, graph_encoder=False, graph_step=False):
         """graph_encoder: capture the image encoder's forward/backward as hipGraphs on the first step (fixed
         batch and image size from then on; other shapes run eagerly) -- see Actor.graph_image_encoder.
         graph_step: capture the WHOLE episode step behind the request encoder (all encoder passes, decoder steps,
         sampling, operators, L1, backward) as one hipGraph per (image shape, request length) --
-        graphs.GraphedEpisodeStep; takes precedence over graph_encoder for the episode step.
-        tune_gemms: let the framework time the library's candidates for every GEMM shape it meets (torch's TunableOp; the
-        decoder's ~20 shapes with M = batch, during the first steps) and keep the fastest -- PROCESS-WIDE and sticky, hence
-        opt-in.  The default pick is latency-bound at these sizes (5.5-9.5 us per call against 3.9-7 us for the best one)."""
-        self.gemms_tuned = False
-        if tune_gemms and next(model.parameters()).is_cuda:
-            try:
-                import tempfile                                # (the result file torch writes at exit: not into the working directory)
-                torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), 't2o_tunableop_%d.csv' % os.getpid()), True)
-                torch.cuda.tunable.set_max_tuning_duration(50)     # ms per candidate set
-                torch.cuda.tunable.enable(True)
-                torch.cuda.tunable.tuning_enable(True)
-                self.gemms_tuned = True
-            except (AttributeError, RuntimeError) as e:        # a framework build without the autotuner: the default picks stay
-                import warnings
-                warnings.warn('library GEMM tuning unavailable (%s: %s)' % (type(e).__name__, e))
+        graphs.GraphedEpisodeStep; takes precedence over graph_encoder for the episode step."""
         self.model, self.opt = model, opt
         self.grads = FlatGradients(model.parameters())
         lr = lr if lr is not None else opt.learning_rate
@@ -270,6 +274,10 @@ class Trainer:
         # allocated for the first batch); their weight gradients are one product per weight over all steps, formed by
         # _flush_tape() after the backward pass
         self._tape_owner = model if (self.grads.flat.is_cuda and hasattr(model, 'decoder') and hasattr(model, 'bn1')) else None
+
+    def close(self):
+        """Release what the Trainer owns beyond tensors: the C-ABI communicator of the gradient all-reduce, if one was built."""
+        self.grads.close()
 
     def _tape(self, B):
         """The persistent tape for batches of B rows (re-allocated when B changes; None for models without a decoder),
@@ -320,18 +328,28 @@ class Trainer:
             return
         key = (img.shape[0], img.shape[2], img.shape[3])
         arenas = self.__dict__.setdefault('_arenas', {})
-        if key in arenas:
-            arena = arenas.pop(key)                           # (re-inserted below: most recently used last)
-        else:
+        arena = arenas.pop(key, None)                         # (re-inserted below: most recently used last)
+        if passes <= 0 or not self._trunk.supported(img):
+            # nothing to defer for this call.  NOT remembered (a cached None would have kept every later step of this
+            # shape off the arena); an arena built earlier for the shape stays
+            if arena is not None:
+                arenas[key] = arena
+            self._trunk.__dict__['arena'] = None
+            return
+        if arena is not None and arena.P < passes:
+            arena = None                                      # grown on demand: rebuilt for the larger pass count
+        if arena is None:
             from .encoder import WgradArena
             while len(arenas) >= self.MAX_ARENAS:
                 arenas.pop(next(iter(arenas)))
-            arena = (WgradArena(self._trunk, key[0], key[1], key[2], self.opt.decoder_max_len + 1, img.device)
-                     if (passes > 0 and self._trunk.supported(img)) else None)
+            # sized for the passes ASKED for (the episode step: decoder_max_len; the teacher-forced step one more) -- training
+            # that only ever runs episode steps no longer pays for a sixth pass (~20 % of a multi-GB arena at bs = 64); the
+            # reference's alternation grows it once, on the first teacher-forced step.  (Arenas a captured step graph pinned
+            # -- graphs.py `_keep` -- live as long as the graph does, beyond MAX_ARENAS: one per captured shape.)
+            arena = WgradArena(self._trunk, key[0], key[1], key[2], passes, img.device)
         arenas[key] = arena
         self._trunk.__dict__['arena'] = arena
-        if arena is not None:
-            arena.begin()
+        arena.begin()
 
     def _maybe_graph(self, img):
         if self.graph_encoder and img.is_cuda and '_graphed_encoders' not in self.model.__dict__:

@@ -28,6 +28,10 @@ def test_launcher_starts_two_ranks_and_relays_one_line():
     assert len(set(pids)) == 2 and 0 not in pids            # two distinct processes took part in the collective
     assert d['steps'] == 4 and d['warmup'] == 1 and d['ms_per_step'] > 0
     assert abs(d['mean_after_allreduce'] - 1.5) < 1e-6      # mean of ranks' (rank + 1): the all-reduce really ran
+    # the N > 1 keys a scaling run is checked by: the collective's own time and size, the spread over the ranks
+    ts = d['train_step']
+    assert ts['allreduce_ms'] > 0 and ts['allreduce_bytes'] == 4 << 16
+    assert 0 < ts['ms_per_step_over_ranks']['min'] <= ts['ms_per_step_over_ranks']['max']
 
 
 def test_refuses_to_run_on_fewer_devices_than_asked():

@@ -272,7 +272,7 @@ def test_on_chip_winograd_matches_conv2d_fp64(shape, with_addend):
 
 # (n_img, Ci, Co, H, W): the stage shapes at small batch, several (co, ci) tiles, Ci != Co, wide / tall maps, one step per split
 WGW_SHAPES = [(2, 64, 64, 16, 16), (3, 64, 64, 32, 48), (2, 128, 128, 32, 32), (1, 64, 128, 16, 32), (2, 128, 64, 48, 16), (5, 64, 64, 64, 64),
-              (1, 192, 64, 16, 16)]
+              (1, 192, 64, 16, 16), (2, 256, 256, 16, 16)]          # (the last: 16 channel-tile combinations)
 
 
 @pytest.mark.parametrize('shape', WGW_SHAPES)
@@ -301,7 +301,7 @@ def test_on_chip_winograd_weight_gradient_matches_fp64(shape, accumulate):
     assert torch.equal(dw, dw2)
 
 
-@pytest.mark.parametrize('shape', [(320, 64, 64, 64, 64), (320, 128, 128, 32, 32)])
+@pytest.mark.parametrize('shape', [(320, 64, 64, 64, 64), (320, 128, 128, 32, 32), (320, 256, 256, 16, 16)])
 def test_on_chip_winograd_weight_gradient_at_the_train_step_size(shape):
     """The shapes of one train step (bs = 64, five encoder passes side by side in encoder.WgradArena): against the direct
     weight-gradient kernel (itself held to fp64 in test_gpu_conv.py) over all 320 images, against fp64 on the first 16,
