@@ -17,6 +17,8 @@
 //   WGRAD      dw[co][kh][kw][ci] = sum_{n,oh,ow} dy[n][oh][ow][co] x[n][oh*s+kh-1][ow*s+kw-1][ci]     (split-K, fixed order)
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "t2onet_hip.h"
 
 namespace t2o {
@@ -88,23 +90,28 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
   }
   const size_t brow0 = (size_t)(n0 + lrow) * 9 * g.K + lc * 4, brow1 = brow0 + (size_t)32 * 9 * g.K;
   const int chunks = g.K / 32, nk = 9 * chunks;
-  float4 ra[4], rb[2];
-  auto gload = [&](int kc) {
+  // Two chunks travel in registers (sets 0 / 1) while a third is multiplied out of LDS: with ONE in flight the loop was a chain of
+  // global round trips -- 1.7 us per chunk, 125 us for the 72 chunks of the 256 -> 512 stride-2 layer of a 128 x 128 image whose
+  // matrix work is 15 us (round 6, profiles/r06_step128_kernel_stats.csv: 10 launches, 1.95 ms of an 18 ms step).
+  float4 ra[2][4], rb[2][2];
+  auto gload = [&](auto sc, int kc) {
+    constexpr int S = decltype(sc)::value;
     const int tap = kc / chunks, cc = kc - tap * chunks;
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long r = pn[j] < 0 ? -1 : a_row(g, pn[j], poh[j], pow_[j], kh, kw);
-      ra[j] = r < 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ld4(g.A + (size_t)r * g.K + cc * 32 + lc * 4);
+      ra[S][j] = r < 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ld4(g.A + (size_t)r * g.K + cc * 32 + lc * 4);
     }
-    rb[0] = ld4(g.B + brow0 + (size_t)tap * g.K + cc * 32);
-    rb[1] = ld4(g.B + brow1 + (size_t)tap * g.K + cc * 32);
+    rb[S][0] = ld4(g.B + brow0 + (size_t)tap * g.K + cc * 32);
+    rb[S][1] = ld4(g.B + brow1 + (size_t)tap * g.K + cc * 32);
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](auto sc, int buf) {
+    constexpr int S = decltype(sc)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) As[buf][(lrow + 32 * j) * 8 + (lc ^ lswz)] = ra[j];
+    for (int j = 0; j < 4; ++j) As[buf][(lrow + 32 * j) * 8 + (lc ^ lswz)] = ra[S][j];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) Bs[buf][(lrow + 32 * j) * 8 + (lc ^ lswz)] = rb[j];
+    for (int j = 0; j < 2; ++j) Bs[buf][(lrow + 32 * j) * 8 + (lc ^ lswz)] = rb[S][j];
   };
   f32x16 acc[2];
 #pragma unroll
@@ -112,12 +119,7 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
   const int frow = wave * 32 + ln, fswz = (ln >> 1) & 7;
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int kc = 0; kc < nk; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < nk) gload(kc + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int pos = (2 * gq + lh) ^ fswz;
@@ -130,7 +132,24 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv1[s], acc[1], 0, 0, 0);
       }
     }
-    if (kc + 1 < nk) sstore(buf ^ 1);
+  };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  gload(S0, 0);
+  sstore(S0, 0);
+  __syncthreads();
+  if (nk > 1) gload(S1, 1);
+  for (int kc = 0; kc < nk; kc += 2) {
+    // LDS buffer 0 holds chunk kc, register set 1 chunk kc + 1
+    if (kc + 2 < nk) gload(S0, kc + 2);
+    compute(0);
+    if (kc + 1 < nk) sstore(S1, 1);
+    __syncthreads();
+    if (kc + 1 >= nk) break;
+    // LDS buffer 1 holds chunk kc + 1, register set 0 chunk kc + 2
+    if (kc + 3 < nk) gload(S1, kc + 3);
+    compute(1);
+    if (kc + 2 < nk) sstore(S0, 0);
     __syncthreads();
   }
 #pragma unroll

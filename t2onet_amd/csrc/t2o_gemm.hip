@@ -8,17 +8,19 @@
 // with either operand stored contraction-major ([K][M] / [K][N]: "dy^T x" weight gradients sum over the ROWS of both operands)
 // or contraction-contiguous ([M][K] / [N][K]: nn.Linear's x W^T), ANY M, N, K (11 output classes, 300 embedding columns, 812
 // decoder inputs, request lengths) and leading dimensions (column slices of a larger matrix).  Rounding is fixed by the
-// shape alone: one workgroup owns a 64 x 64 tile of C and walks K front to back in steps of 16, a lane's sum is the matrix
-// instruction's (v_mfma_f32_32x32x2_f32: exact fp32 multiply-adds, k-pairs in order) -- no split-K, no atomics, the same bits on
+// shape alone: one workgroup owns a 64 x 64 tile of C, its 1, 2 or 4 contraction groups (by K) walk their chunks of 32 front to back and are
+// added in group order; a lane's sum is the matrix instruction's (v_mfma_f32_32x32x2_f32: exact fp32 multiply-adds, k-pairs in order) -- no split-K, no atomics, the same bits on
 // every box and run.  That is what it is for: the library GEMMs it replaces pick a kernel (and a reduction order) per machine, and
 // the episode step's gradient norms moved with it (tests/test_gpu_actor.py).
 //
-//   256 threads = 4 waves (2 x 2), each a 32 x 32 block of the tile.  LDS: As[k][m], Bs[k][n] (16 x 64 floats each, two
+//   A contraction group = 256 threads = 4 waves (2 x 2), each a 32 x 32 block of the tile (1, 2 or 4 groups per workgroup, see kKG).  LDS: As[k][m], Bs[k][n] (32 x 64 floats each, two
 //   buffers); row k's columns are stored at c ^ ((k & 1) << 5), so the MFMA operand read -- lanes 0-31 row 2s, lanes 32-63 row
-//   2s + 1, 32 consecutive columns each -- touches every bank once.  Global loads of chunk i + 1 travel in registers under the
+//   2s + 1, 32 consecutive columns each -- touches every bank once.  Global loads of chunks i + 1 and i + 2 travel in registers under the
 //   MFMAs of chunk i; one barrier per chunk.  A contraction-major operand is read as rows of 64 consecutive floats (coalesced
-//   16-byte loads), a contraction-contiguous one as 16-float row pieces (one 64-byte segment per tile row).
+//   16-byte loads), a contraction-contiguous one as 32-float row pieces (one 128-byte line per tile row).
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "t2onet_hip.h"
 
@@ -52,66 +54,138 @@ __device__ __forceinline__ float4 load4(const float* p, int valid, int vec) {
 }
 
 // kAK / kBK: operand stored contraction-major ([K][M] resp. [K][N]); else contraction-contiguous ([M][K] resp. [N][K])
-template <bool kAK, bool kBK>
-__global__ __launch_bounds__(256) void k_gemm_any(GemmAnyArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[2][16][64];
-  __shared__ __attribute__((aligned(16))) float Bs[2][16][64];
+// kKG: contraction groups.  These products are small (85-416 tiles for 256 CUs) and long in K: one 4-wave workgroup per CU
+// walking K alone is a chain of memory round trips (first version: 106-123 us for K = 2048 where the matrix work is 6 us).  So a
+// workgroup is kKG groups of 4 waves; group g takes the chunks g, g + kKG, ... of the contraction (its own LDS buffers, its own
+// accumulators), all groups step together, and at the end the groups' tiles are added in LDS in group order 0, 1, ... -- a fixed
+// order again, chosen by the shape alone (kKG is a function of K).
+constexpr int kChunk = 32;             // contraction steps per LDS stage and group
+
+template <bool kAK, bool kBK, int kKG>
+__global__ __launch_bounds__(256 * kKG) void k_gemm_any(GemmAnyArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[kKG][2][kChunk][64];
+  __shared__ __attribute__((aligned(16))) float Bs[kKG][2][kChunk][64];
   const int bid = blockIdx.x;
   const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
   const int m0 = tm * 64, n0 = tn * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);          // contraction group of this wave
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, ln = lane & 31, lh = lane >> 5;
 
-  // this thread's piece of a chunk: contraction-major -> (row k = tid / 16, columns 4 (tid % 16) ..); contraction-contiguous ->
-  // (tile row tid % 64, k = 4 (tid / 64) ..)
+  // this thread's two pieces of a chunk: contraction-major -> (rows k = tid / 16 + 16 j, columns 4 (tid % 16) ..);
+  // contraction-contiguous -> (tile row tid % 64, k = 4 (tid / 64) + 16 j ..)
   const int ka = kAK ? (tid >> 4) : ((tid >> 6) << 2), ca = kAK ? ((tid & 15) << 2) : (tid & 63);
   const int kb = kBK ? (tid >> 4) : ((tid >> 6) << 2), cb = kBK ? ((tid & 15) << 2) : (tid & 63);
-  float4 ra, rb;
-  auto gload = [&](int k0) {
-    if constexpr (kAK) {
-      const int k = k0 + ka, valid = k < a.K ? a.M - (m0 + ca) : 0;
-      ra = load4(a.A + (size_t)k * a.lda + m0 + ca, valid, a.vec_a);
+  // a tile whose 64 rows / columns all exist and whose operands allow 16-byte loads reads its full chunks without a single
+  // predicate (uniform per workgroup): the loads of two chunks then stay in flight across the MFMAs of a third
+  const bool full_a = a.vec_a && m0 + 64 <= a.M, full_b = a.vec_b && n0 + 64 <= a.N;
+  const float* const pa = kAK ? a.A + (size_t)ka * a.lda + m0 + ca : a.A + (size_t)(m0 + ca) * a.lda + ka;
+  const float* const pb = kBK ? a.B + (size_t)kb * a.ldb + n0 + cb : a.B + (size_t)(n0 + cb) * a.ldb + kb;
+  const size_t ja = kAK ? (size_t)16 * a.lda : 16, jb = kBK ? (size_t)16 * a.ldb : 16;      // piece j = 1
+  float4 ra[2][2], rb[2][2];
+  auto gload = [&](auto sc, int k0) {
+    constexpr int S = decltype(sc)::value;
+    const bool whole = k0 + kChunk <= a.K;
+    const size_t oa = kAK ? (size_t)k0 * a.lda : (size_t)k0, ob = kBK ? (size_t)k0 * a.ldb : (size_t)k0;
+    if (whole && full_a) {
+      ra[S][0] = *reinterpret_cast<const float4*>(pa + oa);
+      ra[S][1] = *reinterpret_cast<const float4*>(pa + oa + ja);
     } else {
-      const int m = m0 + ca, valid = m < a.M ? a.K - (k0 + ka) : 0;
-      ra = load4(a.A + (size_t)m * a.lda + k0 + ka, valid, a.vec_a);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (kAK) {
+          const int k = k0 + ka + 16 * j, valid = k < a.K ? a.M - (m0 + ca) : 0;
+          ra[S][j] = load4(pa + oa + j * ja, valid, a.vec_a);
+        } else {
+          const int kk = k0 + ka + 16 * j, valid = m0 + ca < a.M ? a.K - kk : 0;
+          ra[S][j] = load4(pa + oa + j * ja, valid, a.vec_a);
+        }
+      }
     }
-    if constexpr (kBK) {
-      const int k = k0 + kb, valid = k < a.K ? a.N - (n0 + cb) : 0;
-      rb = load4(a.B + (size_t)k * a.ldb + n0 + cb, valid, a.vec_b);
+    if (whole && full_b) {
+      rb[S][0] = *reinterpret_cast<const float4*>(pb + ob);
+      rb[S][1] = *reinterpret_cast<const float4*>(pb + ob + jb);
     } else {
-      const int n = n0 + cb, valid = n < a.N ? a.K - (k0 + kb) : 0;
-      rb = load4(a.B + (size_t)n * a.ldb + k0 + kb, valid, a.vec_b);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (kBK) {
+          const int k = k0 + kb + 16 * j, valid = k < a.K ? a.N - (n0 + cb) : 0;
+          rb[S][j] = load4(pb + ob + j * jb, valid, a.vec_b);
+        } else {
+          const int kk = k0 + kb + 16 * j, valid = n0 + cb < a.N ? a.K - kk : 0;
+          rb[S][j] = load4(pb + ob + j * jb, valid, a.vec_b);
+        }
+      }
     }
   };
-  auto sstore = [&](int buf) {
-    if constexpr (kAK) {
-      *reinterpret_cast<float4*>(&As[buf][ka][ca ^ ((ka & 1) << 5)]) = ra;
-    } else {
-      As[buf][ka][ca] = ra.x; As[buf][ka + 1][ca ^ 32] = ra.y; As[buf][ka + 2][ca] = ra.z; As[buf][ka + 3][ca ^ 32] = ra.w;
-    }
-    if constexpr (kBK) {
-      *reinterpret_cast<float4*>(&Bs[buf][kb][cb ^ ((kb & 1) << 5)]) = rb;
-    } else {
-      Bs[buf][kb][cb] = rb.x; Bs[buf][kb + 1][cb ^ 32] = rb.y; Bs[buf][kb + 2][cb] = rb.z; Bs[buf][kb + 3][cb ^ 32] = rb.w;
+  auto sstore = [&](auto sc, int buf) {
+    constexpr int S = decltype(sc)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ra_k = ka + 16 * j, rb_k = kb + 16 * j;
+      if constexpr (kAK) {
+        *reinterpret_cast<float4*>(&As[kg][buf][ra_k][ca ^ ((ra_k & 1) << 5)]) = ra[S][j];
+      } else {                                             // (ra_k is a multiple of 4: rows ra_k + 1, + 3 are the swizzled ones)
+        As[kg][buf][ra_k][ca] = ra[S][j].x; As[kg][buf][ra_k + 1][ca ^ 32] = ra[S][j].y;
+        As[kg][buf][ra_k + 2][ca] = ra[S][j].z; As[kg][buf][ra_k + 3][ca ^ 32] = ra[S][j].w;
+      }
+      if constexpr (kBK) {
+        *reinterpret_cast<float4*>(&Bs[kg][buf][rb_k][cb ^ ((rb_k & 1) << 5)]) = rb[S][j];
+      } else {
+        Bs[kg][buf][rb_k][cb] = rb[S][j].x; Bs[kg][buf][rb_k + 1][cb ^ 32] = rb[S][j].y;
+        Bs[kg][buf][rb_k + 2][cb] = rb[S][j].z; Bs[kg][buf][rb_k + 3][cb ^ 32] = rb[S][j].w;
+      }
     }
   };
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int chunks = (a.K + 15) >> 4;
-  gload(0);
-  sstore(0);
-  __syncthreads();
   const int acol = (wm * 32 + ln) ^ (lh << 5), bcol = (wn * 32 + ln) ^ (lh << 5);     // (row 2s + lh: odd rows are swizzled)
-  for (int c = 0; c < chunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < chunks) gload((c + 1) << 4);
+  auto compute = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + lh][acol], Bs[buf][2 * s + lh][bcol], acc, 0, 0, 0);
-    if (c + 1 < chunks) sstore(buf ^ 1);
+    for (int s = 0; s < kChunk / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kg][buf][2 * s + lh][acol], Bs[kg][buf][2 * s + lh][bcol], acc, 0, 0, 0);
+  };
+  // group kg's chunks are kg, kg + kKG, ...: `rounds` steps for every group (a group past the end of K multiplies zeros: its
+  // loads are predicated off and the stored pieces are zero)
+  const int chunks = (a.K + kChunk - 1) / kChunk, rounds = (chunks + kKG - 1) / kKG;
+  auto k_of = [&](int round) { return (round * kKG + kg) * kChunk; };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  gload(S0, k_of(0));
+  sstore(S0, 0);
+  __syncthreads();
+  if (rounds > 1) gload(S1, k_of(1));
+  for (int c = 0; c < rounds; c += 2) {
+    // LDS buffer 0 holds round c, register set 1 round c + 1
+    if (c + 2 < rounds) gload(S0, k_of(c + 2));
+    compute(0);
+    if (c + 1 < rounds) sstore(S1, 1);
     __syncthreads();
+    if (c + 1 >= rounds) break;
+    // LDS buffer 1 holds round c + 1, register set 0 round c + 2
+    if (c + 3 < rounds) gload(S1, k_of(c + 3));
+    compute(1);
+    if (c + 2 < rounds) sstore(S0, 0);
+    __syncthreads();
+  }
+  // the groups' tiles, added in group order in LDS (a wave's 32 x 32 block as 16 rows of 64 lanes: its own cells only)
+  if constexpr (kKG > 1) {
+    float* red = &As[0][0][0][0] + (size_t)wave * 1024;      // 4 waves x 4 KiB of the (now idle) first A buffers
+    for (int g = 1; g < kKG; ++g) {
+      __syncthreads();
+      if (kg == g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
+      }
+    }
+    if (kg != 0) return;
   }
   // C/D layout: column = lane % 32, row = (r % 4) + 8 (r / 4) + 4 (lane / 32)
   const int n = n0 + wn * 32 + ln;
@@ -168,10 +242,19 @@ int t2o_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
   a.vec_b = ((reinterpret_cast<size_t>(B) & 15) == 0 && ldb % 4 == 0) ? 1 : 0;
   const unsigned grid = (unsigned)(tiles_m * tiles_n);
   hipStream_t st = (hipStream_t)stream;
-  if (a_kmajor && b_kmajor) k_gemm_any<true, true><<<grid, 256, 0, st>>>(a);
-  else if (a_kmajor) k_gemm_any<true, false><<<grid, 256, 0, st>>>(a);
-  else if (b_kmajor) k_gemm_any<false, true><<<grid, 256, 0, st>>>(a);
-  else k_gemm_any<false, false><<<grid, 256, 0, st>>>(a);
+  // contraction groups per workgroup: a function of K alone (the reduction order must not depend on anything else)
+  const int kg = K >= 1024 ? 4 : K >= 192 ? 2 : 1;
+#define T2O_GEMM_LAUNCH(AK, BK)                                                              \
+  do {                                                                                       \
+    if (kg == 4) k_gemm_any<AK, BK, 4><<<grid, 1024, 0, st>>>(a);                            \
+    else if (kg == 2) k_gemm_any<AK, BK, 2><<<grid, 512, 0, st>>>(a);                        \
+    else k_gemm_any<AK, BK, 1><<<grid, 256, 0, st>>>(a);                                     \
+  } while (0)
+  if (a_kmajor && b_kmajor) T2O_GEMM_LAUNCH(true, true);
+  else if (a_kmajor) T2O_GEMM_LAUNCH(true, false);
+  else if (b_kmajor) T2O_GEMM_LAUNCH(false, true);
+  else T2O_GEMM_LAUNCH(false, false);
+#undef T2O_GEMM_LAUNCH
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "gemm launch failed");
 }
 

@@ -159,7 +159,8 @@ def test_backward_outside_the_trainer_after_a_trainer_step():
     tr.supervised_step(x, y, img, img_y, gt)
     assert '_tape' not in model.__dict__ and '_tape' not in model.decoder.__dict__
     assert model.vis_encoder.trunk_plan().__dict__.get('arena') is None
-    assert len(tr._arenas) == 1                              # one arena per batch shape, whatever the number of passes
+    assert len(tr._arenas) <= 1                              # at most one arena per batch shape, whatever the number of passes (none is
+                                                             # remembered for a shape the trunk does not defer: ADVICE r5)
     other, _ = make_model(dev)
     other.load_state_dict(model.state_dict())
     other.train()
