@@ -598,13 +598,6 @@ int t2o_decoder_step_bwd(const t2o_decoder_step_t* args, void* stream);
  * (save_*), running statistics and — backward, 3 launches instead of 6: the gated gradient shared by both branches is
  * never stored — their input gradients dx / dxs and parameter gradients (accumulate != 0: added).  Same arithmetic in the
  * same order as t2o_bn_relu_nhwc_fwd(relu = 0) followed by t2o_bn_relu_nhwc_fwd_partials(res): bit-identical results. */
-/* The finalize step of the channels-last batch norms above INSIDE the kernel that consumes its coefficients (round 6): with a
- * counter block registered for a device -- >= 8 bytes of device memory, zero when registered, 8-byte aligned, owned by the caller
- * -- every t2o_bn_relu_nhwc_* / t2o_bn_dual_relu_nhwc_* call on that device launches one kernel less: the first C/4 (pair: C/2)
- * workgroups of the apply kernel reduce the partial rows (the same code in the same order: bit-identical results), publish the
- * coefficients with an agent-scope release and every workgroup acquires them before use; the block is zero again when the kernel
- * ends.  Calls that share a block must be stream-ordered (the encoder's are: one stream).  counters = NULL: separate launches. */
-int t2o_bn_set_sync_region(int device, void* counters, size_t bytes);
 size_t t2o_bn_dual_nhwc_workspace_bytes(int M, int C);
 int t2o_bn_dual_relu_nhwc_fwd(const float* x, const float* partial, int partial_rows, const float* xs,
                               const float* weight, const float* bias, float* running_mean, float* running_var, float* save_mean,

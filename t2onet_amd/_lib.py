@@ -142,7 +142,6 @@ SIGNATURES = {
     't2o_conv3x3_any_wgrad_nhwc': (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     't2o_lstm_layer_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     't2o_lstm_layer_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    't2o_bn_set_sync_region': (_I, [_I, _P, _Z]),
     't2o_bn_dual_nhwc_workspace_bytes': (_Z, [_I, _I]),
     't2o_bn_dual_relu_nhwc_fwd': (_I, [_P, _P, _I, _P] + [_P] * 13 + [_F, _F, _F, _F, _P, _Z, _I, _I, _P]),
     't2o_bn_dual_relu_nhwc_bwd_acc': (_I, [_P] * 18 + [_I, _P, _Z, _I, _I, _P]),

@@ -1830,7 +1830,9 @@ int t2o_gemm_nt_batched(const float* A, const float* B, float* C, int batches, i
   GemmNtArgs a;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.batches = batches; a.a_rows = a_rows;
   a.tiles_m = (M + 255) / 256;
-  const int bn = N % 128 == 0 ? 2 : 1;
+  // 256 x 128 tiles where they still give every CU a workgroup, 256 x 64 otherwise (the deep stages of a 128 x 128 image: 16 planes
+  // of 1024 x 256 are 128 of the wide tiles -- half the chip idle, round 6).  The same sums in the same order either way.
+  const int bn = (N % 128 == 0 && (long long)batches * a.tiles_m * (N / 128) >= 256) ? 2 : 1;
   a.tiles_n = N / (64 * bn);
   const long long rows = (long long)batches * a.tiles_m;
   const long long grid = ((rows + 7) / 8) * 8 * a.tiles_n;

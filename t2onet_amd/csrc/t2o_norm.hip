@@ -430,57 +430,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_finalize_pair(BnArgs a0, c
   else bn_nhwc_finalize_body<BWD>(a1, partial1, n1, stride1, off1, blockIdx.x - per);
 }
 
-// ---- the finalize step INSIDE the kernel that consumes its coefficients (round 6) ------------------------------------------
-// A finalize launch is C/4 workgroups of one dependent chain (partial rows -> fp64 sums -> coefficients): ~6 us of which the
-// launch itself and the hand-over to the next kernel are more than half, ~170 times per train step.  Here the
-// FIRST nfin workgroups of the apply kernel run exactly that body (same code, same order, same bits), publish the coefficients
-// with an agent-scope release (__threadfence + a release increment of sync[0]: the stores leave this XCD's L2) and every
-// workgroup waits for sync[0] == nfin with agent-scope acquire loads before it reads them (its first loads of those addresses in
-// this kernel; the acquire drops anything older from the caches on its way).  Workgroups are dispatched in index order, so the
-// finalizers are resident before anybody waits for them; the wait is bounded (trap instead of a hang).  The last workgroup PAST
-// the wait (ticket sync[1]) clears both counters: the block is zero again when the kernel ends, for the next call.
-// Calls that share a sync block must be stream-ordered.  nfin == 0: the coefficients are there already (separate launch).
-struct FinArgs {
-  const float* partial0; int n0, stride0, off0;            // as k_bn_nhwc_finalize(_pair)'s arguments
-  const float* partial1; int n1, stride1, off1;            // the second batch norm of a pair (b), or unused
-  BnArgs b;
-  int nfin;                                                // finalizer workgroups: C/4, or 2 C/4 for a pair
-  unsigned* sync;                                          // [0] finalizers done, [1] workgroups past the wait
-};
-
-template <bool BWD>
-__device__ __forceinline__ void fin_head(const BnArgs& a, const FinArgs& f) {
-  if (f.nfin == 0) return;                                 // (kernel argument: uniform)
-  const int per = a.C >> 2;
-  if ((int)blockIdx.x < f.nfin) {
-    if ((int)blockIdx.x < per) bn_nhwc_finalize_body<BWD>(a, f.partial0, f.n0, f.stride0, f.off0, blockIdx.x);
-    else bn_nhwc_finalize_body<BWD>(f.b, f.partial1, f.n1, f.stride1, f.off1, blockIdx.x - per);
-    __threadfence();                                       // this thread's coefficient stores: visible at agent scope
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&f.sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(&f.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)f.nfin) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 25)) __builtin_trap();          // (seconds: a counter block that was not zero -- never a silent hang)
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__device__ __forceinline__ void fin_tail(const FinArgs& f) {
-  if (f.nfin == 0 || threadIdx.x != 0) return;
-  const unsigned t = __hip_atomic_fetch_add(&f.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (t == gridDim.x - 1) {                                // every workgroup is past its wait
-    __hip_atomic_store(&f.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&f.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 template <bool HAS_RES>
-__global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply(BnArgs a, size_t total4, FinArgs f) {
-  fin_head<false>(a, f);
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply(BnArgs a, size_t total4) {
   const int q = a.C >> 2, cq = threadIdx.x % q;
   const float4 sc = ld4(a.coef + 4 * cq), sh = ld4(a.coef + a.C + 4 * cq);
   const size_t span = (size_t)kThreads * kUnroll, stride = (size_t)gridDim.x * span;
@@ -503,7 +454,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply(BnArgs a, size_t tot
       *reinterpret_cast<float4*>(a.out + 4 * i) = o;
     }
   }
-  fin_tail(f);                                            // (at the end: the ticket's round trip delays nothing)
 }
 
 template <bool HAS_RES>
@@ -540,9 +490,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_sums(BnArgs a, int M, 
 }
 
 template <bool HAS_RES>
-__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply(BnArgs a, size_t total4, FinArgs f) {
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply(BnArgs a, size_t total4) {
   constexpr int U = 2;
-  fin_head<true>(a, f);
   const int q = a.C >> 2, cq = threadIdx.x % q;
   const float4 mean = ld4(a.save_mean + 4 * cq), invstd = ld4(a.save_invstd + 4 * cq), bi = ld4(a.bias + 4 * cq);
   const float4 ac = ld4(a.coef + 4 * cq), mg = ld4(a.coef + a.C + 4 * cq), mgx = ld4(a.coef + 2 * a.C + 4 * cq);
@@ -574,7 +523,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply(BnArgs a, size_t
       if (HAS_RES && a.dres) *reinterpret_cast<float4*>(a.dres + 4 * i) = g;
     }
   }
-  fin_tail(f);                                            // (at the end: the ticket's round trip delays nothing)
 }
 
 // ---- the two batch norms of a shortcut block as one pass each way (models/actor_resnet.py:33-36, 42-44) ---------------
@@ -592,8 +540,7 @@ struct BnDual {
   float* out_s;            // backward: gradient w.r.t. xs
 };
 
-__global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply_dual(BnArgs a, BnDual d, size_t total4, FinArgs f) {
-  fin_head<false>(a, f);
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply_dual(BnArgs a, BnDual d, size_t total4) {
   const int q = a.C >> 2, cq = threadIdx.x % q;
   const float4 sc = ld4(a.coef + 4 * cq), sh = ld4(a.coef + a.C + 4 * cq);
   const float4 scs = ld4(d.coef_s + 4 * cq), shs = ld4(d.coef_s + a.C + 4 * cq);
@@ -618,7 +565,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_apply_dual(BnArgs a, BnDua
       *reinterpret_cast<float4*>(a.out + 4 * i) = o;
     }
   }
-  fin_tail(f);                                            // (at the end: the ticket's round trip delays nothing)
 }
 
 // three running sums of the workgroup's threads -> one partial row (3, C)
@@ -675,9 +621,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_sums_dual(BnArgs a, Bn
   nhwc_block_store3(sg, sgx, sgs, q, partial + (size_t)blockIdx.x * 3 * a.C, a.C);
 }
 
-__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply_dual(BnArgs a, BnDual d, size_t total4, FinArgs f) {
+__global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply_dual(BnArgs a, BnDual d, size_t total4) {
   constexpr int U = 2;
-  fin_head<true>(a, f);
   const int q = a.C >> 2, cq = threadIdx.x % q;
   const float4 mean = ld4(a.save_mean + 4 * cq), invstd = ld4(a.save_invstd + 4 * cq);
   const float4 ac = ld4(a.coef + 4 * cq), mg = ld4(a.coef + a.C + 4 * cq), mgx = ld4(a.coef + 2 * a.C + 4 * cq);
@@ -715,7 +660,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_nhwc_bwd_apply_dual(BnArgs a, B
       *reinterpret_cast<float4*>(d.out_s + 4 * i) = os;
     }
   }
-  fin_tail(f);                                            // (at the end: the ticket's round trip delays nothing)
 }
 
 bool nhwc_channels_ok(int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0; }
@@ -746,32 +690,6 @@ unsigned flat_grid(size_t total, int V, int unroll) {
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
-}
-// the registered counter block of the current device (t2o_bn_set_sync_region), or null: then the finalize step is its own launch
-constexpr int kMaxDevices = 64;
-unsigned* g_sync_ptr[kMaxDevices] = {};
-unsigned* sync_block() {
-  int dev = 0;
-  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) ? g_sync_ptr[dev] : nullptr;
-}
-// FinArgs for a launch of `grid` workgroups, or nfin = 0 when the fold does not apply (no block registered, fewer workgroups than
-// finalizers): the caller then launches the finalize kernel itself
-FinArgs fin_single(const float* partial, int nblk, int C, unsigned grid) {
-  FinArgs f = {};
-  unsigned* s = sync_block();
-  if (s && grid >= (unsigned)(C / 4)) { f.partial0 = partial; f.n0 = nblk; f.stride0 = 2 * C; f.off0 = C; f.nfin = C / 4; f.sync = s; }
-  return f;
-}
-FinArgs fin_pair(const float* p0, int n0, int stride0, int off0, const BnArgs& b, const float* p1, int n1, int stride1, int off1, int C,
-                 unsigned grid) {
-  FinArgs f = {};
-  unsigned* s = sync_block();
-  if (s && grid >= (unsigned)(2 * (C / 4))) {
-    f.partial0 = p0; f.n0 = n0; f.stride0 = stride0; f.off0 = off0;
-    f.partial1 = p1; f.n1 = n1; f.stride1 = stride1; f.off1 = off1; f.b = b;
-    f.nfin = 2 * (C / 4); f.sync = s;
-  }
-  return f;
 }
 bool bn_check(const void* x, int N, int C, int HW) { return x && N > 0 && C > 0 && HW > 0 && (size_t)N * C * HW < ((size_t)1 << 40); }
 
@@ -862,11 +780,10 @@ int t2o_bn_relu_nhwc_fwd(const float* x, const float* res, const float* weight, 
   int rpb, nblk;
   nhwc_partition(M, C, kUnroll, &rpb, &nblk);
   k_bn_nhwc_stats<<<nblk, kThreads, 0, st>>>(a, M, rpb, partial);
+  k_bn_nhwc_finalize<false><<<C / 4, kThreads, 0, st>>>(a, partial, nblk);
   const size_t total4 = (size_t)M * (C >> 2);
   const unsigned grid = flat_grid(total4, 1, kUnroll);
-  const FinArgs f = fin_single(partial, nblk, C, grid);
-  if (!f.nfin) k_bn_nhwc_finalize<false><<<C / 4, kThreads, 0, st>>>(a, partial, nblk);
-  if (res) k_bn_nhwc_apply<true><<<grid, kThreads, 0, st>>>(a, total4, f); else k_bn_nhwc_apply<false><<<grid, kThreads, 0, st>>>(a, total4, f);
+  if (res) k_bn_nhwc_apply<true><<<grid, kThreads, 0, st>>>(a, total4); else k_bn_nhwc_apply<false><<<grid, kThreads, 0, st>>>(a, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
@@ -888,11 +805,10 @@ int t2o_bn_relu_nhwc_fwd_partials(const float* x, const float* res, const float*
   a.partials = (double*)workspace;
   a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
   hipStream_t st = (hipStream_t)stream;
+  k_bn_nhwc_finalize<false><<<C / 4, kThreads, 0, st>>>(a, partial, partial_rows);
   const size_t total4 = (size_t)M * (C >> 2);
   const unsigned grid = flat_grid(total4, 1, kUnroll);
-  const FinArgs f = fin_single(partial, partial_rows, C, grid);
-  if (!f.nfin) k_bn_nhwc_finalize<false><<<C / 4, kThreads, 0, st>>>(a, partial, partial_rows);
-  if (res) k_bn_nhwc_apply<true><<<grid, kThreads, 0, st>>>(a, total4, f); else k_bn_nhwc_apply<false><<<grid, kThreads, 0, st>>>(a, total4, f);
+  if (res) k_bn_nhwc_apply<true><<<grid, kThreads, 0, st>>>(a, total4); else k_bn_nhwc_apply<false><<<grid, kThreads, 0, st>>>(a, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
@@ -916,11 +832,10 @@ int t2o_bn_relu_nhwc_bwd_acc(const float* x, const float* y, const float* dy, co
   int rpb, nblk;
   nhwc_partition(M, C, 2, &rpb, &nblk);
   if (has_res) k_bn_nhwc_bwd_sums<true><<<nblk, kThreads, 0, st>>>(a, M, rpb, partial); else k_bn_nhwc_bwd_sums<false><<<nblk, kThreads, 0, st>>>(a, M, rpb, partial);
+  k_bn_nhwc_finalize<true><<<C / 4, kThreads, 0, st>>>(a, partial, nblk);
   const size_t total4 = (size_t)M * (C >> 2);
   const unsigned grid = flat_grid(total4, 1, 2);
-  const FinArgs f = fin_single(partial, nblk, C, grid);
-  if (!f.nfin) k_bn_nhwc_finalize<true><<<C / 4, kThreads, 0, st>>>(a, partial, nblk);
-  if (has_res) k_bn_nhwc_bwd_apply<true><<<grid, kThreads, 0, st>>>(a, total4, f); else k_bn_nhwc_bwd_apply<false><<<grid, kThreads, 0, st>>>(a, total4, f);
+  if (has_res) k_bn_nhwc_bwd_apply<true><<<grid, kThreads, 0, st>>>(a, total4); else k_bn_nhwc_bwd_apply<false><<<grid, kThreads, 0, st>>>(a, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
@@ -943,11 +858,9 @@ int t2o_bn_relu_nhwc_bwd_partials_acc(const float* x, const float* dy, const flo
   a.partials = (double*)workspace;
   a.coef = (float*)((char*)workspace + sizeof(double) * 2 * (size_t)C);
   hipStream_t st = (hipStream_t)stream;
+  k_bn_nhwc_finalize<true><<<C / 4, kThreads, 0, st>>>(a, partial, partial_rows);
   const size_t total4 = (size_t)M * (C >> 2);
-  const unsigned grid = flat_grid(total4, 1, 2);
-  const FinArgs f = fin_single(partial, partial_rows, C, grid);
-  if (!f.nfin) k_bn_nhwc_finalize<true><<<C / 4, kThreads, 0, st>>>(a, partial, partial_rows);
-  k_bn_nhwc_bwd_apply<false><<<grid, kThreads, 0, st>>>(a, total4, f);
+  k_bn_nhwc_bwd_apply<false><<<flat_grid(total4, 1, 2), kThreads, 0, st>>>(a, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
@@ -997,13 +910,11 @@ int t2o_bn_dual_relu_nhwc_fwd(const float* x, const float* partial, int partial_
     partial = part_m;
     partial_rows = nblk;
   }
+  k_bn_nhwc_finalize_pair<false><<<2 * (C / 4), kThreads, 0, st>>>(a, partial, partial_rows, 2 * C, C, b, part_s, nblk, 2 * C, C);
   BnDual d = {};
   d.xs = xs; d.coef_s = coef1;
   const size_t total4 = (size_t)M * (C >> 2);
-  const unsigned grid = flat_grid(total4, 1, kUnroll);
-  const FinArgs f = fin_pair(partial, partial_rows, 2 * C, C, b, part_s, nblk, 2 * C, C, C, grid);
-  if (!f.nfin) k_bn_nhwc_finalize_pair<false><<<2 * (C / 4), kThreads, 0, st>>>(a, partial, partial_rows, 2 * C, C, b, part_s, nblk, 2 * C, C);
-  k_bn_nhwc_apply_dual<<<grid, kThreads, 0, st>>>(a, d, total4, f);
+  k_bn_nhwc_apply_dual<<<flat_grid(total4, 1, kUnroll), kThreads, 0, st>>>(a, d, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
 }
 
@@ -1032,20 +943,10 @@ int t2o_bn_dual_relu_nhwc_bwd_acc(const float* x, const float* xs, const float* 
   int rpb, nblk;
   nhwc_partition(M, C, 2, &rpb, &nblk);
   k_bn_nhwc_bwd_sums_dual<<<nblk, kThreads, 0, st>>>(a, d, M, rpb, partial);
+  k_bn_nhwc_finalize_pair<true><<<2 * (C / 4), kThreads, 0, st>>>(a, partial, nblk, 3 * C, C, b, partial, nblk, 3 * C, 2 * C);
   const size_t total4 = (size_t)M * (C >> 2);
-  const unsigned grid = flat_grid(total4, 1, 2);
-  const FinArgs f = fin_pair(partial, nblk, 3 * C, C, b, partial, nblk, 3 * C, 2 * C, C, grid);
-  if (!f.nfin) k_bn_nhwc_finalize_pair<true><<<2 * (C / 4), kThreads, 0, st>>>(a, partial, nblk, 3 * C, C, b, partial, nblk, 3 * C, 2 * C);
-  k_bn_nhwc_bwd_apply_dual<<<grid, kThreads, 0, st>>>(a, d, total4, f);
+  k_bn_nhwc_bwd_apply_dual<<<flat_grid(total4, 1, 2), kThreads, 0, st>>>(a, d, total4);
   return hipGetLastError() == hipSuccess ? T2O_OK : set_error(T2O_ELAUNCH, "batch-norm kernel launch failed");
-}
-
-int t2o_bn_set_sync_region(int device, void* counters, size_t bytes) {
-  if (device < 0 || device >= kMaxDevices) return set_error(T2O_EINVAL, "bn_set_sync_region: bad device index");
-  if (counters && (bytes < 8 || (reinterpret_cast<size_t>(counters) & 7) != 0))
-    return set_error(T2O_EINVAL, "bn_set_sync_region: at least 8 zeroed bytes, 8-byte aligned");
-  g_sync_ptr[device] = (unsigned*)counters;
-  return T2O_OK;
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from .functional import (_need_gpu, _persistent_grad, bn_fused_finalize, _ptr, _stream, _conv_workspace, _zero_block, wino_conv_nhwc, wino_fused_conv_nhwc, wino_wgrad_nhwc, wino_input,
+from .functional import (_need_gpu, _persistent_grad, _ptr, _stream, _conv_workspace, _zero_block, wino_conv_nhwc, wino_fused_conv_nhwc, wino_wgrad_nhwc, wino_input,
                          wino_backward_nhwc, wino_dw_from, wino_fused_wgrad_nhwc)
 
 # Winograd F(2x2,3x3) for the stride-1 layers with >= 256 channels (t2o_winograd.hip); T2O_WINOGRAD=0: the direct kernels everywhere
@@ -454,7 +454,6 @@ class _TrunkFn(torch.autograd.Function):
         st = _stream(dev)
         planar = 1 if img.is_contiguous() else 0
         N, _, H, W = img.shape
-        bn_fused_finalize(dev)                                # (the batch norms' finalize step inside their apply kernels)
         bn_ws = torch.empty(lib.t2o_bn_nhwc_workspace_bytes(1, 512), dtype=torch.uint8, device=dev)
         conv_ws = _conv_workspace(dev, 64 << 10)               # zero region only (registered once per device: not cleared per call)
         saved = []                                             # per layer: what the backward needs

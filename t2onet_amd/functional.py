@@ -384,8 +384,6 @@ def batch_norm_relu(x, bn, residual=None, relu=True, count=True, partial=None):
         raise NotImplementedError('batch_norm_relu: affine BatchNorm2d with running statistics and a fixed momentum only')
     if count:
         bn.num_batches_tracked.add_(1)
-    if x.is_cuda:
-        bn_fused_finalize(x.device)
     return _BnReluFn.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, partial)
 
 
@@ -505,33 +503,6 @@ def _zero_block(device):
     if idx not in _conv_zeros:
         _conv_workspace(device, 256)
     return _conv_zeros[idx]
-
-
-_bn_sync = {}        # device index -> the counter block registered with the library (kept alive here)
-_BN_FUSED_FINALIZE = True     # (module switch for the tests, which compare with the separate finalize launches)
-
-
-def bn_fused_finalize(device, on=None):
-    """Register (on=True), withdraw (False) or -- on=None -- make sure of the module default for `device`: the batch norms' finalize
-    step inside their apply kernels (t2o_bn_set_sync_region: one launch less per batch-norm call, the same bits).  The block is 64
-    zeroed bytes that live as long as the process; every channels-last batch-norm call of this library on the device then uses it
-    (they are stream-ordered: the encoder runs on one stream)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    want = _BN_FUSED_FINALIZE if on is None else bool(on)
-    have = idx in _bn_sync and _bn_sync[idx][1]
-    if want == have:
-        return
-    if torch.cuda.is_current_stream_capturing():
-        return                                             # (an allocation + a synchronisation: not inside a capture; the state stays)
-    lib = _lib.load()
-    if want:
-        blk = _bn_sync[idx][0] if idx in _bn_sync else torch.zeros(16, dtype=torch.int32, device=device)
-        torch.cuda.current_stream(device).synchronize()
-        _lib.check(lib.t2o_bn_set_sync_region(idx, _ptr(blk), blk.numel() * 4), 't2o_bn_set_sync_region')
-        _bn_sync[idx] = (blk, True)
-    else:
-        _lib.check(lib.t2o_bn_set_sync_region(idx, None, 0), 't2o_bn_set_sync_region')
-        _bn_sync[idx] = (_bn_sync[idx][0], False)
 
 
 def conv3x3_forward(x, weight, want_stats=False):

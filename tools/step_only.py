@@ -22,9 +22,6 @@ if os.environ.get('T2O_NO_DUAL_BN'):
 if os.environ.get('T2O_NO_BN_SUMS_EPI'):
     import t2onet_amd.encoder as _E2
     _E2._BN_SUMS_EPILOGUE = False
-if os.environ.get('T2O_NO_BN_FOLD'):
-    import t2onet_amd.functional as _F
-    _F._BN_FUSED_FINALIZE = False
 if os.environ.get('T2O_NO_ARENA'):
     Trainer._arena = lambda self, img, passes: None
 tr = Trainer(model, opt, graph_encoder=(sys.argv[3] != '0') if len(sys.argv) > 3 else True, graph_step=(sys.argv[2] != '0') if len(sys.argv) > 2 else True)
