@@ -14,7 +14,7 @@
 // the episode step's gradient norms moved with it (tests/test_gpu_actor.py).
 //
 //   A contraction group = 256 threads = 4 waves (2 x 2), each a 32 x 32 block of the tile (1, 2 or 4 groups per workgroup, see kKG).  LDS: As[k][m], Bs[k][n] (32 x 64 floats each, two
-//   buffers); row k's columns are stored at c ^ ((k & 1) << 5), so the MFMA operand read -- lanes 0-31 row 2s, lanes 32-63 row
+//   buffers); row k's columns are stored at c ^ swz(k) (bit 5 = k's parity), so the MFMA operand read -- lanes 0-31 row 2s, lanes 32-63 row
 //   2s + 1, 32 consecutive columns each -- touches every bank once.  Global loads of chunks i + 1 and i + 2 travel in registers under the
 //   MFMAs of chunk i; one barrier per chunk.  A contraction-major operand is read as rows of 64 consecutive floats (coalesced
 //   16-byte loads), a contraction-contiguous one as 32-float row pieces (one 128-byte line per tile row).
@@ -73,15 +73,17 @@ __global__ __launch_bounds__(256 * kKG) void k_gemm_any(GemmAnyArgs a) {
   const int wm = wave >> 1, wn = wave & 1, ln = lane & 31, lh = lane >> 5;
 
   // this thread's two pieces of a chunk: contraction-major -> (rows k = tid / 16 + 16 j, columns 4 (tid % 16) ..);
-  // contraction-contiguous -> (tile row tid % 64, k = 4 (tid / 64) + 16 j ..)
-  const int ka = kAK ? (tid >> 4) : ((tid >> 6) << 2), ca = kAK ? ((tid & 15) << 2) : (tid & 63);
-  const int kb = kBK ? (tid >> 4) : ((tid >> 6) << 2), cb = kBK ? ((tid & 15) << 2) : (tid & 63);
+  // contraction-contiguous -> (tile rows tid / 8 + 32 j, k = 4 (tid % 8) ..)
+  // (contraction-contiguous: 8 neighbouring lanes read the 128 bytes of ONE row piece -- with a lane per row every 16-byte request
+  // was a line of its own and the texture addresser the bottleneck: 62-82 us for K = 2048, round 6 -- rows tid / 8 + 32 j)
+  const int ka = kAK ? (tid >> 4) : ((tid & 7) << 2), ca = kAK ? ((tid & 15) << 2) : (tid >> 3);
+  const int kb = kBK ? (tid >> 4) : ((tid & 7) << 2), cb = kBK ? ((tid & 15) << 2) : (tid >> 3);
   // a tile whose 64 rows / columns all exist and whose operands allow 16-byte loads reads its full chunks without a single
   // predicate (uniform per workgroup): the loads of two chunks then stay in flight across the MFMAs of a third
   const bool full_a = a.vec_a && m0 + 64 <= a.M, full_b = a.vec_b && n0 + 64 <= a.N;
   const float* const pa = kAK ? a.A + (size_t)ka * a.lda + m0 + ca : a.A + (size_t)(m0 + ca) * a.lda + ka;
   const float* const pb = kBK ? a.B + (size_t)kb * a.ldb + n0 + cb : a.B + (size_t)(n0 + cb) * a.ldb + kb;
-  const size_t ja = kAK ? (size_t)16 * a.lda : 16, jb = kBK ? (size_t)16 * a.ldb : 16;      // piece j = 1
+  const size_t ja = kAK ? (size_t)16 * a.lda : (size_t)32 * a.lda, jb = kBK ? (size_t)16 * a.ldb : (size_t)32 * a.ldb;      // piece j = 1
   float4 ra[2][2], rb[2][2];
   auto gload = [&](auto sc, int k0) {
     constexpr int S = decltype(sc)::value;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256 * kKG) void k_gemm_any(GemmAnyArgs a) {
           const int k = k0 + ka + 16 * j, valid = k < a.K ? a.M - (m0 + ca) : 0;
           ra[S][j] = load4(pa + oa + j * ja, valid, a.vec_a);
         } else {
-          const int kk = k0 + ka + 16 * j, valid = m0 + ca < a.M ? a.K - kk : 0;
+          const int kk = k0 + ka, valid = m0 + ca + 32 * j < a.M ? a.K - kk : 0;
           ra[S][j] = load4(pa + oa + j * ja, valid, a.vec_a);
         }
       }
@@ -112,28 +114,35 @@ __global__ __launch_bounds__(256 * kKG) void k_gemm_any(GemmAnyArgs a) {
           const int k = k0 + kb + 16 * j, valid = k < a.K ? a.N - (n0 + cb) : 0;
           rb[S][j] = load4(pb + ob + j * jb, valid, a.vec_b);
         } else {
-          const int kk = k0 + kb + 16 * j, valid = n0 + cb < a.N ? a.K - kk : 0;
+          const int kk = k0 + kb, valid = n0 + cb + 32 * j < a.N ? a.K - kk : 0;
           rb[S][j] = load4(pb + ob + j * jb, valid, a.vec_b);
         }
       }
     }
   };
+  // LDS column swizzle of row k: bit 5 from k's parity (the MFMA operand read: lanes 0-31 row 2s, lanes 32-63 row 2s + 1 -- the
+  // two halves of the banks), bits 3-4 from (k / 4) % 4 (the contraction-contiguous store: lanes with different k land in
+  // different column blocks, 2-way conflicts instead of 8-way); multiples of 8, so a 16-byte store stays in one piece
+  auto swz = [](int k) { return ((k & 1) << 5) | (((k >> 2) & 3) << 3); };
   auto sstore = [&](auto sc, int buf) {
     constexpr int S = decltype(sc)::value;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int ra_k = ka + 16 * j, rb_k = kb + 16 * j;
       if constexpr (kAK) {
-        *reinterpret_cast<float4*>(&As[kg][buf][ra_k][ca ^ ((ra_k & 1) << 5)]) = ra[S][j];
-      } else {                                             // (ra_k is a multiple of 4: rows ra_k + 1, + 3 are the swizzled ones)
-        As[kg][buf][ra_k][ca] = ra[S][j].x; As[kg][buf][ra_k + 1][ca ^ 32] = ra[S][j].y;
-        As[kg][buf][ra_k + 2][ca] = ra[S][j].z; As[kg][buf][ra_k + 3][ca ^ 32] = ra[S][j].w;
+        const int k = ka + 16 * j;
+        *reinterpret_cast<float4*>(&As[kg][buf][k][ca ^ swz(k)]) = ra[S][j];
+      } else {                                             // (ka is a multiple of 4: rows ka .. ka + 3 share bits 3-4 of the swizzle)
+        const int c = (ca + 32 * j) ^ swz(ka);
+        As[kg][buf][ka][c] = ra[S][j].x; As[kg][buf][ka + 1][c ^ 32] = ra[S][j].y;
+        As[kg][buf][ka + 2][c] = ra[S][j].z; As[kg][buf][ka + 3][c ^ 32] = ra[S][j].w;
       }
       if constexpr (kBK) {
-        *reinterpret_cast<float4*>(&Bs[kg][buf][rb_k][cb ^ ((rb_k & 1) << 5)]) = rb[S][j];
+        const int k = kb + 16 * j;
+        *reinterpret_cast<float4*>(&Bs[kg][buf][k][cb ^ swz(k)]) = rb[S][j];
       } else {
-        Bs[kg][buf][rb_k][cb] = rb[S][j].x; Bs[kg][buf][rb_k + 1][cb ^ 32] = rb[S][j].y;
-        Bs[kg][buf][rb_k + 2][cb] = rb[S][j].z; Bs[kg][buf][rb_k + 3][cb ^ 32] = rb[S][j].w;
+        const int c = (cb + 32 * j) ^ swz(kb);
+        Bs[kg][buf][kb][c] = rb[S][j].x; Bs[kg][buf][kb + 1][c ^ 32] = rb[S][j].y;
+        Bs[kg][buf][kb + 2][c] = rb[S][j].z; Bs[kg][buf][kb + 3][c ^ 32] = rb[S][j].w;
       }
     }
   };
@@ -141,11 +150,17 @@ __global__ __launch_bounds__(256 * kKG) void k_gemm_any(GemmAnyArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int acol = (wm * 32 + ln) ^ (lh << 5), bcol = (wn * 32 + ln) ^ (lh << 5);     // (row 2s + lh: odd rows are swizzled)
+  // operand columns of row k = 2s + lh: (k / 4) % 4 = (s / 2) % 4 -- four loop-invariant variants
+  int acol[4], bcol[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    acol[v] = (wm * 32 + ln) ^ (lh << 5) ^ (v << 3);
+    bcol[v] = (wn * 32 + ln) ^ (lh << 5) ^ (v << 3);
+  }
   auto compute = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < kChunk / 2; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kg][buf][2 * s + lh][acol], Bs[kg][buf][2 * s + lh][bcol], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kg][buf][2 * s + lh][acol[(s >> 1) & 3]], Bs[kg][buf][2 * s + lh][bcol[(s >> 1) & 3]], acc, 0, 0, 0);
   };
   // group kg's chunks are kg, kg + kKG, ...: `rounds` steps for every group (a group past the end of K multiplies zeros: its
   // loads are predicated off and the stored pieces are zero)
