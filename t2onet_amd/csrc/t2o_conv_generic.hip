@@ -139,7 +139,20 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
   sstore(S0, 0);
   __syncthreads();
   if (nk > 1) gload(S1, 1);
-  for (int kc = 0; kc < nk; kc += 2) {
+  int kc = 0;
+  // steady state: loads issued on every path, so the wait in front of a store is for the older register set only (behind a
+  // conditional load the compiler waits for everything outstanding)
+  for (; kc + 3 < nk; kc += 2) {
+    gload(S0, kc + 2);
+    compute(0);
+    sstore(S1, 1);
+    __syncthreads();
+    gload(S1, kc + 3);
+    compute(1);
+    sstore(S0, 0);
+    __syncthreads();
+  }
+  for (; kc < nk; kc += 2) {
     // LDS buffer 0 holds chunk kc, register set 1 chunk kc + 1
     if (kc + 2 < nk) gload(S0, kc + 2);
     compute(0);

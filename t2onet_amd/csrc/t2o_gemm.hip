@@ -168,11 +168,36 @@ __global__ __launch_bounds__(256 * kKG) void k_gemm_any(GemmAnyArgs a) {
   auto k_of = [&](int round) { return (round * kKG + kg) * kChunk; };
   constexpr std::integral_constant<int, 0> S0{};
   constexpr std::integral_constant<int, 1> S1{};
+  // the same without a predicate or a branch: full tiles, whole chunks (what the steady-state loop below runs on -- with loads
+  // that are issued on every path the compiler can wait for exactly the older register set, vmcnt(4); behind conditional loads
+  // it waits for everything, and only one chunk was ever in flight)
+  auto gload_fast = [&](auto sc, int k0) {
+    constexpr int S = decltype(sc)::value;
+    const size_t oa = kAK ? (size_t)k0 * a.lda : (size_t)k0, ob = kBK ? (size_t)k0 * a.ldb : (size_t)k0;
+    ra[S][0] = *reinterpret_cast<const float4*>(pa + oa);
+    ra[S][1] = *reinterpret_cast<const float4*>(pa + oa + ja);
+    rb[S][0] = *reinterpret_cast<const float4*>(pb + ob);
+    rb[S][1] = *reinterpret_cast<const float4*>(pb + ob + jb);
+  };
   gload(S0, k_of(0));
   sstore(S0, 0);
   __syncthreads();
   if (rounds > 1) gload(S1, k_of(1));
-  for (int c = 0; c < rounds; c += 2) {
+  int c = 0;
+  if (full_a && full_b) {
+    const int rounds_fast = a.K / (kKG * kChunk);           // rounds whose chunks are whole for every group
+    for (; c + 3 < rounds_fast; c += 2) {
+      gload_fast(S0, k_of(c + 2));
+      compute(0);
+      sstore(S1, 1);
+      __syncthreads();
+      gload_fast(S1, k_of(c + 3));
+      compute(1);
+      sstore(S0, 0);
+      __syncthreads();
+    }
+  }
+  for (; c < rounds; c += 2) {
     // LDS buffer 0 holds round c, register set 1 round c + 1
     if (c + 2 < rounds) gload(S0, k_of(c + 2));
     compute(0);

@@ -102,10 +102,13 @@ def test_winograd_and_direct_kernels_give_the_same_full_size_step(monkeypatch):
     _compare(tr, again, wino, 'repeat', 0.0, 1e-6)
 
 
-def test_trunk_at_batch_64_against_the_fp64_oracle():
-    """relu(bn1(fc(trunk(img)))) -- Actor.image_features, models/actor.py:142-143 -- for one 64 x 3 x 256 x 256 batch against
-    oracle/cpu_ref.image_features in fp64 (training mode: batch statistics everywhere), forward, image gradient and the
-    gradients of every encoder parameter."""
+@pytest.mark.parametrize('size', [256, 128])
+def test_trunk_at_batch_64_against_the_fp64_oracle(size):
+    """relu(bn1(fc(trunk(img)))) -- Actor.image_features, models/actor.py:142-143 -- for one 64 x 3 x 256 x 256 batch (the bench
+    size) and one 64 x 3 x 128 x 128 batch (the size the reference trains at, datasets/FiveKdataset.py:25,68: 32 x 32 ... 4 x 4
+    maps -- other kernel choices: TrunkPlan.flop_table) against oracle/cpu_ref.image_features in fp64 (training mode: batch
+    statistics everywhere), forward, image gradient and the gradients of every encoder parameter."""
+    S = size
     model, opt = _model(seed=12)
     img = synth.images(B, S, S, 911)
     gout = synth.uniform((B, 512), 912, -1.0, 1.0)
@@ -143,8 +146,8 @@ def test_trunk_at_batch_64_against_the_fp64_oracle():
             worst = (d, k)
         if dl > worst_lib[0]:
             worst_lib = (dl, k)
-    print('trunk bs=64 vs fp64: forward max err / scale %.3e (library fp32 %.3e), image gradient rel L2 %.3e (%.3e), worst parameter '
-          'gradient %s %.3e (library: %s %.3e)' % (ferr, ferr_lib, gerr, gerr_lib, worst[1], worst[0], worst_lib[1], worst_lib[0]))
+    print('trunk bs=64 %dx%d vs fp64: forward max err / scale %.3e (library fp32 %.3e), image gradient rel L2 %.3e (%.3e), worst parameter '
+          'gradient %s %.3e (library: %s %.3e)' % (S, S, ferr, ferr_lib, gerr, gerr_lib, worst[1], worst[0], worst_lib[1], worst_lib[0]))
     assert ferr < 5e-5
     assert gerr < max(2e-3, 3 * gerr_lib)
     assert worst[0] < max(2e-3, 3 * worst_lib[0]), (worst, worst_lib)
