@@ -79,13 +79,18 @@ class Actor(nn.Module):
         self.bn1 = nn.BatchNorm1d(512)
         # OP_MASK on the device (not in the state_dict): building it per call is a blocking host-to-device copy
         self.register_buffer('_op_mask_row', torch.tensor(OP_MASK, dtype=torch.float).view(1, -1), persistent=False)
+        # The image encoder is channels-last from the start (round 6): that is the layout this library's convolution kernels
+        # take, so a model that is simply built and moved to the GPU trains on them -- in the default NCHW layout every
+        # convolution was a framework (MIOpen) call, whose algorithm choice differs from machine to machine (the episode step's
+        # gradient norms against the reference moved 9e-5 .. 1.3e-2 with the box: tests/test_gpu_actor.py).  state_dict shapes
+        # and values are unaffected (a memory format, not a shape); use_channels_last(False) restores NCHW.
+        self.use_channels_last(True)
 
     # ------------------------------------------------------------------ helpers
     def use_channels_last(self, on=True):
-        """Run the image encoder channels-last end to end: MIOpen's fp32 implicit-GEMM kernels are NHWC-native
-        on MI355X (NCHW calls pay transposes around them: tools/bench_conv_layers.py, 10.9 -> 9.4 ms of
-        convolutions per encoder pass at bs=64 256x256) and the fused batch-norm kernels have an NHWC form.
-        Same fp32 arithmetic; state_dict shapes are unchanged."""
+        """The image encoder's parameters and activations channels-last end to end (the default since round 6): the layout
+        of this library's convolution and batch-norm kernels (encoder.py).  on=False: NCHW -- the convolutions are then
+        framework calls (an A/B reference; not a path the product needs).  state_dict shapes are unchanged."""
         self._nhwc = bool(on)
         self.vis_encoder.to(memory_format=torch.channels_last if on else torch.contiguous_format)
         return self

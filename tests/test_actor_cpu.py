@@ -285,13 +285,24 @@ def test_chain_specialisation_cache_is_rank_safe(tmp_path):
     assert not [f for f in os.listdir(cache) if '.tmp' in f]        # atomic writes: nothing half-written remains
 
 
-def test_decoder_tape_forms_each_weight_gradient_once_over_all_steps():
-    """decoder_step.DecoderTape host logic (no kernels involved): with the (X, dY) pairs of n recorded steps in the tape's arrays,
-    flush() must ADD exactly sum_s dY_s^T X_s (and the bias / embedding / batch-norm sums) to every parameter's .grad, skip the
-    output projection when no step had a gradient through its scores, zero the slots of a step whose backward never ran, and
-    rewind.  Checked against the same sums written out step by step."""
+def test_decoder_tape_forms_each_weight_gradient_once_over_all_steps(monkeypatch):
+    """decoder_step.DecoderTape host logic: with the (X, dY) pairs of n recorded steps in the tape's arrays, flush() must ADD
+    exactly sum_s dY_s^T X_s (and the bias / embedding / batch-norm sums) to every parameter's .grad, skip the output projection
+    when no step had a gradient through its scores, zero the slots of a step whose backward never ran, and rewind.  Checked
+    against the same sums written out step by step.  (The products themselves are t2o_gemm / t2o_colsum launches -- GPU only,
+    tests/test_gpu_gemm.py; here, on host tensors, the two wrappers are stood in for by their definitions.)"""
     from t2onet_amd.action_decoder import Decoder
     from t2onet_amd.decoder_step import DecoderTape
+    import t2onet_amd.functional as TF
+
+    def gemm(A, B, out=None, a_kmajor=False, b_kmajor=False, accumulate=False):
+        prod = (A.t() if a_kmajor else A) @ (B if b_kmajor else B.t())
+        return out.add_(prod) if accumulate else out.copy_(prod)
+
+    def colsum(X, out=None, accumulate=False):
+        return out.add_(X.sum(0)) if accumulate else out.copy_(X.sum(0))
+    monkeypatch.setattr(TF, 'gemm', gemm)
+    monkeypatch.setattr(TF, 'colsum', colsum)
     torch.manual_seed(1)
     B, D, E, V, K, S, n = 3, 64, 8, 11, 32, 4, 3
     dec = Decoder(V, 5, E, D // 2, 2, bidirectional=True, use_attention=True)
