@@ -89,3 +89,36 @@ def test_lstm_layer_and_tape_launch_no_library_gemm():
     names = [e.key for e in prof.key_averages()]
     assert any('k_gemm_any' in n for n in names), names
     assert not [n for n in names if n.startswith('Cijk_') or 'rocblas' in n.lower()], names
+
+
+def test_train_steps_launch_no_library_gemm_or_convolution():
+    """Both train steps of a model that was simply built and moved to the GPU (no layout call): every kernel is this library's, an
+    element-wise / copy / reduction kernel of the framework, or a runtime copy -- no BLAS (Cijk_*, rocblas*), no MIOpen kernel."""
+    import re
+    from torch.profiler import profile, ProfilerActivity
+    import t2onet_amd
+    from t2onet_amd.actor import Actor
+    from t2onet_amd.train import Trainer
+    opt = t2onet_amd.default_options()
+    torch.manual_seed(3)
+    model = Actor(opt).to(DEV).train()
+    tr = Trainer(model, opt)
+    B, H, W = 8, 128, 128
+    x = synth.requests(B, 17, 41).to(DEV)
+    img, tgt = synth.images(B, H, W, 42).to(DEV), synth.images(B, H, W, 43).to(DEV)
+    y = synth.op_targets(B, 45).to(DEV)
+    img_y = synth.uniform((B, 6, 3, H, W), 46).to(DEV)
+    gt = synth.uniform((B, 5, 24), 47, -1, 1).to(DEV)
+    for _ in range(2):                                      # (first steps: run-time specialisations, allocator warm-up)
+        tr.episode_step(x, img, tgt)
+        tr.supervised_step(x, y, img, img_y, gt)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        tr.episode_step(x, img, tgt)
+        tr.supervised_step(x, y, img, img_y, gt)
+        torch.cuda.synchronize()
+    names = sorted({e.key for e in prof.key_averages()})
+    own = [n for n in names if '(anonymous namespace)::' in n or 't2o::' in n]
+    assert len(own) > 40, names
+    allowed = re.compile(r'\(anonymous namespace\)::k_|t2o::|at::native::|^void at::|at::cuda::|__amd_rocclr_|^Memcpy|^Memset|hipMemcpy|hipMemset')
+    foreign = [n for n in names if not allowed.search(n)]
+    assert not foreign, foreign

@@ -52,6 +52,12 @@ for mode in ('eval', 'train'):
         ref = gold[p + 'grad_norm']
         big = ref > 1e-3 * ref.max()
         print(p, 'grad_norm max rel', float((np.abs(gn[big] - ref[big]) / ref[big]).max()), 'of', int(big.sum()))
+        rel = np.abs(gn - ref) / np.maximum(ref, 1e-30)
+        order = [i for i in np.argsort(-rel) if big[i]][:6]
+        print(p, 'largest gradient-norm deviations:', ', '.join('%s %.3g' % (names[i], rel[i]) for i in order))
+        import hashlib
+        flat = torch.cat([params[n].grad.reshape(-1) for n in names if params[n].grad is not None and 'embedding' not in n])
+        print(p, 'sha256 of all non-embedding gradients (box independence):', hashlib.sha256(flat.cpu().numpy().tobytes()).hexdigest()[:16])
     # supervised
     model, opt = make_model(dev)
     model.train(mode == 'train')
