@@ -4,8 +4,9 @@ tools/gen_golden.py: the reference's CPU run).
 
 Operator indices must be identical (argmax mode).  Floating-point tolerances follow the distances measured with
 tools/measure_parity.py (round 5, profiles/r05_parity_distances.txt), per mode -- ~3x in evaluation mode, where the figures
-are the same on every box; 5-10x in training mode, where they are not (the request encoder's remaining library GEMMs do not round
-alike on every box, and batch statistics over 4 samples amplify it: image crops 1.3e-5, 2.6e-5 and 4.1e-5 on three boxes):
+are the same on every box; 5-10x in training mode (until round 6 this file ran the encoder in NCHW = framework convolutions,
+whose per-machine algorithm choice made them box dependent: image crops 1.3e-5, 2.6e-5 and 4.1e-5 on three boxes; with the
+channels-last default every layer is this library's and the figures repeat bit for bit):
 
                       evaluation mode            training mode (batch statistics over B = 4)
   pred_params         3.4e-8 .. 2.4e-7           5.7e-6 / 4.8e-7        (episode / teacher-forced)
@@ -74,10 +75,16 @@ def test_episode_l1_step_matches_reference(gold, mode):
     gn = np.array([0.0 if params[n].grad is None else params[n].grad.double().norm().item() for n in names])
     ref = gold[p + 'grad_norm']
     big = ref > 1e-3 * ref.max()
-    # three runs of the same build on three boxes: 9.2e-5, 5.7e-3, 1.3e-2 -- the episode's gradient passes through five chained
-    # encoder passes and five operator applications, and the request encoder's remaining LIBRARY GEMMs do not round the same way
-    # on every box (the step amplifies 1e-7 perturbations ~1e4); the teacher-forced step below holds 1e-4
-    np.testing.assert_allclose(gn[big], ref[big], rtol=2e-2)
+    # Rounds 4-5 saw 9.2e-5, 5.7e-3 and 1.3e-2 here on three boxes and blamed the request encoder's library GEMMs.  Round 6 took
+    # every library GEMM AND every framework convolution out of this path (t2o_gemm; the encoder channels-last by default -- this
+    # test had been running MIOpen convolutions, whose algorithm choice is per machine): the figure is now the SAME on every box,
+    # 5.618e-3 (tools/measure_parity.py on three leases, profiles/r06_parity_distances.txt: identical gradient bits), carried by
+    # the colour-curve head (executor.color_op.fc*: 0.47-0.56 %) and two batch-norm biases (0.3 %).  So the old spread was not
+    # GEMM rounding as such: this 4-image batch has gates within rounding of their kink (a clamp bound / ReLU zero in front of
+    # a BatchNorm over 4 values), and which side an fp32 implementation lands on is decided by its last bit -- one flipped gate
+    # moves those tensors by ~0.5 %; the old values were the reference-side and two other sides of the same few gates.  The
+    # as-trained fixtures that move the gates off their kinks (extra2.npz: test_as_trained_*) hold gradients ELEMENTWISE.
+    np.testing.assert_allclose(gn[big], ref[big], rtol=1e-2)
     # heads of unused operators get zeros here (gather over all heads) where the reference has None
     none_ref = gold[p + 'grad_none']
     assert np.all(gn[none_ref] == 0.0)
