@@ -37,3 +37,47 @@ def test_one_rank_job_with_the_c_abi_allreduce_on_the_timed_path(tmp_path):
     with open(os.path.join(str(tmp_path), 'bench_detail.json')) as f:
         detail = json.load(f)
     assert detail['train_step']['parameters_finite'] is True
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+rank = int(os.environ['RANK'])
+torch.cuda.set_device(rank)
+dev = torch.device('cuda', rank)
+dist.init_process_group('nccl', rank=rank, world_size=2, device_id=dev)
+from t2onet_amd.train import Communicator
+comm = Communicator(dev)                                     # id by an object broadcast on the group, t2o_comm_init_rank on both
+t = torch.full((1 << 20,), float(rank + 1), device=dev)
+comm.all_reduce_(t)                                          # 1 + 2
+ok = bool((t == 3.0).all())
+comm.all_reduce_(t, mean=True)                               # (3 + 3) / 2
+ok = ok and bool((t == 3.0).all())
+u = torch.full((5,), float(rank), device=dev)
+dist.all_reduce(u)                                           # torch's own communicator beside it still works
+ok = ok and bool((u == 1.0).all())
+comm.close()
+dist.destroy_process_group()
+print('RANK%%d %%s' %% (rank, 'OK' if ok else 'WRONG'), flush=True)
+'''
+
+
+def test_two_ranks_through_the_c_abi_communicator(tmp_path):
+    """t2o_comm_unique_id / t2o_comm_init_rank / t2o_allreduce(_mean) with TWO ranks over RCCL, next to torch's own communicator
+    (ADVICE r5: the N > 1 path of Communicator had only ever run with one rank).  Needs two GPUs: skipped on the 1-GPU pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (the pool leases one)')
+    script = tmp_path / 'worker.py'
+    script.write_text(_TWO_RANK_WORKER % {'root': ROOT})
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'RANK0 OK' in outs[0] and 'RANK1 OK' in outs[1], outs
