@@ -45,23 +45,29 @@ struct GArgs {
   int tiles_m, tiles_n;
 };
 
-// A row (in pixels of the A grid) that output pixel (n, oh, ow) reads for tap (kh, kw), or -1
-__device__ __forceinline__ long long a_row(const GArgs& g, int n, int oh, int ow, int kh, int kw) {
-  int ih, iw;
-  if (g.mode == 2) {
+// A row (in pixels of the A grid) that output pixel (n, oh, ow) reads for tap (kh, kw), and whether it exists (n < 0: a row past
+// the batch).  Branch-free -- the mode is a template argument, the tests are bit operations: with run-time branches here the
+// chunk loop was 169 basic blocks and every load sat behind one (round 6).
+template <int MODE>
+__device__ __forceinline__ long long a_row(const GArgs& g, int n, int oh, int ow, int kh, int kw, bool& ok) {
+  int ih, iw, bad = n;                                     // (bad < 0 <=> the row does not exist)
+  if constexpr (MODE == 2) {
     const int a = oh + 1 - kh, b = ow + 1 - kw;
-    if ((a | b) < 0 || (a & 1) || (b & 1)) return -1;
+    bad |= a | b | -((a | b) & 1);                         // negative, or odd
     ih = a >> 1; iw = b >> 1;
   } else {
-    const int s = g.mode == 1 ? 2 : 1;
+    constexpr int s = MODE == 1 ? 2 : 1;
     ih = oh * s + kh - 1; iw = ow * s + kw - 1;
   }
-  if (ih < 0 || iw < 0 || ih >= g.Ha || iw >= g.Wa) return -1;
-  return ((long long)n * g.Ha + ih) * g.Wa + iw;
+  bad |= ih | iw | (g.Ha - 1 - ih) | (g.Wa - 1 - iw);
+  ok = bad >= 0;
+  const long long row = ((long long)n * g.Ha + ih) * g.Wa + iw;
+  return ok ? row : 0;
 }
 
 // 128 output pixels x 64 output channels per workgroup, K = (tap, 32 channels) chunks; see k_sc_gemm (t2o_conv1x1.hip) for
 // the LDS layout (16-byte chunks swizzled by row, one conflict-free ds_read_b128 = four k-steps of a lane).
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
   __shared__ float4 As[2][128 * 8];
   __shared__ float4 Bs[2][64 * 8];
@@ -100,8 +106,13 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const long long r = pn[j] < 0 ? -1 : a_row(g, pn[j], poh[j], pow_[j], kh, kw);
-      ra[S][j] = r < 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : ld4(g.A + (size_t)r * g.K + cc * 32 + lc * 4);
+      // (the load is ISSUED for every lane -- row 0 stands in for a padding / parity / out-of-batch row -- and the value
+      // selected afterwards: a load under a branch makes the compiler wait for everything outstanding at the next use,
+      // and the two chunks in flight became one again)
+      bool ok;
+      const long long r = a_row<MODE>(g, pn[j], poh[j], pow_[j], kh, kw, ok);
+      const float4 v = ld4(g.A + (size_t)r * g.K + cc * 32 + lc * 4);
+      ra[S][j] = ok ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     rb[S][0] = ld4(g.B + brow0 + (size_t)tap * g.K + cc * 32);
     rb[S][1] = ld4(g.B + brow1 + (size_t)tap * g.K + cc * 32);
@@ -263,7 +274,10 @@ int launch(const float* A, const float* B, const float* addend, float* C, int N,
   GArgs g;
   g.A = A; g.B = B; g.addend = addend; g.C = C; g.N = N; g.Ha = Ha; g.Wa = Wa; g.Hc = Hc; g.Wc = Wc; g.K = K; g.Ncols = Ncols; g.mode = mode;
   g.tiles_m = (N * Hc * Wc + 127) / 128; g.tiles_n = Ncols / 64;
-  k_gconv<<<(unsigned)(((g.tiles_m + 7) / 8) * 8 * g.tiles_n), kThreads, 0, st>>>(g);
+  const unsigned grid = (unsigned)(((g.tiles_m + 7) / 8) * 8 * g.tiles_n);
+  if (g.mode == 2) k_gconv<2><<<grid, kThreads, 0, st>>>(g);
+  else if (g.mode == 1) k_gconv<1><<<grid, kThreads, 0, st>>>(g);
+  else k_gconv<0><<<grid, kThreads, 0, st>>>(g);
   return hipGetLastError() == hipSuccess ? T2O_OK : T2O_ELAUNCH;
 }
 

@@ -55,6 +55,7 @@ for mode in ('eval', 'train'):
         rel = np.abs(gn - ref) / np.maximum(ref, 1e-30)
         order = [i for i in np.argsort(-rel) if big[i]][:6]
         print(p, 'largest gradient-norm deviations:', ', '.join('%s %.3g' % (names[i], rel[i]) for i in order))
+        print(p, 'gradient norms off by > 1e-3: %d, > 1e-4: %d, of %d' % (int((rel[big] > 1e-3).sum()), int((rel[big] > 1e-4).sum()), int(big.sum())))
         import hashlib
         flat = torch.cat([params[n].grad.reshape(-1) for n in names if params[n].grad is not None and 'embedding' not in n])
         print(p, 'sha256 of all non-embedding gradients (box independence):', hashlib.sha256(flat.cpu().numpy().tobytes()).hexdigest()[:16])
