@@ -317,7 +317,7 @@ def lang_encoder(sd, tokens, opt, training=False, prefix='lang_encoder.'):
     ws = _lstm_weights(sd, prefix + 'rnn.', opt.n_layers, bool(opt.bidirectional))
     B = tokens.size(0)
     nd = 2 if opt.bidirectional else 1
-    zeros = torch.zeros(opt.n_layers * nd, B, opt.hidden_size)
+    zeros = torch.zeros(opt.n_layers * nd, B, opt.hidden_size, dtype=emb.dtype, device=emb.device)     # (fp64 runs of the oracle: tools/measure_parity.py)
     out, h, c = torch._VF.lstm(packed.data, packed.batch_sizes, (zeros, zeros), ws, True,
                                opt.n_layers, opt.dropout_p, training, bool(opt.bidirectional))
     out = torch.nn.utils.rnn.PackedSequence(out, packed.batch_sizes)

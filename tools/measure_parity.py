@@ -59,6 +59,27 @@ for mode in ('eval', 'train'):
         import hashlib
         flat = torch.cat([params[n].grad.reshape(-1) for n in names if params[n].grad is not None and 'embedding' not in n])
         print(p, 'sha256 of all non-embedding gradients (box independence):', hashlib.sha256(flat.cpu().numpy().tobytes()).hexdigest()[:16])
+    if mode == 'train':
+        # Which side is right?  The oracle in fp64 on the host (the same network, exact to ~1e-15): its gradient norms against (a)
+        # this library's fp32 kernels and (b) the reference's own fp32 run (the golden).  If both fp32 executions sit at comparable
+        # distances from the fp64 values, their distance from EACH OTHER is what fp32 does to this 4-image fixture, not an error of
+        # either.
+        def oracle_norms(dt):
+            sd = {k: (v.detach().cpu().to(dt) if torch.is_floating_point(v) else v.detach().cpu()) for k, v in model.state_dict().items()}
+            sd = cpu_ref.make_leaf_params(sd)
+            r = cpu_ref.episode_forward(sd, x.cpu(), img.cpu().to(dt), opt, reinforce_sample=0, training=True)
+            same = bool((r['pred_ops'].numpy() == gold[p + 'pred_ops']).all())
+            cpu_ref.l1_loss(cpu_ref.select_end_images(r['pred_imgs'], r['pred_ops'], opt.end_id), tgt.cpu().to(dt)).backward()
+            return same, np.array([0.0 if sd[n].grad is None else sd[n].grad.double().norm().item() for n in names])
+        same64, g64 = oracle_norms(torch.float64)
+        same32, g32 = oracle_norms(torch.float32)
+
+        def dist(v):
+            d = np.abs(v - g64) / np.maximum(g64, 1e-30)
+            return 'max %.3g median %.3g' % (d[big].max(), np.median(d[big]))
+        print(p, 'operators of the fp64 / fp32 oracle equal the golden\'s: %s / %s' % (same64, same32))
+        print(p, 'gradient norms against the fp64 oracle -- this library (GPU, fp32): %s; the reference\'s fp32 run (golden): %s; '
+                 'the oracle itself in fp32 on this host: %s' % (dist(gn), dist(ref), dist(g32)))
     # supervised
     model, opt = make_model(dev)
     model.train(mode == 'train')
