@@ -65,24 +65,28 @@ __device__ __forceinline__ long long a_row(const GArgs& g, int n, int oh, int ow
   return ok ? row : 0;
 }
 
-// 128 output pixels x 64 output channels per workgroup, K = (tap, 32 channels) chunks; see k_sc_gemm (t2o_conv1x1.hip) for
-// the LDS layout (16-byte chunks swizzled by row, one conflict-free ds_read_b128 = four k-steps of a lane).
-template <int MODE>
+// TM output pixels x 64 output channels per workgroup, K = (tap, 32 channels) chunks; see k_sc_gemm (t2o_conv1x1.hip) for
+// the LDS layout (16-byte chunks swizzled by row, one conflict-free ds_read_b128 = four k-steps of a lane).  TM = 128: a wave owns
+// 32 pixels x 64 channels (two MFMA blocks); TM = 64: 32 x 32 (one block) -- twice the workgroups where 128-pixel tiles leave CUs
+// idle (the 256 -> 512 stride-2 layer of a 128 x 128 image: 64 of them for 256 CUs, round 6).  The same sums in the same order.
+template <int MODE, int TM>
 __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
-  __shared__ float4 As[2][128 * 8];
+  constexpr int RJ = TM / 32, NB = TM / 64;               // A pieces per thread; MFMA blocks per wave
+  __shared__ float4 As[2][TM * 8];
   __shared__ float4 Bs[2][64 * 8];
   const int b = blockIdx.x;
   const int xcd = b % 8, k8 = b / 8;
   const int rt = (k8 / g.tiles_n) * 8 + xcd, ct = k8 % g.tiles_n;
   if (rt >= g.tiles_m) return;
   const int Q = g.N * g.Hc * g.Wc;
-  const int q0 = rt * 128, n0 = ct * 64;
+  const int q0 = rt * TM, n0 = ct * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, lh = lane >> 5;
+  const int wrow = TM == 128 ? wave : (wave >> 1), wcol = TM == 128 ? 0 : (wave & 1);     // this wave's 32-pixel row block, first column block
   const int lrow = tid >> 3, lc = tid & 7;
   const int lswz = (lrow >> 1) & 7;
-  int pn[4], poh[4], pow_[4];
+  int pn[RJ], poh[RJ], pow_[RJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < RJ; ++j) {
     const int q = q0 + lrow + 32 * j;
     if (q < Q) {
       const int hw = g.Hc * g.Wc;
@@ -99,13 +103,13 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
   // Two chunks travel in registers (sets 0 / 1) while a third is multiplied out of LDS: with ONE in flight the loop was a chain of
   // global round trips -- 1.7 us per chunk, 125 us for the 72 chunks of the 256 -> 512 stride-2 layer of a 128 x 128 image whose
   // matrix work is 15 us (round 6, profiles/r06_step128_kernel_stats.csv: 10 launches, 1.95 ms of an 18 ms step).
-  float4 ra[2][4], rb[2][2];
+  float4 ra[2][RJ], rb[2][2];
   auto gload = [&](auto sc, int kc) {
     constexpr int S = decltype(sc)::value;
     const int tap = kc / chunks, cc = kc - tap * chunks;
     const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RJ; ++j) {
       // (the load is ISSUED for every lane -- row 0 stands in for a padding / parity / out-of-batch row -- and the value
       // selected afterwards: a load under a branch makes the compiler wait for everything outstanding at the next use,
       // and the two chunks in flight became one again)
@@ -120,28 +124,32 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
   auto sstore = [&](auto sc, int buf) {
     constexpr int S = decltype(sc)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) As[buf][(lrow + 32 * j) * 8 + (lc ^ lswz)] = ra[S][j];
+    for (int j = 0; j < RJ; ++j) As[buf][(lrow + 32 * j) * 8 + (lc ^ lswz)] = ra[S][j];
 #pragma unroll
     for (int j = 0; j < 2; ++j) Bs[buf][(lrow + 32 * j) * 8 + (lc ^ lswz)] = rb[S][j];
   };
-  f32x16 acc[2];
+  f32x16 acc[NB];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-  const int frow = wave * 32 + ln, fswz = (ln >> 1) & 7;
+  const int frow = wrow * 32 + ln, fswz = (ln >> 1) & 7;
   auto compute = [&](int buf) {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int pos = (2 * gq + lh) ^ fswz;
       const float4 a = As[buf][frow * 8 + pos];
-      const float4 b0 = Bs[buf][ln * 8 + pos], b1 = Bs[buf][(32 + ln) * 8 + pos];
-      const float av[4] = {a.x, a.y, a.z, a.w}, bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      float bv[NB][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv0[s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv1[s], acc[1], 0, 0, 0);
+      for (int nb = 0; nb < NB; ++nb) {
+        const float4 b = Bs[buf][((wcol + nb) * 32 + ln) * 8 + pos];
+        bv[nb][0] = b.x; bv[nb][1] = b.y; bv[nb][2] = b.z; bv[nb][3] = b.w;
       }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[nb][s], acc[nb], 0, 0, 0);
     }
   };
   constexpr std::integral_constant<int, 0> S0{};
@@ -178,13 +186,13 @@ __global__ __launch_bounds__(kThreads) void k_gconv(GArgs g) {
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int q = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int q = q0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     if (q < Q) {
-      const size_t o = (size_t)q * g.Ncols + n0 + ln;
-      float v0 = acc[0][r], v1 = acc[1][r];
-      if (g.addend) { v0 += g.addend[o]; v1 += g.addend[o + 32]; }
-      g.C[o] = v0;
-      g.C[o + 32] = v1;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const size_t o = (size_t)q * g.Ncols + n0 + (wcol + nb) * 32 + ln;
+        g.C[o] = g.addend ? acc[nb][r] + g.addend[o] : acc[nb][r];
+      }
     }
   }
 }
@@ -273,11 +281,20 @@ int launch(const float* A, const float* B, const float* addend, float* C, int N,
            int mode, hipStream_t st) {
   GArgs g;
   g.A = A; g.B = B; g.addend = addend; g.C = C; g.N = N; g.Ha = Ha; g.Wa = Wa; g.Hc = Hc; g.Wc = Wc; g.K = K; g.Ncols = Ncols; g.mode = mode;
-  g.tiles_m = (N * Hc * Wc + 127) / 128; g.tiles_n = Ncols / 64;
+  g.tiles_n = Ncols / 64;
+  const int Q = N * Hc * Wc;
+  const bool small = (long long)((Q + 127) / 128) * g.tiles_n < 256;       // 128-pixel tiles would leave CUs idle: 64-pixel ones
+  g.tiles_m = small ? (Q + 63) / 64 : (Q + 127) / 128;
   const unsigned grid = (unsigned)(((g.tiles_m + 7) / 8) * 8 * g.tiles_n);
-  if (g.mode == 2) k_gconv<2><<<grid, kThreads, 0, st>>>(g);
-  else if (g.mode == 1) k_gconv<1><<<grid, kThreads, 0, st>>>(g);
-  else k_gconv<0><<<grid, kThreads, 0, st>>>(g);
+#define T2O_GCONV(M)                                                        \
+  do {                                                                      \
+    if (small) k_gconv<M, 64><<<grid, kThreads, 0, st>>>(g);                \
+    else k_gconv<M, 128><<<grid, kThreads, 0, st>>>(g);                     \
+  } while (0)
+  if (g.mode == 2) T2O_GCONV(2);
+  else if (g.mode == 1) T2O_GCONV(1);
+  else T2O_GCONV(0);
+#undef T2O_GCONV
   return hipGetLastError() == hipSuccess ? T2O_OK : T2O_ELAUNCH;
 }
 
