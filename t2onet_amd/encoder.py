@@ -125,6 +125,16 @@ class TrunkPlan:
         'wino_fused' (t2o_wino_fused.hip, forward / data gradient), 'wino_wgrad' (t2o_wino_wgrad.hip), 'wino_sep' (the separate-pass
         pipeline of t2o_winograd.hip: transforms + 16 GEMMs), 'direct' (t2o_conv.hip, LDS-DMA implicit GEMM), 'generic'
         (t2o_conv_generic.hip, gathered rows)."""
+        # (memoised: the schedule asks ~60 times per encoder pass, and every answer costs C-ABI `*_supported` calls; the module
+        # switches the tests flip are part of the key)
+        key = (id(conv), N, Hi, Wi, direction, _WINOGRAD, _WINO_MIN_C, _WINO_FUSED, _WINO_WGRAD)
+        memo = self.__dict__.setdefault('_kernel_memo', {})
+        fam = memo.get(key)
+        if fam is None:
+            fam = memo[key] = self._kernel_for(conv, N, Hi, Wi, direction)
+        return fam
+
+    def _kernel_for(self, conv, N, Hi, Wi, direction):
         w = conv.weight
         Co, Ci = w.shape[0], w.shape[1]
         s = conv.stride[0]
@@ -476,7 +486,7 @@ class _TrunkFn(torch.autograd.Function):
             s = conv.stride[0]
             Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
             if plan.wino(conv, Hi, Wi):
-                if plan.onchip_wgrad(conv, Hi, Wi):            # forward, data and weight gradient all on chip: V is never formed
+                if plan.kernel_for(conv, Nn, Hi, Wi, 'wgrad') == 'wino_wgrad':     # forward, data and weight gradient all on chip: V is never formed
                     return wino_fused_conv_nhwc(x, uf[('c', id(conv))], Nn, Hi, Wi, None, True)
                 keep = []
                 y, stats = wino_conv_nhwc(x, uf[id(conv)], Nn, Hi, Wi, None, True, keep_v=keep,
@@ -685,7 +695,7 @@ class _TrunkFn(torch.autograd.Function):
                 dy2, dsc = bn_bwd(b.bn2, rec['y2'], rec['out'], d, rec['m2'], rec['i2'], 1, 1, True, M, Co, slot2)
             da1 = torch.empty_like(rec['a1'])
             rows1 = None                                   # bn1's backward sums, when conv2's data gradient leaves them
-            if plan.wino(b.conv2, Hn, Wn) and not plan.onchip_wgrad(b.conv2, Hn, Wn):
+            if plan.wino(b.conv2, Hn, Wn) and plan.kernel_for(b.conv2, N, Hn, Wn, 'wgrad') != 'wino_wgrad':
                 wino_bwd(b.conv2, rec['a1'], dy2, da1, None, Hn, Wn)
             else:
                 C2o, C2i = b.conv2.weight.shape[0], b.conv2.weight.shape[1]
@@ -723,7 +733,7 @@ class _TrunkFn(torch.autograd.Function):
                 dy1, _ = bn_bwd(b.bn1, rec['y1'], None, da1, rec['m1'], rec['i1'], 0, 1, False, M, Co, slot1)
             del da1
             dx = torch.empty_like(rec['x'])
-            if plan.wino(b.conv1, Hc, Wc) and not len(b.shortcut) and not plan.onchip_wgrad(b.conv1, Hc, Wc):
+            if plan.wino(b.conv1, Hc, Wc) and not len(b.shortcut) and plan.kernel_for(b.conv1, N, Hc, Wc, 'wgrad') != 'wino_wgrad':
                 wino_bwd(b.conv1, rec['x'], dy1, dx, dsc, Hc, Wc)
                 d = dx
                 continue

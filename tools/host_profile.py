@@ -15,7 +15,8 @@ model.use_channels_last()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 tr = Trainer(model, opt, graph_encoder=False, graph_step=False)
 g = torch.Generator().manual_seed(10)
-B, H, W = 64, 256, 256
+B = int(os.environ.get('T2O_BATCH', '64'))
+H = W = int(os.environ.get('T2O_SIZE', '256'))      # T2O_BATCH=2: the GPU work is negligible, what is timed is the host's own work
 img = torch.rand(B, 3, H, W, generator=g).to(dev)
 tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
 x = bench.synthetic_requests(B, g)
