@@ -38,9 +38,6 @@ _BN_SUMS_EPILOGUE = True     # bn1's backward sums from the epilogue of conv2's 
 # the weight gradient of the on-chip Winograd layers in the Winograd domain too, both transforms on chip (t2o_wino_wgrad.hip);
 # T2O_WINOGRAD_WGRAD=0: the direct weight-gradient kernel there (A/B)
 _WINO_WGRAD = os.environ.get('T2O_WINOGRAD_WGRAD', '1') != '0'
-# the once-per-step weight gradients (WgradArena.flush) dealt over this many streams (1: all on the caller's)
-_FLUSH_STREAMS = int(os.environ.get('T2O_FLUSH_STREAMS', '1'))
-_FLUSH_SIDE = {}        # device -> the second stream (module state: a deep copy of a model must not meet a stream)
 
 
 def _fast_direct(stride, Hi, Wi, Wo):
@@ -398,7 +395,7 @@ class WgradArena:
                 else:
                     runs.append([p, 1])
             return runs
-        def one_layer(kind, conv, xkey, Hi, Wi, Hn, Wn):
+        for kind, conv, xkey, Hi, Wi, Hn, Wn in self.layers:
             w = conv.weight
             Co, Ci = w.shape[0], w.shape[1]
             dev = w.device
@@ -431,7 +428,7 @@ class WgradArena:
                     ws = torch.empty(need, dtype=torch.uint8, device=dev)
                     rc = lib.t2o_conv1x1s2_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(w.grad), _ptr(ws), need, n, Hi, Wi, Ci, Co, 1, st)
                     _lib.check(rc, 't2o_conv1x1s2_wgrad_nhwc')
-        def one_wino(conv, Hi, Wi, Tpad):
+        for conv, Hi, Wi, Tpad in self.wino:
             V, Ad, dw = self.V[id(conv)], self.Ad[id(conv)], conv.weight.grad
             for first, count in runs_of(self.rec.get(id(conv), ())):
                 # a run of passes = a row range of every plane: ONE batch of GEMMs over its tiles (a step that made fewer passes
@@ -439,26 +436,6 @@ class WgradArena:
                 rows = slice(first * Tpad, (first + count) * Tpad)
                 if not wino_dw_from(Ad[:, rows], V[:, rows], dw, True):
                     raise RuntimeError('WgradArena: no split for the Winograd weight gradient of %d tiles' % (count * Tpad))
-        jobs = [(one_layer, args) for args in self.layers] + [(one_wino, args) for args in self.wino]
-        if _FLUSH_STREAMS > 1 and jobs and plan.params[0].is_cuda:
-            # the layers' weight gradients are independent of one another: dealt over two streams, a kernel's tail (its last,
-            # partly filled round of workgroups) and the small fixed-order reduce launches run beside the next layer's kernel
-            dev = plan.params[0].device
-            main = torch.cuda.current_stream(dev)
-            side = _FLUSH_SIDE.get(dev)
-            if side is None:
-                side = _FLUSH_SIDE[dev] = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)
-            for i, (fn, args) in enumerate(jobs):
-                if i % 2:
-                    with torch.cuda.stream(side):
-                        fn(*args)
-                else:
-                    fn(*args)
-            main.wait_stream(side)
-        else:
-            for fn, args in jobs:
-                fn(*args)
         self.begin()
 
 
