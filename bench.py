@@ -606,11 +606,11 @@ def cpu_baselines(H, W, sample_cfg2=64, sample_cfg3=64, with_gpu_parity=True):
     # eager ops of this size: the probe must not be able to hold the benchmark up)
     try:
         n_probe = 8
-        allc = _cpu_probe_child(os.cpu_count() or 1, n_probe, H, W, 60)
-        fixed = _cpu_probe_child(threads, n_probe, H, W, 60)
+        allc = _cpu_probe_child(os.cpu_count() or 1, n_probe, H, W, 30)
+        fixed = _cpu_probe_child(threads, n_probe, H, W, 30)
         res['all_cores'] = {'threads': os.cpu_count(), 'images': n_probe, 'value': allc.get('value'), 'unit': 'images/sec',
                             'same_sample_at_fixed_threads': fixed.get('value'), 'fixed_threads': threads,
-                            'sample': 'the configs[2] step on %d images, 1 warm-up + 1 repetition, in a child process (60 s limit)' % n_probe}
+                            'sample': 'the configs[2] step on %d images, 1 warm-up + 1 repetition, in a child process (30 s limit)' % n_probe}
         for r_ in (allc, fixed):
             if 'error' in r_:
                 res['all_cores']['error'] = r_['error']
@@ -1307,7 +1307,7 @@ def main():
     ap.add_argument('--no-train', action='store_true',
                     help='executor legs only (profiling passes; the line then has no headline value)')
     ap.add_argument('--cpu-sample', type=int, default=64, help='images of the configs[1] CPU baseline')
-    ap.add_argument('--cpu-train-sample', type=int, default=32, help='images of the configs[2] CPU baseline (a bounded sample of the 64-image batch; 1 warm-up + 3 reps)')
+    ap.add_argument('--cpu-train-sample', type=int, default=64, help='images of the configs[2] CPU baseline (the headline\'s own batch; 1 warm-up + 3 reps, ~35 s on the MI355X host)')
     ap.add_argument('--train-timeout', type=int, default=600, help='seconds before the train-step leg is abandoned')
     ap.add_argument('--launch-timeout', type=int, default=1500, help='launcher: seconds before the ranks are stopped')
     ap.add_argument('--cpu-probe', default=None, help=argparse.SUPPRESS)

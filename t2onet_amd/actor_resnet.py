@@ -106,12 +106,14 @@ class ResNet(nn.Module):
 
     def _batch_counters(self):
         """num_batches_tracked of the batch norms that are in training mode (a layer frozen with bn.eval() keeps its count)."""
+        bns = self.__dict__.get('_bns')
+        if bns is None:                                      # (the module tree is fixed after construction: walked once, not per call)
+            bns = self.__dict__['_bns'] = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         cached = self.__dict__.get('_nbt')
-        key = tuple(m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        key = tuple(m.training for m in bns)
         if cached is None or cached[0] is not self.bn1.num_batches_tracked or cached[1] != key:      # (.to() replaces the buffer tensors)
             cached = self.__dict__['_nbt'] = (self.bn1.num_batches_tracked, key,
-                                              [m.num_batches_tracked for m in self.modules()
-                                               if isinstance(m, nn.BatchNorm2d) and m.training and m.track_running_stats])
+                                              [m.num_batches_tracked for m in bns if m.training and m.track_running_stats])
         return cached[2]
 
     def _make_layer(self, planes, num_blocks, stride):
