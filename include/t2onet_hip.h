@@ -656,8 +656,9 @@ int t2o_allreduce_mean(float* flat, size_t n, void* comm, void* stream);
  * actor_resnet.py:107).   C (M,N) = [C +] op(A) op(B), row-major, leading dimensions in floats:
  *   a_kmajor = 1: A is stored (K, M) (a "dy^T x" product sums over the rows of both operands), 0: (M, K);
  *   b_kmajor = 1: B is stored (K, N), 0: (N, K) (nn.Linear's weight).
- * Any M, N, K >= 1; operands / C may be column slices of larger matrices.  One workgroup per 64 x 64 tile walks K front to back:
- * the rounding depends on the shape only (no split-K, no atomics) -- bitwise the same on every run and machine.
+ * Any M, N, K >= 1; operands / C may be column slices of larger matrices.  One workgroup per 64 x 64 tile of C; its 1, 2 or 4
+ * contraction groups (chosen by K alone) walk their 32-deep chunks of K front to back and are added in group order: the rounding
+ * depends on the shape only (no split-K across workgroups, no atomics) -- bitwise the same on every run and machine.
  * t2o_colsum: out[n] = [out[n] +] sum over the rows of X (R, N) (bias gradients), fixed order. */
 int t2o_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kmajor, int b_kmajor,
              int accumulate, void* stream);
