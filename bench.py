@@ -1265,7 +1265,7 @@ def worker(args):
     watchdog.cancel()
     # EXTRA key (the headline stays configs[2]): the same step at the size the reference itself trains at -- 128 x 128 crops,
     # bs = 64 (README.md:91, datasets/FiveKdataset.py:25,68).  A quarter of the pixels: the encoder's maps are 32 x 32 ... 4 x 4.
-    if rc[0] == 0 and not args.quick and (H, W) == (256, 256) and world == 1:
+    if rc[0] == 0 and not args.quick and not args.no_128 and (H, W) == (256, 256) and world == 1:
         try:
             torch.cuda.empty_cache()
             t128 = train_step_bench(ctx, B, 128, 128, args.steps, max(args.warmup, 3), with_extras=False)
@@ -1304,6 +1304,7 @@ def main():
     ap.add_argument('--exec-warmup', type=int, default=20)
     ap.add_argument('--quick', action='store_true', help='skip the bs=256 and cfg5 executor legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-128', action='store_true', help='skip the extra train_step_128 leg (profiling passes: its shorter launches of the same kernels would mix into the per-kernel averages)')
     ap.add_argument('--no-train', action='store_true',
                     help='executor legs only (profiling passes; the line then has no headline value)')
     ap.add_argument('--cpu-sample', type=int, default=64, help='images of the configs[1] CPU baseline')

@@ -35,7 +35,7 @@ for stage in "$@"; do
       tail -n 1 $OUT/bench.json | wc -c; python tools/bench_summary.py $OUT/bench.json $OUT/bench_detail.json | head -60; tail -n 3 $OUT/bench.err ;;
     benchprof)
       cd /tmp
-      timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python $ROOT/bench.py --no-cpu-baseline $arg > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof.err; echo "rocprof rc=$?"
+      timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -- python $ROOT/bench.py --no-cpu-baseline --no-128 $arg > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof.err; echo "rocprof rc=$?"
       cd $ROOT
       find $OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} cp {} $OUT/bench_kernel_stats.csv
       rm -rf $OUT/prof; head -n 14 $OUT/bench_kernel_stats.csv | cut -c1-160 ;;
