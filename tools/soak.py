@@ -1,4 +1,5 @@
 """Soak run of the episode train step (configs[1]: bs 64, 256x256): python tools/soak.py [steps=600] [graph_step 0|1] [window=100] [batches=3] [graph_encoder 0|1]
+(T2O_SOAK_ALTERNATE=1: the reference's alternation instead -- teacher-forced and episode steps in turn, train_seq2seqL1.py:51-92.)
 
 Per window of steps: ms/step, the caching allocator's allocated / reserved bytes and the device's free memory (hipMemGetInfo).
 The run FAILS (exit 1) when device memory in use keeps growing after the first window, when a window is more than 5 % slower
@@ -32,9 +33,32 @@ for _ in range(nb):                                            # different batch
     tgt = torch.rand(B, 3, H, W, generator=g).to(dev)
     x = bench.synthetic_requests(B, g)
     batches.append((x.to(dev), img, tgt, (x != 0).sum(1)))
-for i in range(6):
+alternate = os.environ.get('T2O_SOAK_ALTERNATE', '0') != '0'
+sup = []
+if alternate:                                                  # teacher-forced inputs per batch, as bench.py builds them
+    npar = {3: 1, 4: 1, 5: 1, 6: 24, 8: 8, 9: 1}
+    for _ in range(nb):
+        ops_t = torch.stack([torch.randperm(6, generator=g)[:5] for _ in range(B)])
+        y = torch.cat([torch.full((B, 1), 1), torch.tensor([3, 4, 5, 6, 8, 9])[ops_t], torch.full((B, 1), 2)], 1)
+        img_y = torch.rand(B, 6, 3, H, W, generator=g).to(dev)
+        gt = torch.rand(B, 5, 24, generator=g) * 2 - 1
+        for b_ in range(B):
+            for k_ in range(5):
+                gt[b_, k_, npar[int(y[b_, k_ + 1])]:] = 0
+        sup.append((y.to(dev), img_y, gt.to(dev)))
+
+
+def one_step(i):
     x, img, tgt, lengths = batches[i % nb]
-    tr.episode_step(x, img, tgt, lengths=lengths)
+    if alternate and i % 2 == 0:
+        y, img_y, gt = sup[i % nb]
+        op_loss, param_loss = tr.supervised_step(x, y, img, img_y, gt, lengths=lengths)
+        return op_loss + param_loss
+    return tr.episode_step(x, img, tgt, lengths=lengths)
+
+
+for i in range(6):
+    one_step(i)
 torch.cuda.synchronize()
 
 rows, ok = [], True
@@ -43,8 +67,7 @@ while done < steps:
     n = min(window, steps - done)
     t0 = time.perf_counter()
     for i in range(n):
-        x, img, tgt, lengths = batches[(done + i) % nb]
-        out = tr.episode_step(x, img, tgt, lengths=lengths)
+        out = one_step(done + i)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     done += n
